@@ -1,0 +1,95 @@
+"""ctypes binding of libbevfusion_amd.so (C ABI declared in include/bevfusion_amd.h).
+
+This is the only place the shared library is loaded.  There is NO fallback: if the
+library is missing or a symbol cannot be resolved, importing a product op raises.
+PyTorch is used by callers for device memory and streams only.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbevfusion_amd.so")
+
+_lib = None
+
+P = c_void_p
+I = c_int
+Z = c_size_t
+
+# name -> (restype, argtypes); must list every function of include/bevfusion_amd.h
+_SIGNATURES = {
+    "bevamd_last_error": (c_char_p, []),
+    # bev_pool
+    "bevamd_bev_pool_forward": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_forward_bf16": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_backward": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_prepare_workspace_bytes": (Z, [I, I, I, I, I]),
+    "bevamd_bev_pool_prepare": (I, [P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, Z, P]),
+    "bevamd_bev_pool_prepare_from_geom": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, Z, P]),
+    "bevamd_bev_pool_forward_cells": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    # primitives
+    "bevamd_scan_workspace_bytes": (Z, [Z]),
+    "bevamd_exclusive_scan_u32": (I, [P, P, Z, P, P, Z, P]),
+    "bevamd_radix_sort_workspace_bytes": (Z, [Z]),
+    "bevamd_radix_sort_pairs_u32": (I, [P, P, P, P, Z, I, P, Z, P]),
+}
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library handle; raise loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). "
+            "Build it with `python -m bevfusion_amd.build` or `__graft_entry__.build()`."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise NativeLibraryMissing(f"symbol {name} missing from {LIB_PATH}: rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return list(_SIGNATURES)
+
+
+def last_error():
+    return load().bevamd_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"bevfusion_amd {what} failed (code {rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    """The HIP stream PyTorch is currently using on `device`, as void*."""
+    import torch
+
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def float3(values):
+    arr = (c_float * 3)(*[float(v) for v in values])
+    return arr

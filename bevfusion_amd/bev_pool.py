@@ -1,0 +1,250 @@
+"""bev_pool — host-side mirror of `mmdet3d/ops/bev_pool/bev_pool.py` over the HIP C ABI.
+
+Reference interface reproduced here (same names, argument order, shapes):
+  * `bev_pool_ext.bev_pool_forward / bev_pool_backward`  (bev_pool_cpu.cpp:22-28,60-66, :89-94)
+  * `QuickCumsumCuda`                                     (bev_pool.py:37-80)
+  * `bev_pool(feats, coords, B, D, H, W) -> [B, C, D, H, W]`  (bev_pool.py:83-97)
+
+MI355X-native additions: `BevPoolPlan` (the rank/sort/interval precompute as a cached,
+sync-free device object) and the indexed kernels that read features through the sort
+permutation instead of materialising `feats[indices]`.
+"""
+import torch
+
+from . import _capi
+
+__all__ = ["bev_pool", "bev_pool_ext", "QuickCumsumCuda", "BevPoolPlan"]
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: the HIP extension has no CPU path")
+
+
+class _BevPoolExt:
+    """Drop-in for the reference's pybind module `bev_pool_ext`."""
+
+    @staticmethod
+    def bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, b, d, h, w):
+        _require_cuda(x, "x")
+        lib = _capi.load()
+        b, d, h, w = int(b), int(d), int(h), int(w)
+        n, c = x.shape
+        out = torch.empty((b, d, h, w, c), dtype=torch.float32, device=x.device)
+        geom_feats = geom_feats.contiguous()
+        interval_lengths = interval_lengths.contiguous()
+        interval_starts = interval_starts.contiguous()
+        if geom_feats.dtype != torch.int32 or interval_lengths.dtype != torch.int32 or interval_starts.dtype != torch.int32:
+            raise RuntimeError("geom_feats / interval_lengths / interval_starts must be int32")
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            if x.dtype == torch.float32:
+                fn = lib.bevamd_bev_pool_forward
+            elif x.dtype == torch.bfloat16:
+                fn = lib.bevamd_bev_pool_forward_bf16
+            else:
+                raise RuntimeError(f"bev_pool_forward: unsupported dtype {x.dtype}")
+            rc = fn(_capi.ptr(x), _capi.ptr(geom_feats), _capi.ptr(interval_lengths), _capi.ptr(interval_starts),
+                    _capi.ptr(out), n, c, interval_lengths.shape[0], b, d, h, w, _capi.stream_ptr(x.device))
+        _capi.check(rc, "bev_pool_forward")
+        return out
+
+    @staticmethod
+    def bev_pool_backward(out_grad, geom_feats, interval_lengths, interval_starts, b, d, h, w):
+        _require_cuda(out_grad, "out_grad")
+        lib = _capi.load()
+        b, d, h, w = int(b), int(d), int(h), int(w)
+        out_grad = out_grad.contiguous().float()
+        n = geom_feats.shape[0]
+        c = out_grad.shape[4]
+        x_grad = torch.empty((n, c), dtype=torch.float32, device=out_grad.device)
+        with torch.cuda.device(out_grad.device):
+            rc = lib.bevamd_bev_pool_backward(
+                _capi.ptr(out_grad), _capi.ptr(geom_feats.contiguous()), _capi.ptr(interval_lengths.contiguous()),
+                _capi.ptr(interval_starts.contiguous()), _capi.ptr(x_grad), n, c, interval_lengths.shape[0],
+                b, d, h, w, 0, _capi.stream_ptr(out_grad.device))
+        _capi.check(rc, "bev_pool_backward")
+        return x_grad
+
+
+bev_pool_ext = _BevPoolExt()
+
+
+class QuickCumsumCuda(torch.autograd.Function):
+    """Same contract as the reference class (bev_pool.py:37-80): sorted feats/coords/ranks in,
+    dense [B, D, H, W, C] out.  Interval boundaries are found on the host side of the op exactly
+    as the reference does (torch ops; one D2H sync in torch.where)."""
+
+    @staticmethod
+    def forward(ctx, x, geom_feats, ranks, B, D, H, W):
+        kept = torch.ones(x.shape[0], device=x.device, dtype=torch.bool)
+        kept[1:] = ranks[1:] != ranks[:-1]
+        interval_starts = torch.where(kept)[0].int()
+        interval_lengths = torch.zeros_like(interval_starts)
+        interval_lengths[:-1] = interval_starts[1:] - interval_starts[:-1]
+        interval_lengths[-1] = x.shape[0] - interval_starts[-1]
+        geom_feats = geom_feats.int()
+        out = bev_pool_ext.bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, B, D, H, W)
+        ctx.save_for_backward(interval_starts, interval_lengths, geom_feats)
+        ctx.saved_shapes = B, D, H, W
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        interval_starts, interval_lengths, geom_feats = ctx.saved_tensors
+        B, D, H, W = ctx.saved_shapes
+        out_grad = out_grad.contiguous()
+        x_grad = bev_pool_ext.bev_pool_backward(out_grad, geom_feats, interval_lengths, interval_starts, B, D, H, W)
+        return x_grad, None, None, None, None, None, None
+
+
+class BevPoolPlan:
+    """Device-resident result of the bev_pool precompute (rank -> stable sort -> cell CSR).
+
+    Built once per camera calibration and reused every frame at inference; building it never
+    synchronises with the host.  Holds `order` (sorted row -> input row), `ranks_sorted` and the
+    CSR `cell_start` over rank-ordered cells; the reference-shaped interval arrays are optional
+    (`want_intervals`) and exist for API parity / tests.
+    """
+
+    def __init__(self, n, B, D, H, W, device, want_intervals, want_geom):
+        self.n, self.B, self.D, self.H, self.W = int(n), int(B), int(D), int(H), int(W)
+        self.device = device
+        self.ncells = self.B * self.D * self.H * self.W
+        n_alloc = max(self.n, 1)
+        self.ranks_sorted = torch.empty(n_alloc, dtype=torch.int32, device=device)
+        self.order = torch.empty(n_alloc, dtype=torch.int32, device=device)
+        self.cell_start = torch.empty(self.ncells + 2, dtype=torch.int32, device=device)
+        self.interval_starts = self.interval_lengths = self.n_intervals_dev = self.geom_sorted = None
+        if want_intervals:
+            cap = max(min(self.n, self.ncells), 1)
+            self.interval_starts = torch.empty(cap, dtype=torch.int32, device=device)
+            self.interval_lengths = torch.empty(cap, dtype=torch.int32, device=device)
+            self.n_intervals_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        if want_geom:
+            self.geom_sorted = torch.empty((n_alloc, 4), dtype=torch.int32, device=device)
+
+    def _workspace(self, lib):
+        nbytes = lib.bevamd_bev_pool_prepare_workspace_bytes(self.n, self.B, self.D, self.H, self.W)
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device), nbytes
+
+    # -- builders ---------------------------------------------------------------------------
+    @classmethod
+    def from_coords(cls, coords, B, D, H, W, want_intervals=False, want_geom=False):
+        """coords: [N, 4] (x, y, z, b), int32 or int64 — the tensor `bev_pool()` receives."""
+        _require_cuda(coords, "coords")
+        lib = _capi.load()
+        if coords.dtype not in (torch.int32, torch.int64):
+            coords = coords.long()
+        coords = coords.contiguous()
+        plan = cls(coords.shape[0], B, D, H, W, coords.device, want_intervals, want_geom)
+        with torch.cuda.device(coords.device):
+            ws, ws_bytes = plan._workspace(lib)
+            rc = lib.bevamd_bev_pool_prepare(
+                _capi.ptr(coords), int(coords.dtype == torch.int64), plan.n, plan.B, plan.D, plan.H, plan.W,
+                _capi.ptr(plan.ranks_sorted), _capi.ptr(plan.order), _capi.ptr(plan.cell_start),
+                _capi.ptr(plan.interval_starts), _capi.ptr(plan.interval_lengths), _capi.ptr(plan.n_intervals_dev),
+                _capi.ptr(plan.geom_sorted), _capi.ptr(ws), ws_bytes, _capi.stream_ptr(coords.device))
+        _capi.check(rc, "bev_pool_prepare")
+        return plan
+
+    @classmethod
+    def from_geometry(cls, geom_xyz, batch, bx_minus_half_dx, dx, nx, want_intervals=False, want_geom=False):
+        """geom_xyz: [N', 3] fp32 frustum points in the lidar frame (batch-major), unfiltered.
+        Implements vtransforms/base.py:149-169 (truncation, batch index, range mask) + the
+        prologue of bev_pool.py:83-93 in one device pipeline."""
+        _require_cuda(geom_xyz, "geom_xyz")
+        lib = _capi.load()
+        geom_xyz = geom_xyz.contiguous().float()
+        H, W, D = int(nx[0]), int(nx[1]), int(nx[2])
+        plan = cls(geom_xyz.shape[0], batch, D, H, W, geom_xyz.device, want_intervals, want_geom)
+        o = _capi.float3(bx_minus_half_dx)
+        s = _capi.float3(dx)
+        with torch.cuda.device(geom_xyz.device):
+            ws, ws_bytes = plan._workspace(lib)
+            rc = lib.bevamd_bev_pool_prepare_from_geom(
+                _capi.ptr(geom_xyz), plan.n, plan.B, plan.D, plan.H, plan.W, o, s,
+                _capi.ptr(plan.ranks_sorted), _capi.ptr(plan.order), _capi.ptr(plan.cell_start),
+                _capi.ptr(plan.interval_starts), _capi.ptr(plan.interval_lengths), _capi.ptr(plan.n_intervals_dev),
+                _capi.ptr(plan.geom_sorted), _capi.ptr(ws), ws_bytes, _capi.stream_ptr(geom_xyz.device))
+        _capi.check(rc, "bev_pool_prepare_from_geom")
+        return plan
+
+    # -- host-visible scalars (these DO synchronise; for tests and the reference-shaped API) ---
+    def n_intervals(self):
+        if self.n_intervals_dev is None:
+            raise RuntimeError("plan was built without want_intervals=True")
+        return int(self.n_intervals_dev.item())
+
+    def n_kept(self):
+        return int(self.cell_start[self.ncells].item())
+
+    # -- kernels ----------------------------------------------------------------------------
+    def forward(self, feats):
+        """feats: [N, C] fp32 or bf16, UNSORTED (row i belongs to coords[i]).  -> [B, D, H, W, C] fp32."""
+        return _PlannedBevPool.apply(feats, self)
+
+    def launch_forward(self, feats, out=None):
+        lib = _capi.load()
+        feats = feats.contiguous()
+        if feats.shape[0] != self.n:
+            raise RuntimeError(f"feats has {feats.shape[0]} rows, plan was built for {self.n}")
+        if feats.dtype == torch.float32:
+            is_bf16 = 0
+        elif feats.dtype == torch.bfloat16:
+            is_bf16 = 1
+        else:
+            raise RuntimeError(f"bev_pool: unsupported feature dtype {feats.dtype}")
+        c = feats.shape[1]
+        if out is None:
+            out = torch.empty((self.B, self.D, self.H, self.W, c), dtype=torch.float32, device=feats.device)
+        with torch.cuda.device(feats.device):
+            rc = lib.bevamd_bev_pool_forward_cells(
+                _capi.ptr(feats), is_bf16, _capi.ptr(self.order), _capi.ptr(self.cell_start), _capi.ptr(out),
+                self.n, c, self.B, self.D, self.H, self.W, _capi.stream_ptr(feats.device))
+        _capi.check(rc, "bev_pool_forward_cells")
+        return out
+
+    def launch_backward(self, out_grad, c):
+        lib = _capi.load()
+        out_grad = out_grad.contiguous().float()
+        x_grad = torch.empty((self.n, c), dtype=torch.float32, device=out_grad.device)
+        with torch.cuda.device(out_grad.device):
+            rc = lib.bevamd_bev_pool_backward_rows(
+                _capi.ptr(out_grad), _capi.ptr(self.order), _capi.ptr(self.ranks_sorted), _capi.ptr(x_grad),
+                self.n, c, self.B, self.D, self.H, self.W, _capi.stream_ptr(out_grad.device))
+        _capi.check(rc, "bev_pool_backward_rows")
+        return x_grad
+
+
+class _PlannedBevPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, plan):
+        ctx.plan = plan
+        ctx.c = feats.shape[1]
+        ctx.in_dtype = feats.dtype
+        return plan.launch_forward(feats)
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        g = ctx.plan.launch_backward(out_grad, ctx.c)
+        return g.to(ctx.in_dtype), None
+
+
+def bev_pool(feats, coords, B, D, H, W, plan=None, channels_last_view=False):
+    """Drop-in for `mmdet3d.ops.bev_pool(feats, coords, B, D, H, W)` (bev_pool.py:83-97).
+
+    feats [N, C]; coords [N, 4] integer (x, y, z, b) -> [B, C, D, H, W].
+    `plan` lets a caller reuse the precompute across frames (static calibration);
+    `channels_last_view=True` skips the final permute copy and returns the [B,D,H,W,C]
+    buffer viewed as [B,C,D,H,W] (same values, channels-last strides).
+    """
+    assert feats.shape[0] == coords.shape[0]
+    B, D, H, W = int(B), int(D), int(H), int(W)
+    if plan is None:
+        plan = BevPoolPlan.from_coords(coords, B, D, H, W)
+    x = plan.forward(feats)
+    x = x.permute(0, 4, 1, 2, 3)
+    if not channels_last_view:
+        x = x.contiguous()
+    return x

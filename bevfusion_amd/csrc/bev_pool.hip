@@ -1,0 +1,646 @@
+// bev_pool for gfx950: interval reduction of camera-frustum features into the
+// BEV grid, plus the rank/sort/interval precompute.
+//
+// Replaces (reference, /root/reference/mmdet3d/ops/bev_pool):
+//   src/bev_pool_cuda.cu:20-42   bev_pool_kernel       (thread per (interval, channel), serial walk)
+//   src/bev_pool_cuda.cu:61-84   bev_pool_grad_kernel
+//   src/bev_pool_cpu.cpp:22-87   host wrappers (zero-filled outputs)
+//   bev_pool.py:37-62,83-93      rank formula, argsort, interval construction
+//
+// Design (HBM-bound: 1 add per 4 bytes read, no reuse):
+//   * one 64-lane wavefront per BEV cell / interval; a feature row (C channels) is
+//     covered by C/4 lanes holding one 16-byte vector each, so floor(64 / (C/4))
+//     consecutive rows are fetched by ONE fully coalesced wave instruction
+//     (C=80: 20 lanes/row, 3 rows = 960 contiguous bytes per instruction);
+//   * each lane keeps 4 independent 16-byte loads in flight, accumulates in fp32 and
+//     the row-slots are folded with __shfl at the end: no LDS round trip, no atomics,
+//     one store of the finished cell;
+//   * two forward flavours:
+//       - "intervals" : the reference's contract (pre-sorted rows + interval arrays,
+//                       output zero-filled first) — the drop-in;
+//       - "cells"     : the native path.  Rows are read THROUGH the sort permutation
+//                       (the reference's sorted copy `feats[indices]`, 581 MB read +
+//                       581 MB written per frame, never exists) and the grid walks a
+//                       CSR over ALL cells, so every output cell — empty ones as zeros —
+//                       is written exactly once by a single launch: no memset pass,
+//                       no interval compaction, no host sync.
+//   * 64-bit address arithmetic throughout (reference overflows at N*C > 2^31).
+#include "common.h"
+
+namespace bevamd {
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+template <int VEC> struct Acc { float v[VEC]; };
+
+__device__ __forceinline__ void acc_add(Acc<4>& a, const float4& f) {
+  a.v[0] += f.x; a.v[1] += f.y; a.v[2] += f.z; a.v[3] += f.w;
+}
+// 8 packed bf16 -> fp32 adds (bf16 -> f32 is a 16-bit left shift)
+__device__ __forceinline__ void acc_add(Acc<8>& a, const U4& u) {
+  a.v[0] += __uint_as_float(u.x << 16); a.v[1] += __uint_as_float(u.x & 0xFFFF0000u);
+  a.v[2] += __uint_as_float(u.y << 16); a.v[3] += __uint_as_float(u.y & 0xFFFF0000u);
+  a.v[4] += __uint_as_float(u.z << 16); a.v[5] += __uint_as_float(u.z & 0xFFFF0000u);
+  a.v[6] += __uint_as_float(u.w << 16); a.v[7] += __uint_as_float(u.w & 0xFFFF0000u);
+}
+
+struct BevDims { int B, D, H, W, C; };
+
+// cell -> element offset of out[b, z, x, y, 0]   (bev_pool_cuda.cu:33-35)
+__device__ __forceinline__ size_t cell_offset(int gx, int gy, int gz, int gb, const BevDims& s) {
+  return ((((size_t)gb * s.D + gz) * s.H + gx) * s.W + gy) * (size_t)s.C;
+}
+
+// rank = x*(W*D*B) + y*(D*B) + z*B + b   (bev_pool.py:86-91) -> (x,y,z,b)
+__device__ __forceinline__ void decode_rank(uint32_t r, const BevDims& s, int& gx, int& gy, int& gz, int& gb) {
+  gb = r % s.B; r /= s.B;
+  gz = r % s.D; r /= s.D;
+  gy = r % s.W; r /= s.W;
+  gx = r;
+}
+
+// Sum rows [0,len) of one cell.  Lane (slot, cv) takes rows slot, slot+rpi, ... and the
+// 16-byte column vector cv; 4 loads in flight per lane.  ord == nullptr: rows are
+// contiguous from `first_row`; else row r is ord[r].
+template <typename VecT, int VEC>
+__device__ __forceinline__ void accumulate_rows(Acc<VEC>& acc, const VecT* __restrict__ x,
+                                                const uint32_t* __restrict__ ord, size_t first_row, int len,
+                                                int slot, int cv, int lpr, int rpi) {
+  int r = slot;
+  const int step = rpi;
+  if (ord) {
+    for (; r + 3 * step < len; r += 4 * step) {
+      uint32_t i0 = ord[r], i1 = ord[r + step], i2 = ord[r + 2 * step], i3 = ord[r + 3 * step];
+      VecT a0 = x[(size_t)i0 * lpr + cv];
+      VecT a1 = x[(size_t)i1 * lpr + cv];
+      VecT a2 = x[(size_t)i2 * lpr + cv];
+      VecT a3 = x[(size_t)i3 * lpr + cv];
+      acc_add(acc, a0); acc_add(acc, a1); acc_add(acc, a2); acc_add(acc, a3);
+    }
+    for (; r < len; r += step) {
+      VecT a0 = x[(size_t)ord[r] * lpr + cv];
+      acc_add(acc, a0);
+    }
+  } else {
+    const VecT* xr = x + first_row * lpr + cv;
+    for (; r + 3 * step < len; r += 4 * step) {
+      VecT a0 = xr[(size_t)r * lpr];
+      VecT a1 = xr[(size_t)(r + step) * lpr];
+      VecT a2 = xr[(size_t)(r + 2 * step) * lpr];
+      VecT a3 = xr[(size_t)(r + 3 * step) * lpr];
+      acc_add(acc, a0); acc_add(acc, a1); acc_add(acc, a2); acc_add(acc, a3);
+    }
+    for (; r < len; r += step) {
+      VecT a0 = xr[(size_t)r * lpr];
+      acc_add(acc, a0);
+    }
+  }
+}
+
+// fold the row-slots into slot 0 (wave-uniform trip count: every lane shuffles)
+template <int VEC>
+__device__ __forceinline__ void fold_slots(Acc<VEC>& acc, int lane, int lpr, int rpi) {
+  for (int sl = 1; sl < rpi; ++sl) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float o = __shfl(acc.v[j], lane + sl * lpr, 64);
+      acc.v[j] += o;
+    }
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_cell(const Acc<VEC>& acc, float* __restrict__ cell, int cv) {
+  float4* o = (float4*)(cell + (size_t)cv * VEC);
+#pragma unroll
+  for (int j = 0; j < VEC / 4; ++j)
+    o[j] = make_float4(acc.v[4 * j], acc.v[4 * j + 1], acc.v[4 * j + 2], acc.v[4 * j + 3]);
+}
+
+// ---------------------------------------------------------------------------
+// forward over the reference's interval arrays (drop-in contract)
+// ---------------------------------------------------------------------------
+template <typename VecT, int VEC>
+__global__ __launch_bounds__(256) void bev_pool_fwd_intervals_vec_kernel(
+    const VecT* __restrict__ x, const int* __restrict__ geom, const int* __restrict__ starts,
+    const int* __restrict__ lengths, int n_int, float* __restrict__ out, int lpr, int rpi, BevDims s) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= n_int) return;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+  const int start = starts[wave];
+  const int len = lengths[wave];
+  Acc<VEC> acc;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
+  if (slot < rpi) accumulate_rows<VecT, VEC>(acc, x, nullptr, (size_t)start, len, slot, cv, lpr, rpi);
+  fold_slots<VEC>(acc, lane, lpr, rpi);
+  if (slot == 0) {
+    const int* g = geom + (size_t)start * 4;
+    store_cell<VEC>(acc, out + cell_offset(g[0], g[1], g[2], g[3], s), cv);
+  }
+}
+
+// any channel count / alignment: wave per interval, lanes stride the channels
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void bev_pool_fwd_intervals_scalar_kernel(
+    const void* __restrict__ xv, const int* __restrict__ geom, const int* __restrict__ starts,
+    const int* __restrict__ lengths, int n_int, float* __restrict__ out, BevDims s) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= n_int) return;
+  const int lane = threadIdx.x & 63;
+  const int start = starts[wave], len = lengths[wave];
+  const int* g = geom + (size_t)start * 4;
+  float* o = out + cell_offset(g[0], g[1], g[2], g[3], s);
+  for (int c = lane; c < s.C; c += 64) {
+    float psum = 0.f;
+    for (int r = 0; r < len; ++r) {
+      size_t e = (size_t)(start + r) * s.C + c;
+      psum += IS_BF16 ? __uint_as_float((uint32_t)((const uint16_t*)xv)[e] << 16) : ((const float*)xv)[e];
+    }
+    o[c] = psum;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward over the cell CSR (native path): one launch writes every output cell
+// ---------------------------------------------------------------------------
+template <typename VecT, int VEC>
+__global__ __launch_bounds__(256) void bev_pool_fwd_cells_vec_kernel(
+    const VecT* __restrict__ x, const uint32_t* __restrict__ order, const uint32_t* __restrict__ cell_start,
+    uint32_t ncells, float* __restrict__ out, int lpr, int rpi, BevDims s) {
+  const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (cell >= ncells) return;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+  const uint32_t start = cell_start[cell];
+  const int len = (int)(cell_start[cell + 1] - start);
+  Acc<VEC> acc;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
+  if (len > 0) {  // wave-uniform
+    if (slot < rpi) accumulate_rows<VecT, VEC>(acc, x, order + start, 0, len, slot, cv, lpr, rpi);
+    fold_slots<VEC>(acc, lane, lpr, rpi);
+  }
+  if (slot == 0) {
+    int gx, gy, gz, gb;
+    decode_rank(cell, s, gx, gy, gz, gb);
+    store_cell<VEC>(acc, out + cell_offset(gx, gy, gz, gb, s), cv);
+  }
+}
+
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void bev_pool_fwd_cells_scalar_kernel(
+    const void* __restrict__ xv, const uint32_t* __restrict__ order, const uint32_t* __restrict__ cell_start,
+    uint32_t ncells, float* __restrict__ out, BevDims s) {
+  const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (cell >= ncells) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t start = cell_start[cell];
+  const int len = (int)(cell_start[cell + 1] - start);
+  int gx, gy, gz, gb;
+  decode_rank(cell, s, gx, gy, gz, gb);
+  float* o = out + cell_offset(gx, gy, gz, gb, s);
+  for (int c = lane; c < s.C; c += 64) {
+    float psum = 0.f;
+    for (int r = 0; r < len; ++r) {
+      size_t e = (size_t)order[start + r] * s.C + c;
+      psum += IS_BF16 ? __uint_as_float((uint32_t)((const uint16_t*)xv)[e] << 16) : ((const float*)xv)[e];
+    }
+    o[c] = psum;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward: broadcast the cell gradient to every point of its interval
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bev_pool_bwd_intervals_vec_kernel(
+    const float* __restrict__ out_grad, const int* __restrict__ geom, const int* __restrict__ starts,
+    const int* __restrict__ lengths, int n_int, float4* __restrict__ x_grad, int lpr, int rpi, BevDims s) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= n_int) return;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+  if (slot >= rpi) return;
+  const int start = starts[wave], len = lengths[wave];
+  const int* g = geom + (size_t)start * 4;
+  const float4 gval = *(const float4*)(out_grad + cell_offset(g[0], g[1], g[2], g[3], s) + (size_t)cv * 4);
+  float4* xr = x_grad + (size_t)start * lpr + cv;
+  for (int r = slot; r < len; r += rpi) xr[(size_t)r * lpr] = gval;
+}
+
+__global__ __launch_bounds__(256) void bev_pool_bwd_intervals_scalar_kernel(
+    const float* __restrict__ out_grad, const int* __restrict__ geom, const int* __restrict__ starts,
+    const int* __restrict__ lengths, int n_int, float* __restrict__ x_grad, BevDims s) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= n_int) return;
+  const int lane = threadIdx.x & 63;
+  const int start = starts[wave], len = lengths[wave];
+  const int* g = geom + (size_t)start * 4;
+  const float* go = out_grad + cell_offset(g[0], g[1], g[2], g[3], s);
+  for (int c = lane; c < s.C; c += 64) {
+    float gval = go[c];
+    for (int r = 0; r < len; ++r) x_grad[(size_t)(start + r) * s.C + c] = gval;
+  }
+}
+
+// native backward: row-parallel over the SORTED rows, so a 900-row cell and a 1-row cell
+// cost the same per row; rows the range mask dropped (sentinel rank) get zeros.
+__global__ __launch_bounds__(256) void bev_pool_bwd_rows_vec_kernel(
+    const float* __restrict__ out_grad, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ ranks_sorted, uint32_t ncells, int n, float4* __restrict__ x_grad, int lpr,
+    int rpi, BevDims s) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+  if (slot >= rpi) return;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t j = wave * rpi + slot;
+  if (j >= (size_t)n) return;
+  const uint32_t r = ranks_sorted[j];
+  float4 gval = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < ncells) {
+    int gx, gy, gz, gb;
+    decode_rank(r, s, gx, gy, gz, gb);
+    gval = *(const float4*)(out_grad + cell_offset(gx, gy, gz, gb, s) + (size_t)cv * 4);
+  }
+  x_grad[(size_t)order[j] * lpr + cv] = gval;
+}
+
+__global__ __launch_bounds__(256) void bev_pool_bwd_rows_scalar_kernel(
+    const float* __restrict__ out_grad, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ ranks_sorted, uint32_t ncells, int n, float* __restrict__ x_grad, BevDims s) {
+  const int lane = threadIdx.x & 63;
+  const size_t j = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= (size_t)n) return;
+  const uint32_t r = ranks_sorted[j];
+  const float* go = nullptr;
+  if (r < ncells) {
+    int gx, gy, gz, gb;
+    decode_rank(r, s, gx, gy, gz, gb);
+    go = out_grad + cell_offset(gx, gy, gz, gb, s);
+  }
+  float* xr = x_grad + (size_t)order[j] * s.C;
+  for (int c = lane; c < s.C; c += 64) xr[c] = go ? go[c] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// precompute: rank (+ per-cell histogram) -> stable sort -> CSR / interval boundaries
+// ---------------------------------------------------------------------------
+// key = reference rank for in-range cells; `ncells` (sentinel) for anything outside
+// [0,H)x[0,W)x[0,D)x[0,B), so a caller may hand over unfiltered coordinates: the range
+// mask of vtransforms/base.py:160-169 folds into the sort instead of a boolean gather.
+template <typename CoordT>
+__global__ __launch_bounds__(256) void bev_rank_kernel(const CoordT* __restrict__ coords, int n, BevDims s,
+                                                       uint32_t ncells, uint32_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ cell_count) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const CoordT* c = coords + (size_t)i * 4;
+  long long gx = c[0], gy = c[1], gz = c[2], gb = c[3];
+  bool ok = gx >= 0 && gx < s.H && gy >= 0 && gy < s.W && gz >= 0 && gz < s.D && gb >= 0 && gb < s.B;
+  uint32_t r = ok ? (uint32_t)(((gx * s.W + gy) * s.D + gz) * s.B + gb) : ncells;
+  keys[i] = r;
+  vals[i] = (uint32_t)i;
+  atomicAdd(&cell_count[r], 1u);
+}
+
+// Same, straight from fp32 lidar-frame geometry (vtransforms/base.py:149):
+//   idx = trunc((p - (bx - dx/2)) / dx)  as int64 (C++ cast semantics == .long()),
+// batch index = i / points_per_batch.
+__global__ __launch_bounds__(256) void bev_rank_from_geom_kernel(const float* __restrict__ geom, int n,
+                                                                 int points_per_batch, float ox, float oy,
+                                                                 float oz, float dx, float dy, float dz,
+                                                                 BevDims s, uint32_t ncells,
+                                                                 uint32_t* __restrict__ keys,
+                                                                 uint32_t* __restrict__ vals,
+                                                                 uint32_t* __restrict__ cell_count) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = geom + (size_t)i * 3;
+  // the subtraction and the division are separate fp32 roundings, as in torch
+  float fx = __fdiv_rn(__fsub_rn(p[0], ox), dx);
+  float fy = __fdiv_rn(__fsub_rn(p[1], oy), dy);
+  float fz = __fdiv_rn(__fsub_rn(p[2], oz), dz);
+  // truncation toward zero; NaN / huge values fall out of range below
+  bool finite = (fabsf(fx) < 1.0e9f) && (fabsf(fy) < 1.0e9f) && (fabsf(fz) < 1.0e9f);
+  long long gx = finite ? (long long)fx : -1, gy = finite ? (long long)fy : -1,
+            gz = finite ? (long long)fz : -1;
+  int gb = i / points_per_batch;
+  bool ok = gx >= 0 && gx < s.H && gy >= 0 && gy < s.W && gz >= 0 && gz < s.D && gb < s.B;
+  uint32_t r = ok ? (uint32_t)(((gx * s.W + gy) * s.D + gz) * s.B + gb) : ncells;
+  keys[i] = r;
+  vals[i] = (uint32_t)i;
+  atomicAdd(&cell_count[r], 1u);
+}
+
+// interval arrays in the reference's shape, compacted from the CSR: interval k is the k-th
+// non-empty cell in rank order (== bev_pool.py:39-46 on the sorted ranks).
+__global__ __launch_bounds__(256) void bev_cell_flags_kernel(const uint32_t* __restrict__ cell_start,
+                                                             uint32_t ncells, uint32_t* __restrict__ flags) {
+  uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= ncells) return;
+  flags[c] = cell_start[c + 1] > cell_start[c] ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void bev_intervals_from_cells_kernel(const uint32_t* __restrict__ cell_start,
+                                                                       const uint32_t* __restrict__ flag_scan,
+                                                                       uint32_t ncells, int* __restrict__ starts,
+                                                                       int* __restrict__ lengths) {
+  uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= ncells) return;
+  uint32_t a = cell_start[c], b = cell_start[c + 1];
+  if (b > a) {
+    uint32_t k = flag_scan[c];
+    starts[k] = (int)a;
+    lengths[k] = (int)(b - a);
+  }
+}
+
+// sorted coordinate rows (x,y,z,b) int32 for the reference-shaped API
+__global__ __launch_bounds__(256) void bev_geom_from_ranks_kernel(const uint32_t* __restrict__ keys, int n,
+                                                                  BevDims s, uint32_t ncells,
+                                                                  int* __restrict__ geom) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t k = keys[j];
+  int gx = -1, gy = -1, gz = -1, gb = -1;
+  if (k < ncells) decode_rank(k, s, gx, gy, gz, gb);
+  ((int4*)geom)[j] = make_int4(gx, gy, gz, gb);
+}
+
+// ---------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------
+static int check_dims(int n, int c, int b, int d, int h, int w) {
+  BEVAMD_REQUIRE(n >= 0 && c > 0 && b > 0 && d > 0 && h > 0 && w > 0,
+                 "bev_pool: bad sizes n=%d c=%d b=%d d=%d h=%d w=%d", n, c, b, d, h, w);
+  BEVAMD_REQUIRE((unsigned long long)b * d * h * w < 0xFFFFFFF0ull, "bev_pool: B*D*H*W must be < 2^32-16");
+  return BEVAMD_OK;
+}
+
+static bool vec_path_ok(int C, int vec, const void* a, const void* b) {
+  return (C % vec == 0) && (C / vec <= 64) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)b & 15) == 0);
+}
+
+static int launch_forward_intervals(const void* x, int x_is_bf16, const int* geom, const int* starts,
+                                    const int* lengths, int n_int, float* out, BevDims s, hipStream_t stream) {
+  if (n_int <= 0) return BEVAMD_OK;
+  const int vec = x_is_bf16 ? 8 : 4;
+  dim3 grid(cdiv(n_int, 4)), block(256);
+  if (vec_path_ok(s.C, vec, x, out)) {
+    int lpr = s.C / vec, rpi = 64 / lpr;
+    if (x_is_bf16)
+      bev_pool_fwd_intervals_vec_kernel<U4, 8><<<grid, block, 0, stream>>>((const U4*)x, geom, starts, lengths,
+                                                                          n_int, out, lpr, rpi, s);
+    else
+      bev_pool_fwd_intervals_vec_kernel<float4, 4><<<grid, block, 0, stream>>>((const float4*)x, geom, starts,
+                                                                              lengths, n_int, out, lpr, rpi, s);
+  } else {
+    if (x_is_bf16)
+      bev_pool_fwd_intervals_scalar_kernel<true><<<grid, block, 0, stream>>>(x, geom, starts, lengths, n_int, out, s);
+    else
+      bev_pool_fwd_intervals_scalar_kernel<false><<<grid, block, 0, stream>>>(x, geom, starts, lengths, n_int, out, s);
+  }
+  BEVAMD_LAUNCH_CHECK("bev_pool_fwd_intervals");
+  return BEVAMD_OK;
+}
+
+static size_t prepare_ws_bytes(size_t n, size_t ncells) {
+  size_t b = 0;
+  b += 2 * align_up(n * sizeof(uint32_t), 256);             // keys_a, vals_a
+  b += 2 * align_up((ncells + 2) * sizeof(uint32_t), 256);  // cell flags, flag scan
+  size_t s1 = radix_sort_workspace_bytes(n), s2 = scan_workspace_bytes(ncells + 2);
+  b += align_up(s1 > s2 ? s1 : s2, 256);
+  return b;
+}
+
+struct PrepBuffers {
+  uint32_t *keys_a, *vals_a, *flags, *flag_scan;
+  void* sort_ws; size_t sort_ws_bytes;
+};
+
+static int carve_prep(PrepBuffers& pb, int n, uint32_t ncells, void* ws, size_t ws_bytes) {
+  size_t need = prepare_ws_bytes((size_t)n, ncells);
+  if (ws == nullptr || ws_bytes < need) {
+    set_error("bev_pool_prepare: workspace too small (%zu < %zu)", ws_bytes, need);
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  Carver cv(ws, ws_bytes);
+  pb.keys_a = cv.take<uint32_t>(n);
+  pb.vals_a = cv.take<uint32_t>(n);
+  pb.flags = cv.take<uint32_t>((size_t)ncells + 2);
+  pb.flag_scan = cv.take<uint32_t>((size_t)ncells + 2);
+  pb.sort_ws = cv.base + cv.off;
+  pb.sort_ws_bytes = ws_bytes - cv.off;
+  return BEVAMD_OK;
+}
+
+// after keys/vals/cell_count are filled: sort, CSR, optional reference-shaped arrays
+static int prepare_tail(PrepBuffers& pb, int n, BevDims s, uint32_t ncells, uint32_t* ranks_sorted,
+                        uint32_t* order, uint32_t* cell_start, int* starts, int* lengths, int* n_int_dev,
+                        int* geom_sorted, hipStream_t stream) {
+  const int nbits = bits_for((uint64_t)ncells + 1);
+  int rc = radix_sort_pairs_u32(pb.keys_a, pb.vals_a, ranks_sorted, order, (size_t)n, nbits, pb.sort_ws,
+                                pb.sort_ws_bytes, stream);
+  if (rc != BEVAMD_OK) return rc;
+  // cell_start currently holds the per-cell counts ([ncells] + sentinel bucket + 0): scan in place
+  rc = exclusive_scan_u32(cell_start, cell_start, (size_t)ncells + 2, nullptr, pb.sort_ws, pb.sort_ws_bytes, stream);
+  if (rc != BEVAMD_OK) return rc;
+  if (starts && lengths && n_int_dev) {
+    dim3 grid(cdiv(ncells, 256)), block(256);
+    bev_cell_flags_kernel<<<grid, block, 0, stream>>>(cell_start, ncells, pb.flags);
+    BEVAMD_LAUNCH_CHECK("bev_cell_flags");
+    rc = exclusive_scan_u32(pb.flags, pb.flag_scan, (size_t)ncells, (uint32_t*)n_int_dev, pb.sort_ws,
+                            pb.sort_ws_bytes, stream);
+    if (rc != BEVAMD_OK) return rc;
+    bev_intervals_from_cells_kernel<<<grid, block, 0, stream>>>(cell_start, pb.flag_scan, ncells, starts, lengths);
+    BEVAMD_LAUNCH_CHECK("bev_intervals_from_cells");
+  }
+  if (geom_sorted) {
+    bev_geom_from_ranks_kernel<<<dim3(cdiv(n, 256)), dim3(256), 0, stream>>>(ranks_sorted, n, s, ncells, geom_sorted);
+    BEVAMD_LAUNCH_CHECK("bev_geom_from_ranks");
+  }
+  return BEVAMD_OK;
+}
+
+}  // namespace bevamd
+
+using namespace bevamd;
+
+extern "C" {
+
+int bevamd_bev_pool_forward(const float* x, const int* geom_feats, const int* interval_lengths,
+                            const int* interval_starts, float* out, int n, int c, int n_intervals, int b,
+                            int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_dims(n, c, b, d, h, w);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n_intervals >= 0, "bev_pool_forward: n_intervals < 0");
+  BEVAMD_REQUIRE(out != nullptr, "bev_pool_forward: out is null");
+  BEVAMD_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)b * d * h * w * c * sizeof(float), stream));
+  if (n == 0 || n_intervals == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(x && geom_feats && interval_lengths && interval_starts, "bev_pool_forward: null input");
+  return launch_forward_intervals(x, 0, geom_feats, interval_starts, interval_lengths, n_intervals, out,
+                                  BevDims{b, d, h, w, c}, stream);
+}
+
+int bevamd_bev_pool_forward_bf16(const uint16_t* x, const int* geom_feats, const int* interval_lengths,
+                                 const int* interval_starts, float* out, int n, int c, int n_intervals,
+                                 int b, int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_dims(n, c, b, d, h, w);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n_intervals >= 0, "bev_pool_forward_bf16: n_intervals < 0");
+  BEVAMD_REQUIRE(out != nullptr, "bev_pool_forward_bf16: out is null");
+  BEVAMD_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)b * d * h * w * c * sizeof(float), stream));
+  if (n == 0 || n_intervals == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(x && geom_feats && interval_lengths && interval_starts, "bev_pool_forward_bf16: null input");
+  return launch_forward_intervals(x, 1, geom_feats, interval_starts, interval_lengths, n_intervals, out,
+                                  BevDims{b, d, h, w, c}, stream);
+}
+
+int bevamd_bev_pool_backward(const float* out_grad, const int* geom_feats, const int* interval_lengths,
+                             const int* interval_starts, float* x_grad, int n, int c, int n_intervals, int b,
+                             int d, int h, int w, int skip_zero_fill, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_dims(n, c, b, d, h, w);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n_intervals >= 0, "bev_pool_backward: n_intervals < 0");
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(x_grad != nullptr, "bev_pool_backward: x_grad is null");
+  if (!skip_zero_fill) BEVAMD_HIP_CHECK(hipMemsetAsync(x_grad, 0, (size_t)n * c * sizeof(float), stream));
+  if (n_intervals == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(out_grad && geom_feats && interval_lengths && interval_starts, "bev_pool_backward: null input");
+  BevDims s{b, d, h, w, c};
+  dim3 grid(cdiv(n_intervals, 4)), block(256);
+  if (vec_path_ok(c, 4, out_grad, x_grad)) {
+    int lpr = c / 4, rpi = 64 / lpr;
+    bev_pool_bwd_intervals_vec_kernel<<<grid, block, 0, stream>>>(out_grad, geom_feats, interval_starts,
+                                                                  interval_lengths, n_intervals, (float4*)x_grad,
+                                                                  lpr, rpi, s);
+  } else {
+    bev_pool_bwd_intervals_scalar_kernel<<<grid, block, 0, stream>>>(out_grad, geom_feats, interval_starts,
+                                                                     interval_lengths, n_intervals, x_grad, s);
+  }
+  BEVAMD_LAUNCH_CHECK("bev_pool_bwd_intervals");
+  return BEVAMD_OK;
+}
+
+size_t bevamd_bev_pool_prepare_workspace_bytes(int n, int b, int d, int h, int w) {
+  if (n < 1) n = 1;
+  unsigned long long ncells = (unsigned long long)(b > 0 ? b : 1) * (d > 0 ? d : 1) * (h > 0 ? h : 1) * (w > 0 ? w : 1);
+  return prepare_ws_bytes((size_t)n, (size_t)ncells);
+}
+
+static int prepare_common(const void* coords, int coords_kind /*0 i32, 1 i64, 2 geom f32*/, int n, int b, int d,
+                          int h, int w, const float* origin, const float* dx, uint32_t* ranks_sorted,
+                          uint32_t* order, uint32_t* cell_start, int* interval_starts, int* interval_lengths,
+                          int* n_intervals_dev, int* geom_sorted, void* ws, size_t ws_bytes, hipStream_t stream) {
+  int rc = check_dims(n, 1, b, d, h, w);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(cell_start != nullptr, "bev_pool_prepare: cell_start is null");
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  BEVAMD_HIP_CHECK(hipMemsetAsync(cell_start, 0, ((size_t)ncells + 2) * sizeof(uint32_t), stream));
+  if (n == 0) {
+    if (n_intervals_dev) BEVAMD_HIP_CHECK(hipMemsetAsync(n_intervals_dev, 0, sizeof(int), stream));
+    return BEVAMD_OK;
+  }
+  BEVAMD_REQUIRE(coords && ranks_sorted && order, "bev_pool_prepare: null buffer");
+  PrepBuffers pb;
+  rc = carve_prep(pb, n, ncells, ws, ws_bytes);
+  if (rc) return rc;
+  BevDims s{b, d, h, w, 1};
+  dim3 grid(cdiv(n, 256)), block(256);
+  if (coords_kind == 1)
+    bev_rank_kernel<long long><<<grid, block, 0, stream>>>((const long long*)coords, n, s, ncells, pb.keys_a,
+                                                           pb.vals_a, cell_start);
+  else if (coords_kind == 0)
+    bev_rank_kernel<int><<<grid, block, 0, stream>>>((const int*)coords, n, s, ncells, pb.keys_a, pb.vals_a,
+                                                     cell_start);
+  else
+    bev_rank_from_geom_kernel<<<grid, block, 0, stream>>>((const float*)coords, n, n / b, origin[0], origin[1],
+                                                          origin[2], dx[0], dx[1], dx[2], s, ncells, pb.keys_a,
+                                                          pb.vals_a, cell_start);
+  BEVAMD_LAUNCH_CHECK("bev_rank");
+  return prepare_tail(pb, n, s, ncells, ranks_sorted, order, cell_start, interval_starts, interval_lengths,
+                      n_intervals_dev, geom_sorted, stream);
+}
+
+int bevamd_bev_pool_prepare(const void* coords, int coords_are_int64, int n, int b, int d, int h, int w,
+                            uint32_t* ranks_sorted, uint32_t* order, uint32_t* cell_start, int* interval_starts,
+                            int* interval_lengths, int* n_intervals_dev, int* geom_sorted, void* ws,
+                            size_t ws_bytes, void* stream_) {
+  return prepare_common(coords, coords_are_int64 ? 1 : 0, n, b, d, h, w, nullptr, nullptr, ranks_sorted, order,
+                        cell_start, interval_starts, interval_lengths, n_intervals_dev, geom_sorted, ws, ws_bytes,
+                        (hipStream_t)stream_);
+}
+
+int bevamd_bev_pool_prepare_from_geom(const float* geom_xyz, int n, int b, int d, int h, int w,
+                                      const float* bx_minus_half_dx, const float* dx, uint32_t* ranks_sorted,
+                                      uint32_t* order, uint32_t* cell_start, int* interval_starts,
+                                      int* interval_lengths, int* n_intervals_dev, int* geom_sorted, void* ws,
+                                      size_t ws_bytes, void* stream_) {
+  BEVAMD_REQUIRE(bx_minus_half_dx && dx, "bev_pool_prepare_from_geom: null grid origin/step (host pointers)");
+  BEVAMD_REQUIRE(b > 0 && n % b == 0, "bev_pool_prepare_from_geom: n=%d not divisible by batch=%d", n, b);
+  return prepare_common(geom_xyz, 2, n, b, d, h, w, bx_minus_half_dx, dx, ranks_sorted, order, cell_start,
+                        interval_starts, interval_lengths, n_intervals_dev, geom_sorted, ws, ws_bytes,
+                        (hipStream_t)stream_);
+}
+
+int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* order, const uint32_t* cell_start,
+                                  float* out, int n, int c, int b, int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_dims(n, c, b, d, h, w);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(out && cell_start, "bev_pool_forward_cells: null out / cell_start");
+  BEVAMD_REQUIRE(n == 0 || (x && order), "bev_pool_forward_cells: null input");
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  BevDims s{b, d, h, w, c};
+  const int vec = x_is_bf16 ? 8 : 4;
+  dim3 grid(cdiv(ncells, 4)), block(256);
+  if (vec_path_ok(c, vec, x, out)) {
+    int lpr = c / vec, rpi = 64 / lpr;
+    if (x_is_bf16)
+      bev_pool_fwd_cells_vec_kernel<U4, 8><<<grid, block, 0, stream>>>((const U4*)x, order, cell_start, ncells, out,
+                                                                      lpr, rpi, s);
+    else
+      bev_pool_fwd_cells_vec_kernel<float4, 4><<<grid, block, 0, stream>>>((const float4*)x, order, cell_start,
+                                                                          ncells, out, lpr, rpi, s);
+  } else {
+    if (x_is_bf16)
+      bev_pool_fwd_cells_scalar_kernel<true><<<grid, block, 0, stream>>>(x, order, cell_start, ncells, out, s);
+    else
+      bev_pool_fwd_cells_scalar_kernel<false><<<grid, block, 0, stream>>>(x, order, cell_start, ncells, out, s);
+  }
+  BEVAMD_LAUNCH_CHECK("bev_pool_fwd_cells");
+  return BEVAMD_OK;
+}
+
+int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order, const uint32_t* ranks_sorted,
+                                  float* x_grad, int n, int c, int b, int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_dims(n, c, b, d, h, w);
+  if (rc) return rc;
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(out_grad && order && ranks_sorted && x_grad, "bev_pool_backward_rows: null buffer");
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  BevDims s{b, d, h, w, c};
+  if (vec_path_ok(c, 4, out_grad, x_grad)) {
+    int lpr = c / 4, rpi = 64 / lpr;
+    dim3 grid(cdiv(cdiv(n, rpi), 4)), block(256);
+    bev_pool_bwd_rows_vec_kernel<<<grid, block, 0, stream>>>(out_grad, order, ranks_sorted, ncells, n,
+                                                             (float4*)x_grad, lpr, rpi, s);
+  } else {
+    dim3 grid(cdiv(n, 4)), block(256);
+    bev_pool_bwd_rows_scalar_kernel<<<grid, block, 0, stream>>>(out_grad, order, ranks_sorted, ncells, n, x_grad, s);
+  }
+  BEVAMD_LAUNCH_CHECK("bev_pool_bwd_rows");
+  return BEVAMD_OK;
+}
+
+}  // extern "C"

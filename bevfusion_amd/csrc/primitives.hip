@@ -1,0 +1,317 @@
+// Device-wide primitives used by bev_pool precompute, hard voxelization and the
+// spconv rulebook builder: exclusive scan and a stable LSD radix sort, written
+// for wave64 (ballot-based match inside a wave, LDS counters across the 4 waves
+// of a 256-thread workgroup).  Integer-only, HBM/L2-bound; no MFMA here.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace bevamd {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ============================================================================
+// exclusive scan
+// ============================================================================
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048
+
+// Exclusive scan of one value per thread across a 256-thread block.
+// Returns the exclusive prefix; *block_total gets the block sum (all threads).
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned* lds_wave /*[4]*/,
+                                                             unsigned* block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = wave_inclusive_scan(v);
+  if (lane == 63) lds_wave[wave] = inc;
+  __syncthreads();
+  unsigned w0 = lds_wave[0], w1 = lds_wave[1], w2 = lds_wave[2], w3 = lds_wave[3];
+  unsigned base = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+  *block_total = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_reduce_kernel(const uint32_t* __restrict__ in,
+                                                                        uint32_t* __restrict__ tile_sums,
+                                                                        size_t n) {
+  __shared__ unsigned lds_wave[4];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    size_t idx = base + (size_t)i * SCAN_THREADS + threadIdx.x;
+    if (idx < n) s += in[idx];
+  }
+  s = (unsigned)wave_reduce_add((int)s);
+  if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+}
+
+// Single workgroup: exclusive scan of `n` values in place (n arbitrary), total out.
+__global__ __launch_bounds__(1024) void scan_single_block_kernel(const uint32_t* __restrict__ in,
+                                                                 uint32_t* __restrict__ out, size_t n,
+                                                                 uint32_t* __restrict__ total) {
+  __shared__ unsigned lds_wave[16];
+  __shared__ unsigned carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (size_t base = 0; base < n; base += 1024) {
+    size_t idx = base + threadIdx.x;
+    unsigned v = idx < n ? in[idx] : 0u;
+    unsigned inc = wave_inclusive_scan(v);
+    if (lane == 63) lds_wave[wave] = inc;
+    __syncthreads();
+    unsigned wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      unsigned t = lds_wave[w];
+      if (w < wave) wbase += t;
+      tot += t;
+    }
+    unsigned carry = carry_s;
+    if (idx < n) out[idx] = carry + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total) *total = carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_kernel(const uint32_t* __restrict__ in,
+                                                                       uint32_t* __restrict__ out,
+                                                                       const uint32_t* __restrict__ tile_offsets,
+                                                                       size_t n) {
+  __shared__ unsigned lds_wave[4];
+  // blocked arrangement: thread t owns items [t*ITEMS, t*ITEMS+ITEMS) of the tile
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+  unsigned v[SCAN_ITEMS];
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0u;
+    s += v[i];
+  }
+  unsigned tot;
+  unsigned ex = block_exclusive_scan_256(s, lds_wave, &tot);
+  unsigned run = tile_offsets[blockIdx.x] + ex;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+}
+
+constexpr size_t SCAN_SINGLE_BLOCK_MAX = 1u << 17;
+
+size_t scan_workspace_bytes(size_t n) {
+  size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  return align_up((ntiles + 1) * sizeof(uint32_t), 256);
+}
+
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* ws,
+                       size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) {
+    if (total) BEVAMD_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint32_t), stream));
+    return BEVAMD_OK;
+  }
+  if (n <= SCAN_SINGLE_BLOCK_MAX) {
+    scan_single_block_kernel<<<1, 1024, 0, stream>>>(in, out, n, total);
+    BEVAMD_LAUNCH_CHECK("scan_single_block");
+    return BEVAMD_OK;
+  }
+  size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (ws_bytes < scan_workspace_bytes(n) || ws == nullptr) {
+    set_error("exclusive_scan_u32: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  uint32_t* tile_sums = (uint32_t*)ws;
+  scan_tile_reduce_kernel<<<(unsigned)ntiles, SCAN_THREADS, 0, stream>>>(in, tile_sums, n);
+  BEVAMD_LAUNCH_CHECK("scan_tile_reduce");
+  scan_single_block_kernel<<<1, 1024, 0, stream>>>(tile_sums, tile_sums, ntiles, total);
+  BEVAMD_LAUNCH_CHECK("scan_single_block");
+  scan_tile_apply_kernel<<<(unsigned)ntiles, SCAN_THREADS, 0, stream>>>(in, out, tile_sums, n);
+  BEVAMD_LAUNCH_CHECK("scan_tile_apply");
+  return BEVAMD_OK;
+}
+
+// ============================================================================
+// stable LSD radix sort, (u32 key, u32 value)
+// ============================================================================
+// Tile = 4096 pairs per 256-thread workgroup; wave w owns the contiguous chunk
+// [w*1024, (w+1)*1024) of the tile and walks it in 16 rounds of 64 lanes, so the
+// order (wave, round, lane) is the input order: ranking by "items before me with
+// my digit" in that order is a stable partition.
+constexpr int RS_THREADS = 256;
+constexpr int RS_ROUNDS = 16;
+constexpr int RS_WAVE_CHUNK = 64 * RS_ROUNDS;     // 1024
+constexpr int RS_TILE = 4 * RS_WAVE_CHUNK;        // 4096
+constexpr int RS_MAX_BITS = 8;
+constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
+
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
+                                                                int shift, int bits, unsigned nblocks,
+                                                                uint32_t* __restrict__ hist) {
+  __shared__ unsigned lh[RS_MAX_BINS];
+  const unsigned nbins = 1u << bits, mask = nbins - 1u;
+  for (unsigned i = threadIdx.x; i < nbins; i += RS_THREADS) lh[i] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int i = 0; i < RS_TILE / RS_THREADS; ++i) {
+    size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&lh[(keys[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < nbins; i += RS_THREADS) hist[(size_t)i * nblocks + blockIdx.x] = lh[i];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift, int bits,
+    unsigned nblocks, const uint32_t* __restrict__ hist_scanned) {
+  __shared__ unsigned cnt[4][RS_MAX_BINS];  // per-wave running digit counters -> later: bases
+  const unsigned nbins = 1u << bits, mask = nbins - 1u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (unsigned i = threadIdx.x; i < 4 * RS_MAX_BINS; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+
+  const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)wave * RS_WAVE_CHUNK;
+  uint32_t k[RS_ROUNDS], v[RS_ROUNDS];
+  unsigned short rnk[RS_ROUNDS];
+  const unsigned long long lt = lanemask_lt();
+  volatile unsigned* wc = cnt[wave];
+
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    size_t idx = wbase + (size_t)r * 64 + lane;
+    bool valid = idx < n;
+    k[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+    v[r] = valid ? vals_in[idx] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    size_t idx = wbase + (size_t)r * 64 + lane;
+    bool valid = idx < n;
+    unsigned d = (k[r] >> shift) & mask;
+    // match-any over the wave: lanes holding the same digit
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    unsigned before = __popcll(peers & lt);
+    unsigned old = valid ? wc[d] : 0u;
+    // leader (lowest peer lane) bumps the wave's counter for this digit
+    if (valid && before == 0) wc[d] = old + (unsigned)__popcll(peers);
+    rnk[r] = (unsigned short)(old + before);
+  }
+  __syncthreads();
+  // per-digit exclusive prefix over the 4 waves + global base of (digit, block)
+  for (unsigned d = threadIdx.x; d < nbins; d += RS_THREADS) {
+    unsigned g = hist_scanned[(size_t)d * nblocks + blockIdx.x];
+    unsigned c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
+    cnt[0][d] = g;
+    cnt[1][d] = g + c0;
+    cnt[2][d] = g + c0 + c1;
+    cnt[3][d] = g + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    size_t idx = wbase + (size_t)r * 64 + lane;
+    if (idx < n) {
+      unsigned d = (k[r] >> shift) & mask;
+      unsigned dst = cnt[wave][d] + rnk[r];
+      keys_out[dst] = k[r];
+      vals_out[dst] = v[r];
+    }
+  }
+}
+
+size_t radix_sort_workspace_bytes(size_t n) {
+  size_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+  if (nblocks == 0) nblocks = 1;
+  size_t hist = align_up(nblocks * RS_MAX_BINS * sizeof(uint32_t), 256);
+  return hist + scan_workspace_bytes(nblocks * RS_MAX_BINS);
+}
+
+int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                         size_t n, int nbits, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) return BEVAMD_OK;
+  if (n >= (1ull << 32)) {
+    set_error("radix_sort_pairs_u32: n too large");
+    return BEVAMD_ERR_INVALID_ARG;
+  }
+  if (nbits < 1) nbits = 1;
+  if (nbits > 32) nbits = 32;
+  if (ws == nullptr || ws_bytes < radix_sort_workspace_bytes(n)) {
+    set_error("radix_sort_pairs_u32: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  const unsigned nblocks = (unsigned)((n + RS_TILE - 1) / RS_TILE);
+  uint32_t* hist = (uint32_t*)ws;
+  size_t hist_bytes = align_up((size_t)nblocks * RS_MAX_BINS * sizeof(uint32_t), 256);
+  void* scan_ws = (char*)ws + hist_bytes;
+  size_t scan_ws_bytes = ws_bytes - hist_bytes;
+
+  int npass = (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  // an odd number of passes would leave the result in the wrong buffer; the data
+  // must end in *_out, so start from the buffer that makes the last pass land there.
+  int bits_per_pass = (nbits + npass - 1) / npass;
+  uint32_t *ki = keys_in, *vi = vals_in, *ko = keys_out, *vo = vals_out;
+  if ((npass & 1) == 0) {
+    // even: in -> out -> in ... ends in `in`; copy first so that we end in out.
+    BEVAMD_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    BEVAMD_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    ki = keys_out; vi = vals_out; ko = keys_in; vo = vals_in;
+  }
+  int shift = 0;
+  for (int p = 0; p < npass; ++p) {
+    int bits = bits_per_pass;
+    if (shift + bits > nbits) bits = nbits - shift;
+    if (bits <= 0) bits = 1;
+    size_t hn = (size_t)nblocks << bits;
+    radix_hist_kernel<<<nblocks, RS_THREADS, 0, stream>>>(ki, n, shift, bits, nblocks, hist);
+    BEVAMD_LAUNCH_CHECK("radix_hist");
+    int rc = exclusive_scan_u32(hist, hist, hn, nullptr, scan_ws, scan_ws_bytes, stream);
+    if (rc != BEVAMD_OK) return rc;
+    radix_scatter_kernel<<<nblocks, RS_THREADS, 0, stream>>>(ki, vi, ko, vo, n, shift, bits, nblocks, hist);
+    BEVAMD_LAUNCH_CHECK("radix_scatter");
+    uint32_t* t;
+    t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+    shift += bits;
+  }
+  return BEVAMD_OK;
+}
+
+}  // namespace bevamd
+
+// ---- C-ABI test hooks for the primitives (used by tests/ only) --------------
+extern "C" {
+const char* bevamd_last_error(void) { return bevamd::get_error(); }
+
+size_t bevamd_scan_workspace_bytes(size_t n) { return bevamd::scan_workspace_bytes(n); }
+int bevamd_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* ws,
+                              size_t ws_bytes, void* stream) {
+  return bevamd::exclusive_scan_u32(in, out, n, total, ws, ws_bytes, (hipStream_t)stream);
+}
+size_t bevamd_radix_sort_workspace_bytes(size_t n) { return bevamd::radix_sort_workspace_bytes(n); }
+int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
+                                uint32_t* vals_out, size_t n, int nbits, void* ws, size_t ws_bytes,
+                                void* stream) {
+  return bevamd::radix_sort_pairs_u32(keys_in, vals_in, keys_out, vals_out, n, nbits, ws, ws_bytes,
+                                      (hipStream_t)stream);
+}
+}

@@ -1,0 +1,153 @@
+"""Seeded synthetic nuScenes-shaped inputs (no dataset, no network): the workload generator used
+by tests and bench.py.  Shapes and constants follow SURVEY.md §8d:
+
+  * camera rig: 6 cameras, 1600x900 sensor, fx=fy=1266, cx=816, cy=491, yaw 0/∓55/∓110/180 deg,
+    mounted (1.5, 0, -0.3) m from the LiDAR origin; eval-time image aug = resize 0.48, crop
+    (-32, -176)  (datasets/pipelines/transforms_3d.py:123-131 with resize_lim [0.48, 0.48]);
+  * frustum / geometry math restated from vtransforms/base.py:66-89, 92-135 in numpy fp32;
+  * LiDAR: 32-beam spinning model, 10 sweeps, ~300k points after range crop, shuffled.
+
+numpy only; everything is deterministic given the seed.
+"""
+import math
+
+import numpy as np
+
+# C+L flagship config (configs/nuscenes/det/transfusion/secfpn/camera+lidar/swint_v0p075)
+CL_CONFIG = dict(
+    image_size=(256, 704),
+    feature_size=(32, 88),
+    xbound=(-54.0, 54.0, 0.3),
+    ybound=(-54.0, 54.0, 0.3),
+    zbound=(-10.0, 10.0, 20.0),
+    dbound=(1.0, 60.0, 0.5),
+    channels=80,
+    num_cameras=6,
+    point_cloud_range=(-54.0, -54.0, -5.0, 54.0, 54.0, 3.0),
+    voxel_size=(0.075, 0.075, 0.2),
+    max_num_points=10,
+    max_voxels=(120000, 160000),
+    sparse_shape=(1440, 1440, 41),
+    point_dim=5,
+)
+
+# BASELINE config 1: camera-only LSS, 1 camera, 64x64 BEV
+LSS_SMALL_CONFIG = dict(
+    image_size=(256, 704),
+    feature_size=(32, 88),
+    xbound=(-51.2, 51.2, 1.6),
+    ybound=(-51.2, 51.2, 1.6),
+    zbound=(-10.0, 10.0, 20.0),
+    dbound=(1.0, 60.0, 1.0),
+    channels=80,
+    num_cameras=1,
+)
+
+
+def gen_dx_bx(xbound, ybound, zbound):
+    """vtransforms/base.py:15-21 (fp32 tensors; nx by float division then int truncation)."""
+    rows = [xbound, ybound, zbound]
+    dx = np.array([r[2] for r in rows], dtype=np.float32)
+    bx = np.array([r[0] + r[2] / 2.0 for r in rows], dtype=np.float32)
+    nx = np.array([int((r[1] - r[0]) / r[2]) for r in rows], dtype=np.int64)
+    return dx, bx, nx
+
+
+def create_frustum(image_size, feature_size, dbound):
+    """vtransforms/base.py:66-89 -> [D, fH, fW, 3] fp32 (u, v, depth)."""
+    iH, iW = image_size
+    fH, fW = feature_size
+    ds = np.arange(dbound[0], dbound[1], dbound[2], dtype=np.float32)
+    D = ds.shape[0]
+    xs = np.linspace(0, iW - 1, fW, dtype=np.float32)
+    ys = np.linspace(0, iH - 1, fH, dtype=np.float32)
+    fr = np.empty((D, fH, fW, 3), dtype=np.float32)
+    fr[..., 0] = xs[None, None, :]
+    fr[..., 1] = ys[None, :, None]
+    fr[..., 2] = ds[:, None, None]
+    return fr
+
+
+def camera_rig(num_cameras=6):
+    """Returns dict of fp32 arrays: camera2lidar_rots [N,3,3], camera2lidar_trans [N,3],
+    intrins [N,3,3], post_rots [N,3,3], post_trans [N,3]."""
+    yaws = [0.0, -55.0, 55.0, -110.0, 110.0, 180.0][:num_cameras]
+    base = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64)  # cam(x right,y down,z fwd) -> lidar
+    rots, trans, intr, prot, ptr = [], [], [], [], []
+    for y in yaws:
+        a = math.radians(y)
+        rz = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]], dtype=np.float64)
+        rots.append(rz @ base)
+        trans.append(rz @ np.array([1.5, 0.0, -0.3]))
+        intr.append(np.array([[1266.0, 0, 816.0], [0, 1266.0, 491.0], [0, 0, 1]]))
+        prot.append(np.diag([0.48, 0.48, 1.0]))
+        ptr.append(np.array([-32.0, -176.0, 0.0]))
+    f = lambda l: np.stack(l).astype(np.float32)
+    return dict(camera2lidar_rots=f(rots), camera2lidar_trans=f(trans), intrins=f(intr), post_rots=f(prot),
+                post_trans=f(ptr))
+
+
+def get_geometry(frustum, rig, batch=1):
+    """vtransforms/base.py:92-135 restated in numpy fp32 -> [B, N, D, fH, fW, 3] lidar-frame points."""
+    N = rig["intrins"].shape[0]
+    out = np.empty((batch, N) + frustum.shape, dtype=np.float32)
+    for n in range(N):
+        pts = frustum - rig["post_trans"][n].reshape(1, 1, 1, 3)
+        inv_post = np.linalg.inv(rig["post_rots"][n].astype(np.float32)).astype(np.float32)
+        pts = np.einsum("ij,dhwj->dhwi", inv_post, pts).astype(np.float32)
+        pts = np.concatenate([pts[..., :2] * pts[..., 2:3], pts[..., 2:3]], axis=-1).astype(np.float32)
+        combine = (rig["camera2lidar_rots"][n] @ np.linalg.inv(rig["intrins"][n]).astype(np.float32)).astype(np.float32)
+        pts = np.einsum("ij,dhwj->dhwi", combine, pts).astype(np.float32)
+        pts = pts + rig["camera2lidar_trans"][n].reshape(1, 1, 1, 3)
+        out[:, n] = pts[None]
+    return out
+
+
+def bev_pool_inputs(cfg=CL_CONFIG, batch=1, channels=None, seed=0, with_feats=True, feat_dtype=np.float32):
+    """Everything `BaseTransform.bev_pool` consumes for one batch: unfiltered geometry [N',3],
+    features [N',C], and the grid (origin = bx - dx/2, dx, nx).  N' = B*Ncam*D*fH*fW."""
+    dx, bx, nx = gen_dx_bx(cfg["xbound"], cfg["ybound"], cfg["zbound"])
+    fr = create_frustum(cfg["image_size"], cfg["feature_size"], cfg["dbound"])
+    rig = camera_rig(cfg["num_cameras"])
+    geom = get_geometry(fr, rig, batch=batch).reshape(-1, 3)
+    c = channels or cfg["channels"]
+    out = dict(geom=geom, dx=dx, bx=bx, nx=nx, origin=(bx - dx / np.float32(2.0)).astype(np.float32), channels=c,
+               batch=batch, D=fr.shape[0])
+    if with_feats:
+        rng = np.random.default_rng(seed)
+        out["feats"] = rng.standard_normal((geom.shape[0], c), dtype=np.float32).astype(feat_dtype)
+    return out
+
+
+def lidar_points(seed=0, sweeps=10, cfg=CL_CONFIG):
+    """32-beam x 1084-azimuth spinning LiDAR, `sweeps` sweeps with ego motion, ground + walls,
+    cropped to the point-cloud range and SHUFFLED.  -> [~300k, 5] fp32 (x, y, z, intensity, dt)."""
+    rng = np.random.default_rng(seed)
+    elev = np.radians(np.linspace(-30.67, 10.67, 32))
+    azim = np.linspace(-np.pi, np.pi, 1084, endpoint=False)
+    sector_wall = rng.uniform(8.0, 50.0, size=72)  # one wall distance per 5 degree sector
+    pts = []
+    for s in range(sweeps):
+        ego = np.array([0.5 * s, 0.02 * s, 0.0])
+        el, az = np.meshgrid(elev, azim, indexing="ij")
+        dirs = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], -1).reshape(-1, 3)
+        # range to ground plane z = -1.84 (sensor at z=0), or to the sector wall
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t_ground = np.where(dirs[:, 2] < -1e-3, -1.84 / dirs[:, 2], np.inf)
+        sector = ((np.degrees(np.arctan2(dirs[:, 1], dirs[:, 0])) + 180.0) // 5.0).astype(np.int64) % 72
+        horiz = np.maximum(np.hypot(dirs[:, 0], dirs[:, 1]), 1e-6)
+        t_wall = sector_wall[sector] / horiz
+        t = np.minimum(t_ground, t_wall)
+        t = t * (1.0 + 0.003 * rng.standard_normal(t.shape))
+        p = dirs * t[:, None] - ego[None]
+        p[:, 2] += 0.02 * rng.standard_normal(p.shape[0])
+        inten = rng.uniform(0, 255, size=(p.shape[0], 1))
+        dt = np.full((p.shape[0], 1), 0.05 * s)
+        pts.append(np.concatenate([p, inten, dt], 1))
+    pts = np.concatenate(pts, 0).astype(np.float32)
+    r = cfg["point_cloud_range"]
+    m = ((pts[:, 0] >= r[0]) & (pts[:, 0] < r[3]) & (pts[:, 1] >= r[1]) & (pts[:, 1] < r[4]) & (pts[:, 2] >= r[2])
+         & (pts[:, 2] < r[5]))
+    pts = pts[m]
+    rng.shuffle(pts, axis=0)
+    return np.ascontiguousarray(pts)

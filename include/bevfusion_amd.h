@@ -1,0 +1,129 @@
+/*
+ * bevfusion_amd — C ABI of the MI355X (gfx950) BEVFusion hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one native
+ * function that the reference (mit-han-lab/bevfusion, /root/reference) exposes to
+ * Python through pybind11.  Signatures use plain pointers and sizes only — no
+ * torch types — so the library can be bound from ctypes, pybind11 or any FFI.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the HIP default stream);
+ *     all work is enqueued on it and nothing synchronises unless stated;
+ *   - return value: BEVAMD_OK or an error code; bevamd_last_error() returns a
+ *     thread-local, human-readable message for the last non-zero return;
+ *   - scratch memory is caller-provided: `*_workspace_bytes()` gives the size, the
+ *     caller allocates (e.g. torch.empty(uint8)) and passes `ws, ws_bytes`;
+ *   - tensors are dense, row-major, contiguous, 16-byte aligned (torch allocations are).
+ */
+#ifndef BEVFUSION_AMD_H_
+#define BEVFUSION_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEVAMD_OK 0
+#define BEVAMD_ERR_INVALID_ARG 1
+#define BEVAMD_ERR_WORKSPACE 2
+#define BEVAMD_ERR_HIP 3
+#define BEVAMD_ERR_UNSUPPORTED 4
+
+const char* bevamd_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * bev_pool  (reference: mmdet3d/ops/bev_pool)
+ * ------------------------------------------------------------------------- */
+
+/* Replaces bev_pool_ext.bev_pool_forward
+ *   (mmdet3d/ops/bev_pool/src/bev_pool_cpu.cpp:22-47 -> bev_pool_cuda.cu:20-42,86-91).
+ * x                [n, c]   fp32, rows already sorted by rank
+ * geom_feats       [n, 4]   int32 (x, y, z, b) per sorted row
+ * interval_lengths [n_intervals] int32      (argument order as in the reference:
+ * interval_starts  [n_intervals] int32       lengths BEFORE starts)
+ * out              [b, d, h, w, c] fp32 — zero-filled by this call (the reference
+ *                  allocates torch::zeros), then out[b,z,x,y,:] = sum of the interval.
+ */
+int bevamd_bev_pool_forward(const float* x, const int* geom_feats, const int* interval_lengths,
+                            const int* interval_starts, float* out, int n, int c, int n_intervals,
+                            int b, int d, int h, int w, void* stream);
+
+/* Same with bf16 features (raw uint16 bit patterns), fp32 accumulate, fp32 out.
+ * BASELINE config 2 ("bf16 on 1 MI355X"); no reference counterpart (reference is fp32-only). */
+int bevamd_bev_pool_forward_bf16(const uint16_t* x, const int* geom_feats, const int* interval_lengths,
+                                 const int* interval_starts, float* out, int n, int c, int n_intervals,
+                                 int b, int d, int h, int w, void* stream);
+
+/* Replaces bev_pool_ext.bev_pool_backward
+ *   (bev_pool_cpu.cpp:60-87 -> bev_pool_cuda.cu:61-84,93-98).
+ * out_grad [b,d,h,w,c] fp32 contiguous;  x_grad [n, c] fp32.
+ * skip_zero_fill = 0 reproduces the reference (x_grad = zeros, then interval rows
+ * written); pass 1 when the intervals are known to cover [0, n). */
+int bevamd_bev_pool_backward(const float* out_grad, const int* geom_feats, const int* interval_lengths,
+                             const int* interval_starts, float* x_grad, int n, int c, int n_intervals,
+                             int b, int d, int h, int w, int skip_zero_fill, void* stream);
+
+/* Precompute = the PyTorch prologue of the reference op, on device, without host syncs:
+ *   rank = x*(W*D*B) + y*(D*B) + z*B + b          (bev_pool.py:86-91)
+ *   stable sort by rank                            (bev_pool.py:92-93; ties in input order)
+ *   interval starts / lengths                      (bev_pool.py:41-46)
+ * coords [n,4] (x,y,z,b), int32 or int64 (coords_are_int64).  Rows outside
+ * [0,h)x[0,w)x[0,d)x[0,b) are dropped (sorted behind every valid row) — a superset of the
+ * reference, whose caller filters first (vtransforms/base.py:160-169).
+ * Outputs:
+ *   ranks_sorted [n] u32 (dropped rows carry the sentinel b*d*h*w), order [n] u32
+ *     (order[j] = input row of sorted row j),
+ *   cell_start [b*d*h*w + 2] u32 — CSR over rank-ordered cells: rows of cell r are sorted rows
+ *     [cell_start[r], cell_start[r+1]); cell_start[b*d*h*w] = number of kept rows,
+ *   optional (NULL to skip) reference-shaped arrays: interval_starts / interval_lengths
+ *     (capacity min(n, b*d*h*w)), n_intervals_dev [1], geom_sorted [n,4] int32. */
+size_t bevamd_bev_pool_prepare_workspace_bytes(int n, int b, int d, int h, int w);
+int bevamd_bev_pool_prepare(const void* coords, int coords_are_int64, int n, int b, int d, int h, int w,
+                            uint32_t* ranks_sorted, uint32_t* order, uint32_t* cell_start,
+                            int* interval_starts, int* interval_lengths, int* n_intervals_dev,
+                            int* geom_sorted, void* ws, size_t ws_bytes, void* stream);
+
+/* Same, straight from the fp32 frustum geometry [n,3] in the lidar frame: replaces
+ * BaseTransform.bev_pool's index computation, batch-index concat and range mask
+ * (vtransforms/base.py:149-169): idx = trunc((p - (bx - dx/2)) / dx), b = i / (n / batch).
+ * bx_minus_half_dx, dx: HOST float[3]. */
+int bevamd_bev_pool_prepare_from_geom(const float* geom_xyz, int n, int b, int d, int h, int w,
+                                      const float* bx_minus_half_dx, const float* dx,
+                                      uint32_t* ranks_sorted, uint32_t* order, uint32_t* cell_start,
+                                      int* interval_starts, int* interval_lengths, int* n_intervals_dev,
+                                      int* geom_sorted, void* ws, size_t ws_bytes, void* stream);
+
+/* Native forward: reads the UNSORTED feature rows through `order` (the sorted copy
+ * `feats[indices]` of bev_pool.py:93 is never materialised) and walks the cell CSR, so ONE
+ * launch writes every cell of out [b,d,h,w,c] exactly once (empty cells as zeros): no memset,
+ * no interval list, no host sync where the reference has torch.where (bev_pool.py:42).
+ * x_is_bf16: 0 fp32, 1 bf16 (fp32 accumulate, fp32 out). */
+int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* order,
+                                  const uint32_t* cell_start, float* out, int n, int c, int b, int d,
+                                  int h, int w, void* stream);
+
+/* Native backward (row-parallel): x_grad[order[j], :] = out_grad[cell(ranks_sorted[j]), :],
+ * zeros for dropped rows.  Every row of x_grad [n,c] is written once. */
+int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order,
+                                  const uint32_t* ranks_sorted, float* x_grad, int n, int c, int b,
+                                  int d, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * device primitives (exposed for tests; used by every precompute path)
+ * ------------------------------------------------------------------------- */
+size_t bevamd_scan_workspace_bytes(size_t n);
+int bevamd_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* ws,
+                              size_t ws_bytes, void* stream);
+size_t bevamd_radix_sort_workspace_bytes(size_t n);
+/* stable; sorts on the low nbits of the key; keys_in/vals_in are clobbered */
+int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
+                                uint32_t* vals_out, size_t n, int nbits, void* ws, size_t ws_bytes,
+                                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVFUSION_AMD_H_ */

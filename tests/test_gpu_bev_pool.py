@@ -1,0 +1,234 @@
+"""GPU parity: HIP bev_pool (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): ranks / sort / interval arrays bit-exact; BEV feature sums within
+1e-4 of the float64 oracle (ABS_TOL below; sums of up to ~900 N(0,1) fp32 values per cell)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from bevfusion_amd import _capi, synth
+from bevfusion_amd.bev_pool import BevPoolPlan, QuickCumsumCuda, bev_pool, bev_pool_ext
+
+pytestmark = pytest.mark.gpu
+
+ABS_TOL = 1e-4
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _case(seed, n, B, D, H, W, c, hot=None):
+    rng = np.random.default_rng(seed)
+    coords = np.stack([rng.integers(0, H, n), rng.integers(0, W, n), rng.integers(0, D, n), rng.integers(0, B, n)], 1)
+    if hot is not None:  # a heavy-tailed interval: `hot` rows in one cell
+        coords[:hot] = coords[0]
+    feats = (rng.standard_normal((n, c)) * 0.25).astype(np.float32)
+    return feats, coords.astype(np.int64)
+
+
+def _sorted_inputs(feats, coords, B, D, H, W, dev):
+    pro = oracle.bev_pool_prologue(coords, B, D, H, W)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    return pro, t(feats[pro["order"]], torch.float32), t(pro["geom_sorted"], torch.int32), \
+        t(pro["interval_lengths"], torch.int32), t(pro["interval_starts"], torch.int32)
+
+
+CASES = [
+    # n, B, D, H, W, C, hot
+    (1, 1, 1, 1, 1, 4, None),
+    (777, 2, 3, 5, 7, 80, None),
+    (20000, 1, 1, 40, 40, 80, 3000),      # one 3000-row interval among short ones
+    (5000, 3, 1, 8, 8, 64, None),
+    (5000, 1, 2, 8, 8, 128, None),
+    (3000, 1, 1, 6, 6, 256, None),
+    (3000, 2, 1, 6, 6, 3, None),          # scalar path (C % 4 != 0)
+    (3000, 1, 1, 6, 6, 1, None),
+    (2000, 1, 1, 5, 5, 260, None),        # scalar path (C/4 > 64)
+    (4000, 1, 1, 9, 9, 12, None),         # 3 lanes per row, 21 rows per wave instruction
+    (100000, 4, 1, 64, 64, 80, 5000),
+]
+
+
+@pytest.mark.parametrize("n,B,D,H,W,c,hot", CASES)
+def test_forward_drop_in_vs_oracle(dev, n, B, D, H, W, c, hot):
+    feats, coords = _case(n + c, n, B, D, H, W, c, hot)
+    pro, x, geom, lengths, starts = _sorted_inputs(feats, coords, B, D, H, W, dev)
+    out = bev_pool_ext.bev_pool_forward(x, geom, lengths, starts, B, D, H, W)
+    assert out.shape == (B, D, H, W, c) and out.dtype == torch.float32
+    ref = oracle.bev_pool_forward_sorted(feats[pro["order"]], pro["geom_sorted"], pro["interval_starts"],
+                                         pro["interval_lengths"], B, D, H, W)
+    err = np.max(np.abs(out.cpu().numpy().astype(np.float64) - ref))
+    assert err <= ABS_TOL, err
+    # cells no interval touches are exactly zero
+    g = pro["geom_sorted"][pro["interval_starts"]]
+    touched = np.zeros((B, D, H, W), bool)
+    touched[g[:, 3], g[:, 2], g[:, 0], g[:, 1]] = True
+    assert np.all(out.cpu().numpy()[~touched] == 0)
+
+
+@pytest.mark.parametrize("n,B,D,H,W,c,hot", CASES[:8])
+def test_backward_drop_in_is_bit_exact(dev, n, B, D, H, W, c, hot):
+    feats, coords = _case(n + c + 1, n, B, D, H, W, c, hot)
+    pro, x, geom, lengths, starts = _sorted_inputs(feats, coords, B, D, H, W, dev)
+    og = np.random.default_rng(5).standard_normal((B, D, H, W, c)).astype(np.float32)
+    xg = bev_pool_ext.bev_pool_backward(torch.from_numpy(og).to(dev), geom, lengths, starts, B, D, H, W)
+    ref = oracle.bev_pool_backward_sorted(og, pro["geom_sorted"], pro["interval_starts"], pro["interval_lengths"], n,
+                                          B, D, H, W)
+    assert np.array_equal(xg.cpu().numpy(), ref)
+
+
+def test_backward_zero_fills_rows_outside_intervals(dev):
+    """bev_pool_cpu.cpp:78 allocates x_grad with torch::zeros; rows no interval covers stay zero."""
+    B, D, H, W, c, n = 1, 1, 4, 4, 8, 100
+    feats, coords = _case(9, n, B, D, H, W, c)
+    pro, x, geom, lengths, starts = _sorted_inputs(feats, coords, B, D, H, W, dev)
+    og = torch.ones(B, D, H, W, c, device=dev)
+    xg = bev_pool_ext.bev_pool_backward(og, geom, lengths[:1], starts[:1], B, D, H, W)
+    L0 = int(pro["interval_lengths"][0])
+    assert torch.all(xg[:L0] == 1) and torch.all(xg[L0:] == 0)
+
+
+@pytest.mark.parametrize("n,B,D,H,W", [(1, 1, 1, 1, 1), (4097, 2, 3, 5, 7), (200000, 1, 1, 360, 360),
+                                       (150000, 8, 1, 90, 90), (30000, 2, 2, 16, 16)])
+@pytest.mark.parametrize("i64", [True, False])
+def test_prepare_ranks_sort_intervals_bit_exact(dev, n, B, D, H, W, i64):
+    _, coords = _case(n, n, B, D, H, W, 1)
+    pro = oracle.bev_pool_prologue(coords, B, D, H, W)
+    ct = torch.from_numpy(coords if i64 else coords.astype(np.int32)).to(dev)
+    plan = BevPoolPlan.from_coords(ct, B, D, H, W, want_intervals=True, want_geom=True)
+    k = plan.n_intervals()
+    assert k == len(pro["interval_starts"]) and plan.n_kept() == n
+    cs = plan.cell_start.cpu().numpy().astype(np.int64)
+    counts = np.bincount(pro["ranks"], minlength=B * D * H * W)
+    assert np.array_equal(cs[1:B * D * H * W + 1] - cs[:B * D * H * W], counts) and cs[-1] == n
+    assert np.array_equal(plan.ranks_sorted.cpu().numpy().astype(np.int64), pro["ranks_sorted"])
+    assert np.array_equal(plan.order.cpu().numpy().astype(np.int64), pro["order"])  # stable tie order
+    assert np.array_equal(plan.interval_starts[:k].cpu().numpy(), pro["interval_starts"])
+    assert np.array_equal(plan.interval_lengths[:k].cpu().numpy(), pro["interval_lengths"])
+    assert np.array_equal(plan.geom_sorted.cpu().numpy(), pro["geom_sorted"])
+
+
+def test_prepare_drops_out_of_range_rows(dev):
+    B, D, H, W, n = 2, 1, 6, 5, 5000
+    rng = np.random.default_rng(0)
+    coords = np.stack([rng.integers(-2, H + 2, n), rng.integers(-2, W + 2, n), rng.integers(-1, D + 1, n),
+                       rng.integers(0, B, n)], 1).astype(np.int64)
+    kept = (coords[:, 0] >= 0) & (coords[:, 0] < H) & (coords[:, 1] >= 0) & (coords[:, 1] < W) & \
+        (coords[:, 2] >= 0) & (coords[:, 2] < D)
+    pro = oracle.bev_pool_prologue(coords[kept], B, D, H, W)
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, D, H, W)
+    nk = plan.n_kept()
+    assert nk == int(kept.sum())
+    assert np.array_equal(plan.ranks_sorted[:nk].cpu().numpy().astype(np.int64), pro["ranks_sorted"])
+    assert np.array_equal(plan.order[:nk].cpu().numpy(), np.nonzero(kept)[0][pro["order"]])
+    feats = rng.standard_normal((n, 16)).astype(np.float32)
+    out = plan.forward(torch.from_numpy(feats).to(dev))
+    ref = oracle.bev_pool(feats[kept], coords[kept], B, D, H, W).transpose(0, 2, 3, 4, 1)
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= ABS_TOL
+
+
+@pytest.mark.parametrize("n,B,D,H,W,c,hot", [CASES[1], CASES[2], CASES[6], CASES[10]])
+def test_full_op_matches_oracle(dev, n, B, D, H, W, c, hot):
+    """bev_pool(feats, coords, B, D, H, W) -> [B, C, D, H, W], unsorted inputs, like the reference."""
+    feats, coords = _case(n, n, B, D, H, W, c, hot)
+    out = bev_pool(torch.from_numpy(feats).to(dev), torch.from_numpy(coords).to(dev), B, D, H, W)
+    assert out.shape == (B, c, D, H, W) and out.is_contiguous()
+    ref = oracle.bev_pool(feats, coords, B, D, H, W)
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= ABS_TOL
+    view = bev_pool(torch.from_numpy(feats).to(dev), torch.from_numpy(coords).to(dev), B, D, H, W,
+                    channels_last_view=True)
+    assert torch.equal(view, out)
+
+
+def test_bf16_features(dev):
+    n, B, D, H, W, c = 30000, 2, 1, 20, 20, 80
+    feats, coords = _case(3, n, B, D, H, W, c, 2000)
+    fb = torch.from_numpy(feats).to(dev).bfloat16()
+    out = bev_pool(fb, torch.from_numpy(coords).to(dev), B, D, H, W)
+    ref = oracle.bev_pool(fb.float().cpu().numpy(), coords, B, D, H, W)  # oracle on the bf16-rounded values
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= ABS_TOL
+    pro, x, geom, lengths, starts = _sorted_inputs(fb.float().cpu().numpy(), coords, B, D, H, W, dev)
+    out2 = bev_pool_ext.bev_pool_forward(x.bfloat16(), geom, lengths, starts, B, D, H, W)
+    assert np.max(np.abs(out2.permute(0, 4, 1, 2, 3).cpu().numpy() - ref)) <= ABS_TOL
+
+
+def test_autograd_through_plan_and_quickcumsum(dev):
+    n, B, D, H, W, c = 4000, 2, 1, 8, 8, 16
+    feats, coords = _case(11, n, B, D, H, W, c)
+    x = torch.from_numpy(feats).to(dev).requires_grad_(True)
+    out = bev_pool(x, torch.from_numpy(coords).to(dev), B, D, H, W)
+    wgt = torch.randn_like(out)
+    (out * wgt).sum().backward()
+    exp = wgt.permute(0, 2, 3, 4, 1)[coords[:, 3], coords[:, 2], coords[:, 0], coords[:, 1]]
+    assert torch.equal(x.grad, exp)
+    # reference-shaped autograd function on pre-sorted inputs
+    pro = oracle.bev_pool_prologue(coords, B, D, H, W)
+    xs = torch.from_numpy(feats[pro["order"]]).to(dev).requires_grad_(True)
+    o2 = QuickCumsumCuda.apply(xs, torch.from_numpy(coords[pro["order"]]).to(dev),
+                               torch.from_numpy(pro["ranks_sorted"]).to(dev), B, D, H, W)
+    assert torch.allclose(o2.permute(0, 4, 1, 2, 3), out, atol=1e-5)
+    (o2.permute(0, 4, 1, 2, 3) * wgt).sum().backward()
+    assert torch.equal(xs.grad, exp[torch.from_numpy(pro["order"]).to(dev)])
+
+
+def test_empty_inputs(dev):
+    out = bev_pool(torch.zeros(0, 8, device=dev), torch.zeros(0, 4, dtype=torch.long, device=dev), 1, 1, 3, 3)
+    assert out.shape == (1, 8, 1, 3, 3) and torch.all(out == 0)
+
+
+def test_plan_from_geometry_matches_oracle_cell_index(dev):
+    """BASELINE config 1 shapes (1 camera, 64x64 BEV): geometry -> truncation -> mask -> ranks."""
+    inp = synth.bev_pool_inputs(synth.LSS_SMALL_CONFIG, batch=2, channels=8, seed=1)
+    coords, kept = oracle.bev_cell_index(inp["geom"], 2, inp["origin"], inp["dx"], inp["nx"])
+    H, W, D = (int(v) for v in inp["nx"])
+    pro = oracle.bev_pool_prologue(coords[kept], 2, D, H, W)
+    plan = BevPoolPlan.from_geometry(torch.from_numpy(inp["geom"]).to(dev), 2, inp["origin"], inp["dx"], inp["nx"],
+                                     want_intervals=True)
+    nk = plan.n_kept()
+    assert nk == int(kept.sum())
+    assert np.array_equal(plan.ranks_sorted[:nk].cpu().numpy().astype(np.int64), pro["ranks_sorted"])
+    k = plan.n_intervals()
+    assert np.array_equal(plan.interval_lengths[:k].cpu().numpy(), pro["interval_lengths"])
+    out = plan.forward(torch.from_numpy(inp["feats"]).to(dev))
+    ref = oracle.bev_pool(inp["feats"][kept], coords[kept], 2, D, H, W).transpose(0, 2, 3, 4, 1)
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= ABS_TOL
+
+
+def test_flagship_size_properties(dev):
+    """Full C+L size (1 993 728 frustum points, C=80, 360x360): size-independent properties —
+    linearity, channel-sum checksum, and the interval statistics of SURVEY.md §8d."""
+    inp = synth.bev_pool_inputs(seed=0)
+    H, W, D = (int(v) for v in inp["nx"])
+    geom = torch.from_numpy(inp["geom"]).to(dev)
+    plan = BevPoolPlan.from_geometry(geom, 1, inp["origin"], inp["dx"], inp["nx"], want_intervals=True)
+    assert plan.n_kept() == 1815552 and plan.n_intervals() == 45469
+    L = plan.interval_lengths[:45469]
+    assert int(L.max()) == 864 and int(L.sum()) == 1815552
+    x = torch.from_numpy(inp["feats"]).to(dev)
+    out = plan.forward(x)
+    # checksum of checksums: total mass is preserved per channel (float64 on the kept rows)
+    kept_rows = plan.order[:1815552].long()
+    exp = x[kept_rows].double().sum(0)
+    got = out.double().sum((0, 1, 2, 3))
+    assert torch.max(torch.abs(exp - got)) < 1e-2
+    # linearity: pool(2x + y) == 2 pool(x) + pool(y) to rounding
+    y = torch.roll(x, 1, 0)
+    lhs = plan.forward(2 * x + y)
+    rhs = 2 * out + plan.forward(y)
+    assert torch.max(torch.abs(lhs - rhs)) < 1e-3
+    # non-empty cell count
+    assert int((out.abs().sum(-1) > 0).sum()) == 45469
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "bev_pool_ref_small.npz")), reason="golden not committed")
+def test_against_reference_kernel_golden(dev):
+    z = np.load(os.path.join(GOLDEN, "bev_pool_ref_small.npz"))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    B, D, H, W = (int(z[k]) for k in "BDHW")
+    out = bev_pool_ext.bev_pool_forward(t(z["x"]), t(z["geom"]), t(z["interval_lengths"]), t(z["interval_starts"]),
+                                        B, D, H, W)
+    assert np.max(np.abs(out.cpu().numpy() - z["out"])) <= ABS_TOL
+    xg = bev_pool_ext.bev_pool_backward(t(z["out_grad"]), t(z["geom"]), t(z["interval_lengths"]),
+                                        t(z["interval_starts"]), B, D, H, W)
+    assert np.array_equal(xg.cpu().numpy(), z["x_grad"])

@@ -1,0 +1,72 @@
+"""GPU: exclusive scan and stable radix sort (bevfusion_amd/csrc/primitives.hip) vs numpy."""
+import numpy as np
+import pytest
+import torch
+
+from bevfusion_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _scan(x, dev):
+    lib = _capi.load()
+    n = x.shape[0]
+    t = torch.from_numpy(x.astype(np.int32)).to(dev)
+    out = torch.empty_like(t)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.bevamd_scan_workspace_bytes(n)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    rc = lib.bevamd_exclusive_scan_u32(_capi.ptr(t), _capi.ptr(out), n, _capi.ptr(total), _capi.ptr(ws), wsb,
+                                       _capi.stream_ptr(dev))
+    _capi.check(rc, "scan")
+    return out.cpu().numpy().astype(np.int64), int(total.item())
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 1023, 1024, 1025, 2048, 5000, 131072, 131073, 1 << 20, 3000001])
+def test_exclusive_scan(dev, n):
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 5, n).astype(np.int64)
+    got, total = _scan(x, dev)
+    exp = np.cumsum(x) - x
+    assert np.array_equal(got, exp)
+    assert total == int(x.sum())
+
+
+def _sort(keys, vals, nbits, dev):
+    lib = _capi.load()
+    n = keys.shape[0]
+    k = torch.from_numpy(keys.astype(np.int64).astype(np.uint32).view(np.int32)).to(dev)
+    v = torch.from_numpy(vals.astype(np.uint32).view(np.int32)).to(dev)
+    ko, vo = torch.empty_like(k), torch.empty_like(v)
+    wsb = lib.bevamd_radix_sort_workspace_bytes(n)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    rc = lib.bevamd_radix_sort_pairs_u32(_capi.ptr(k), _capi.ptr(v), _capi.ptr(ko), _capi.ptr(vo), n, nbits,
+                                         _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+    _capi.check(rc, "radix sort")
+    return ko.cpu().numpy().view(np.uint32), vo.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("n,nbits", [(1, 8), (64, 3), (4095, 17), (4096, 17), (4097, 20), (100000, 27),
+                                     (1000003, 32), (2000000, 18), (50000, 1), (70000, 9)])
+def test_radix_sort_is_a_stable_sort(dev, n, nbits):
+    rng = np.random.default_rng(n + nbits)
+    hi = (1 << nbits) - 1
+    # few distinct keys on purpose: long runs of ties exercise stability
+    keys = rng.integers(0, min(hi, 5000) + 1, n).astype(np.uint32)
+    if nbits == 32:
+        keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        keys[::3] = keys[0]
+    vals = np.arange(n, dtype=np.uint32)
+    ko, vo = _sort(keys, vals, nbits, dev)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ko, keys[order])
+    assert np.array_equal(vo, vals[order])
+
+
+def test_radix_sort_all_equal_and_already_sorted(dev):
+    n = 300000
+    ko, vo = _sort(np.full(n, 7, np.uint32), np.arange(n, dtype=np.uint32), 8, dev)
+    assert np.all(ko == 7) and np.array_equal(vo, np.arange(n, dtype=np.uint32))
+    keys = np.arange(n, dtype=np.uint32)
+    ko, vo = _sort(keys, keys[::-1].copy(), 19, dev)
+    assert np.array_equal(ko, keys) and np.array_equal(vo, keys[::-1])
