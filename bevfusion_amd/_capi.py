@@ -28,7 +28,13 @@ _SIGNATURES = {
     "bevamd_bev_pool_prepare": (I, [P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_prepare_from_geom": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_forward_cells": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_forward_cells_tuned": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    # voxelization
+    "bevamd_hard_voxelize_workspace_bytes": (Z, [I]),
+    "bevamd_hard_voxelize": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, Z, P]),
+    "bevamd_dynamic_voxelize": (I, [P, P, P, P, I, I, I, P]),
+    "bevamd_voxelize_mean": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, Z, P]),
     # primitives
     "bevamd_scan_workspace_bytes": (Z, [Z]),
     "bevamd_exclusive_scan_u32": (I, [P, P, Z, P, P, Z, P]),
@@ -51,6 +57,11 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is required (no CPU/PyTorch fallback). "
             "Build it with `python -m bevfusion_amd.build` or `__graft_entry__.build()`."
         )
+    # PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch FIRST so that the
+    # dynamic loader binds this library to the runtime that owns torch's device memory and streams;
+    # loading ours first would put two HIP runtimes in the process ("no ROCm-capable device").
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         try:
@@ -93,3 +104,8 @@ def stream_ptr(device=None):
 def float3(values):
     arr = (c_float * 3)(*[float(v) for v in values])
     return arr
+
+
+def floats(values):
+    vals = [float(v) for v in values]
+    return (c_float * len(vals))(*vals)

@@ -59,54 +59,42 @@ __device__ __forceinline__ void decode_rank(uint32_t r, const BevDims& s, int& g
   gx = r;
 }
 
-// Sum rows [0,len) of one cell.  Lane (slot, cv) takes rows slot, slot+rpi, ... and the
-// 16-byte column vector cv; 4 loads in flight per lane.  ord == nullptr: rows are
-// contiguous from `first_row`; else row r is ord[r].
-template <typename VecT, int VEC>
+// Sum rows [0,len) of one cell.  The calling lane takes rows r0, r0+step, ... and the 16-byte
+// column vector cv; U independent loads in flight per lane.  INDEXED: row r is ord[r], else rows
+// are contiguous from `first_row`.
+template <typename VecT, int VEC, int U, bool INDEXED>
 __device__ __forceinline__ void accumulate_rows(Acc<VEC>& acc, const VecT* __restrict__ x,
                                                 const uint32_t* __restrict__ ord, size_t first_row, int len,
-                                                int slot, int cv, int lpr, int rpi) {
-  int r = slot;
-  const int step = rpi;
-  if (ord) {
-    for (; r + 3 * step < len; r += 4 * step) {
-      uint32_t i0 = ord[r], i1 = ord[r + step], i2 = ord[r + 2 * step], i3 = ord[r + 3 * step];
-      VecT a0 = x[(size_t)i0 * lpr + cv];
-      VecT a1 = x[(size_t)i1 * lpr + cv];
-      VecT a2 = x[(size_t)i2 * lpr + cv];
-      VecT a3 = x[(size_t)i3 * lpr + cv];
-      acc_add(acc, a0); acc_add(acc, a1); acc_add(acc, a2); acc_add(acc, a3);
+                                                int r0, int step, int cv, int lpr) {
+  int r = r0;
+  for (; r + (U - 1) * step < len; r += U * step) {
+    VecT a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      size_t row = INDEXED ? (size_t)ord[r + u * step] : first_row + (size_t)(r + u * step);
+      a[u] = x[row * lpr + cv];
     }
-    for (; r < len; r += step) {
-      VecT a0 = x[(size_t)ord[r] * lpr + cv];
-      acc_add(acc, a0);
-    }
-  } else {
-    const VecT* xr = x + first_row * lpr + cv;
-    for (; r + 3 * step < len; r += 4 * step) {
-      VecT a0 = xr[(size_t)r * lpr];
-      VecT a1 = xr[(size_t)(r + step) * lpr];
-      VecT a2 = xr[(size_t)(r + 2 * step) * lpr];
-      VecT a3 = xr[(size_t)(r + 3 * step) * lpr];
-      acc_add(acc, a0); acc_add(acc, a1); acc_add(acc, a2); acc_add(acc, a3);
-    }
-    for (; r < len; r += step) {
-      VecT a0 = xr[(size_t)r * lpr];
-      acc_add(acc, a0);
-    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc_add(acc, a[u]);
+  }
+  for (; r < len; r += step) {
+    size_t row = INDEXED ? (size_t)ord[r] : first_row + (size_t)r;
+    VecT a0 = x[row * lpr + cv];
+    acc_add(acc, a0);
   }
 }
 
-// fold the row-slots into slot 0 (wave-uniform trip count: every lane shuffles)
+// fold the row-slots into slot 0.  Wave-uniform trip count (every lane shuffles); the partials
+// are read-only during the fold — lanes of other slots receive wrapped-around garbage in `tot`
+// that nobody stores.
 template <int VEC>
 __device__ __forceinline__ void fold_slots(Acc<VEC>& acc, int lane, int lpr, int rpi) {
+  Acc<VEC> tot = acc;
   for (int sl = 1; sl < rpi; ++sl) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float o = __shfl(acc.v[j], lane + sl * lpr, 64);
-      acc.v[j] += o;
-    }
+    for (int j = 0; j < VEC; ++j) tot.v[j] += __shfl(acc.v[j], lane + sl * lpr, 64);
   }
+  acc = tot;
 }
 
 template <int VEC>
@@ -134,7 +122,7 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_intervals_vec_kernel(
   Acc<VEC> acc;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
-  if (slot < rpi) accumulate_rows<VecT, VEC>(acc, x, nullptr, (size_t)start, len, slot, cv, lpr, rpi);
+  if (slot < rpi) accumulate_rows<VecT, VEC, 4, false>(acc, x, nullptr, (size_t)start, len, slot, rpi, cv, lpr);
   fold_slots<VEC>(acc, lane, lpr, rpi);
   if (slot == 0) {
     const int* g = geom + (size_t)start * 4;
@@ -166,7 +154,7 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_intervals_scalar_kernel(
 // ---------------------------------------------------------------------------
 // forward over the cell CSR (native path): one launch writes every output cell
 // ---------------------------------------------------------------------------
-template <typename VecT, int VEC>
+template <typename VecT, int VEC, int U>
 __global__ __launch_bounds__(256) void bev_pool_fwd_cells_vec_kernel(
     const VecT* __restrict__ x, const uint32_t* __restrict__ order, const uint32_t* __restrict__ cell_start,
     uint32_t ncells, float* __restrict__ out, int lpr, int rpi, BevDims s) {
@@ -181,13 +169,83 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_cells_vec_kernel(
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
   if (len > 0) {  // wave-uniform
-    if (slot < rpi) accumulate_rows<VecT, VEC>(acc, x, order + start, 0, len, slot, cv, lpr, rpi);
+    if (slot < rpi) accumulate_rows<VecT, VEC, U, true>(acc, x, order + start, 0, len, slot, rpi, cv, lpr);
     fold_slots<VEC>(acc, lane, lpr, rpi);
   }
   if (slot == 0) {
     int gx, gy, gz, gb;
     decode_rank(cell, s, gx, gy, gz, gb);
     store_cell<VEC>(acc, out + cell_offset(gx, gy, gz, gb, s), cv);
+  }
+}
+
+// Cooperative flavour: a workgroup of NW waves owns NW consecutive cells and EVERY wave works on
+// EVERY cell (row r of a cell goes to wave (r / rpi) % NW), so a 900-row cell is walked by NW*rpi
+// row-slots at once instead of rpi: the longest dependent-load chain — which bounds the kernel when
+// cell populations are heavy-tailed — shrinks NW-fold, and each lane has loads of up to NW cells in
+// flight.  Partials meet in LDS once; wave w finishes and stores cell w.
+template <typename VecT, int VEC, int U, int NW>
+__global__ __launch_bounds__(NW * 64) void bev_pool_fwd_cells_coop_kernel(
+    const VecT* __restrict__ x, const uint32_t* __restrict__ order, const uint32_t* __restrict__ cell_start,
+    uint32_t ncells, float* __restrict__ out, int lpr, int rpi, BevDims s) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [NW cells][NW waves][lpr][VEC]
+  const uint32_t cell0 = blockIdx.x * (uint32_t)NW;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+
+  uint32_t cs[NW + 1];
+#pragma unroll
+  for (int q = 0; q <= NW; ++q) {
+    uint32_t c = cell0 + (uint32_t)q;
+    cs[q] = cell_start[c < ncells ? c : ncells];
+  }
+  Acc<VEC> acc[NW];
+#pragma unroll
+  for (int q = 0; q < NW; ++q)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[q].v[j] = 0.f;
+
+  const bool any = cs[NW] != cs[0];  // block-uniform
+  if (any) {
+    if (slot < rpi) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q)
+        accumulate_rows<VecT, VEC, U, true>(acc[q], x, order + cs[q], 0, (int)(cs[q + 1] - cs[q]),
+                                            wave * rpi + slot, NW * rpi, cv, lpr);
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      fold_slots<VEC>(acc[q], lane, lpr, rpi);
+      if (slot == 0) {
+        float4* p = (float4*)(part + ((size_t)(q * NW + wave) * lpr + cv) * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC / 4; ++j)
+          p[j] = make_float4(acc[q].v[4 * j], acc[q].v[4 * j + 1], acc[q].v[4 * j + 2], acc[q].v[4 * j + 3]);
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t cell = cell0 + (uint32_t)wave;
+  if (cell < ncells && slot == 0) {
+    Acc<VEC> tot;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) tot.v[j] = 0.f;
+    if (any) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float4* p = (const float4*)(part + ((size_t)(wave * NW + w) * lpr + cv) * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC / 4; ++j) {
+          float4 t = p[j];
+          tot.v[4 * j] += t.x; tot.v[4 * j + 1] += t.y; tot.v[4 * j + 2] += t.z; tot.v[4 * j + 3] += t.w;
+        }
+      }
+    }
+    int gx, gy, gz, gb;
+    decode_rank(cell, s, gx, gy, gz, gb);
+    store_cell<VEC>(tot, out + cell_offset(gx, gy, gz, gb, s), cv);
   }
 }
 
@@ -296,8 +354,7 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_rows_scalar_kernel(
 template <typename CoordT>
 __global__ __launch_bounds__(256) void bev_rank_kernel(const CoordT* __restrict__ coords, int n, BevDims s,
                                                        uint32_t ncells, uint32_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals,
-                                                       uint32_t* __restrict__ cell_count) {
+                                                       uint32_t* __restrict__ vals) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const CoordT* c = coords + (size_t)i * 4;
@@ -306,7 +363,6 @@ __global__ __launch_bounds__(256) void bev_rank_kernel(const CoordT* __restrict_
   uint32_t r = ok ? (uint32_t)(((gx * s.W + gy) * s.D + gz) * s.B + gb) : ncells;
   keys[i] = r;
   vals[i] = (uint32_t)i;
-  atomicAdd(&cell_count[r], 1u);
 }
 
 // Same, straight from fp32 lidar-frame geometry (vtransforms/base.py:149):
@@ -317,8 +373,7 @@ __global__ __launch_bounds__(256) void bev_rank_from_geom_kernel(const float* __
                                                                  float oz, float dx, float dy, float dz,
                                                                  BevDims s, uint32_t ncells,
                                                                  uint32_t* __restrict__ keys,
-                                                                 uint32_t* __restrict__ vals,
-                                                                 uint32_t* __restrict__ cell_count) {
+                                                                 uint32_t* __restrict__ vals) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float* p = geom + (size_t)i * 3;
@@ -335,7 +390,21 @@ __global__ __launch_bounds__(256) void bev_rank_from_geom_kernel(const float* __
   uint32_t r = ok ? (uint32_t)(((gx * s.W + gy) * s.D + gz) * s.B + gb) : ncells;
   keys[i] = r;
   vals[i] = (uint32_t)i;
-  atomicAdd(&cell_count[r], 1u);
+}
+
+// CSR over rank-ordered cells from the sorted keys: cell_start[c] = lower_bound(keys, c).
+// (A histogram with atomics costs 2 ms here: 178 k dropped rows hammer one sentinel counter.)
+__global__ __launch_bounds__(256) void bev_cell_start_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                             uint32_t ncells, uint32_t* __restrict__ cell_start) {
+  uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c > ncells + 1u) return;
+  uint32_t lo = 0, hi = n;
+  if (c > ncells) lo = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  cell_start[c] = lo;
 }
 
 // interval arrays in the reference's shape, compacted from the CSR: interval k is the k-th
@@ -448,9 +517,9 @@ static int prepare_tail(PrepBuffers& pb, int n, BevDims s, uint32_t ncells, uint
   int rc = radix_sort_pairs_u32(pb.keys_a, pb.vals_a, ranks_sorted, order, (size_t)n, nbits, pb.sort_ws,
                                 pb.sort_ws_bytes, stream);
   if (rc != BEVAMD_OK) return rc;
-  // cell_start currently holds the per-cell counts ([ncells] + sentinel bucket + 0): scan in place
-  rc = exclusive_scan_u32(cell_start, cell_start, (size_t)ncells + 2, nullptr, pb.sort_ws, pb.sort_ws_bytes, stream);
-  if (rc != BEVAMD_OK) return rc;
+  bev_cell_start_kernel<<<dim3(cdiv((long long)ncells + 2, 256)), dim3(256), 0, stream>>>(ranks_sorted, (uint32_t)n,
+                                                                                           ncells, cell_start);
+  BEVAMD_LAUNCH_CHECK("bev_cell_start");
   if (starts && lengths && n_int_dev) {
     dim3 grid(cdiv(ncells, 256)), block(256);
     bev_cell_flags_kernel<<<grid, block, 0, stream>>>(cell_start, ncells, pb.flags);
@@ -465,6 +534,34 @@ static int prepare_tail(PrepBuffers& pb, int n, BevDims s, uint32_t ncells, uint
     bev_geom_from_ranks_kernel<<<dim3(cdiv(n, 256)), dim3(256), 0, stream>>>(ranks_sorted, n, s, ncells, geom_sorted);
     BEVAMD_LAUNCH_CHECK("bev_geom_from_ranks");
   }
+  return BEVAMD_OK;
+}
+
+// variant: 0 = default (tuned), 1 = wave-per-cell U4, 2 = wave-per-cell U8,
+//          3 = coop NW4 U4, 4 = coop NW4 U8, 5 = coop NW8 U4, 6 = coop NW8 U2, 7 = coop NW4 U2
+#define BEVAMD_FWD_CELLS_DEFAULT_VARIANT 3
+template <typename VecT, int VEC>
+static int launch_cells_vec(const void* x, const uint32_t* order, const uint32_t* cell_start, uint32_t ncells,
+                            float* out, int lpr, int rpi, BevDims s, int variant, hipStream_t stream) {
+  const VecT* xv = (const VecT*)x;
+#define BEVAMD_COOP(U, NW)                                                                                 \
+  bev_pool_fwd_cells_coop_kernel<VecT, VEC, U, NW>                                                         \
+      <<<dim3(cdiv(ncells, NW)), dim3(NW * 64), (size_t)NW * NW * lpr * VEC * sizeof(float), stream>>>(    \
+          xv, order, cell_start, ncells, out, lpr, rpi, s)
+  switch (variant) {
+    case 1: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 4><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
+                xv, order, cell_start, ncells, out, lpr, rpi, s); break;
+    case 2: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 8><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
+                xv, order, cell_start, ncells, out, lpr, rpi, s); break;
+    case 3: BEVAMD_COOP(4, 4); break;
+    case 4: BEVAMD_COOP(8, 4); break;
+    case 5: BEVAMD_COOP(4, 8); break;
+    case 6: BEVAMD_COOP(2, 8); break;
+    case 7: BEVAMD_COOP(2, 4); break;
+    default: set_error("bev_pool_forward_cells: unknown variant %d", variant); return BEVAMD_ERR_INVALID_ARG;
+  }
+#undef BEVAMD_COOP
+  BEVAMD_LAUNCH_CHECK("bev_pool_fwd_cells");
   return BEVAMD_OK;
 }
 
@@ -545,8 +642,8 @@ static int prepare_common(const void* coords, int coords_kind /*0 i32, 1 i64, 2 
   if (rc) return rc;
   BEVAMD_REQUIRE(cell_start != nullptr, "bev_pool_prepare: cell_start is null");
   const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
-  BEVAMD_HIP_CHECK(hipMemsetAsync(cell_start, 0, ((size_t)ncells + 2) * sizeof(uint32_t), stream));
   if (n == 0) {
+    BEVAMD_HIP_CHECK(hipMemsetAsync(cell_start, 0, ((size_t)ncells + 2) * sizeof(uint32_t), stream));
     if (n_intervals_dev) BEVAMD_HIP_CHECK(hipMemsetAsync(n_intervals_dev, 0, sizeof(int), stream));
     return BEVAMD_OK;
   }
@@ -558,14 +655,13 @@ static int prepare_common(const void* coords, int coords_kind /*0 i32, 1 i64, 2 
   dim3 grid(cdiv(n, 256)), block(256);
   if (coords_kind == 1)
     bev_rank_kernel<long long><<<grid, block, 0, stream>>>((const long long*)coords, n, s, ncells, pb.keys_a,
-                                                           pb.vals_a, cell_start);
+                                                           pb.vals_a);
   else if (coords_kind == 0)
-    bev_rank_kernel<int><<<grid, block, 0, stream>>>((const int*)coords, n, s, ncells, pb.keys_a, pb.vals_a,
-                                                     cell_start);
+    bev_rank_kernel<int><<<grid, block, 0, stream>>>((const int*)coords, n, s, ncells, pb.keys_a, pb.vals_a);
   else
     bev_rank_from_geom_kernel<<<grid, block, 0, stream>>>((const float*)coords, n, n / b, origin[0], origin[1],
                                                           origin[2], dx[0], dx[1], dx[2], s, ncells, pb.keys_a,
-                                                          pb.vals_a, cell_start);
+                                                          pb.vals_a);
   BEVAMD_LAUNCH_CHECK("bev_rank");
   return prepare_tail(pb, n, s, ncells, ranks_sorted, order, cell_start, interval_starts, interval_lengths,
                       n_intervals_dev, geom_sorted, stream);
@@ -592,8 +688,9 @@ int bevamd_bev_pool_prepare_from_geom(const float* geom_xyz, int n, int b, int d
                         (hipStream_t)stream_);
 }
 
-int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* order, const uint32_t* cell_start,
-                                  float* out, int n, int c, int b, int d, int h, int w, void* stream_) {
+int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint32_t* order,
+                                        const uint32_t* cell_start, float* out, int n, int c, int b, int d, int h,
+                                        int w, int variant, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_dims(n, c, b, d, h, w);
   if (rc) return rc;
@@ -602,23 +699,24 @@ int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* 
   const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
   BevDims s{b, d, h, w, c};
   const int vec = x_is_bf16 ? 8 : 4;
-  dim3 grid(cdiv(ncells, 4)), block(256);
+  if (variant == 0) variant = BEVAMD_FWD_CELLS_DEFAULT_VARIANT;
   if (vec_path_ok(c, vec, x, out)) {
     int lpr = c / vec, rpi = 64 / lpr;
-    if (x_is_bf16)
-      bev_pool_fwd_cells_vec_kernel<U4, 8><<<grid, block, 0, stream>>>((const U4*)x, order, cell_start, ncells, out,
-                                                                      lpr, rpi, s);
-    else
-      bev_pool_fwd_cells_vec_kernel<float4, 4><<<grid, block, 0, stream>>>((const float4*)x, order, cell_start,
-                                                                          ncells, out, lpr, rpi, s);
-  } else {
-    if (x_is_bf16)
-      bev_pool_fwd_cells_scalar_kernel<true><<<grid, block, 0, stream>>>(x, order, cell_start, ncells, out, s);
-    else
-      bev_pool_fwd_cells_scalar_kernel<false><<<grid, block, 0, stream>>>(x, order, cell_start, ncells, out, s);
+    return x_is_bf16 ? launch_cells_vec<U4, 8>(x, order, cell_start, ncells, out, lpr, rpi, s, variant, stream)
+                     : launch_cells_vec<float4, 4>(x, order, cell_start, ncells, out, lpr, rpi, s, variant, stream);
   }
-  BEVAMD_LAUNCH_CHECK("bev_pool_fwd_cells");
+  dim3 grid(cdiv(ncells, 4)), block(256);
+  if (x_is_bf16)
+    bev_pool_fwd_cells_scalar_kernel<true><<<grid, block, 0, stream>>>(x, order, cell_start, ncells, out, s);
+  else
+    bev_pool_fwd_cells_scalar_kernel<false><<<grid, block, 0, stream>>>(x, order, cell_start, ncells, out, s);
+  BEVAMD_LAUNCH_CHECK("bev_pool_fwd_cells_scalar");
   return BEVAMD_OK;
+}
+
+int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* order, const uint32_t* cell_start,
+                                  float* out, int n, int c, int b, int d, int h, int w, void* stream_) {
+  return bevamd_bev_pool_forward_cells_tuned(x, x_is_bf16, order, cell_start, out, n, c, b, d, h, w, 0, stream_);
 }
 
 int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order, const uint32_t* ranks_sorted,

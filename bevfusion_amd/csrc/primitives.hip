@@ -57,19 +57,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_reduce_kernel(const ui
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
 }
 
-// Single workgroup: exclusive scan of `n` values in place (n arbitrary), total out.
+// Single workgroup: exclusive scan of `n` values (in place allowed), total out.
+// 16 items per thread per trip (16 384 per trip) so that ~10^5 entries — the radix-sort digit
+// histogram of a 2 M-key pass — take a handful of trips, not a hundred barrier-bound ones.
+constexpr int SSB_ITEMS = 16;
 __global__ __launch_bounds__(1024) void scan_single_block_kernel(const uint32_t* __restrict__ in,
                                                                  uint32_t* __restrict__ out, size_t n,
                                                                  uint32_t* __restrict__ total) {
   __shared__ unsigned lds_wave[16];
-  __shared__ unsigned carry_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (size_t base = 0; base < n; base += 1024) {
-    size_t idx = base + threadIdx.x;
-    unsigned v = idx < n ? in[idx] : 0u;
-    unsigned inc = wave_inclusive_scan(v);
+  unsigned carry = 0;
+  for (size_t base = 0; base < n; base += (size_t)1024 * SSB_ITEMS) {
+    const size_t first = base + (size_t)threadIdx.x * SSB_ITEMS;
+    unsigned v[SSB_ITEMS];
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < SSB_ITEMS; ++i) {
+      v[i] = (first + i < n) ? in[first + i] : 0u;
+      s += v[i];
+    }
+    unsigned inc = wave_inclusive_scan(s);
     if (lane == 63) lds_wave[wave] = inc;
     __syncthreads();
     unsigned wbase = 0, tot = 0;
@@ -79,13 +86,16 @@ __global__ __launch_bounds__(1024) void scan_single_block_kernel(const uint32_t*
       if (w < wave) wbase += t;
       tot += t;
     }
-    unsigned carry = carry_s;
-    if (idx < n) out[idx] = carry + wbase + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s = carry + tot;
-    __syncthreads();
+    unsigned run = carry + wbase + inc - s;
+#pragma unroll
+    for (int i = 0; i < SSB_ITEMS; ++i) {
+      if (first + i < n) out[first + i] = run;
+      run += v[i];
+    }
+    carry += tot;
+    __syncthreads();  // lds_wave is rewritten next trip
   }
-  if (threadIdx.x == 0 && total) *total = carry_s;
+  if (threadIdx.x == 0 && total) *total = carry;
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_kernel(const uint32_t* __restrict__ in,
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_kernel(const uin
   }
 }
 
-constexpr size_t SCAN_SINGLE_BLOCK_MAX = 1u << 17;
+constexpr size_t SCAN_SINGLE_BLOCK_MAX = 1u << 18;
 
 size_t scan_workspace_bytes(size_t n) {
   size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;

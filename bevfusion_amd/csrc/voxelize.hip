@@ -1,0 +1,343 @@
+// Hard voxelization for gfx950 — deterministic semantics of the reference, without its O(N^2)
+// duplicate scan and its single-thread numbering pass.
+//
+// Replaces (reference, /root/reference/mmdet3d/ops/voxel/src):
+//   voxelization_cuda.cu:25-61    dynamic_voxelize_kernel   (point -> voxel coords)
+//   voxelization_cuda.cu:106-147  point_to_voxelidx_kernel  (O(N^2): all previous points)
+//   voxelization_cuda.cu:150-180  determin_voxel_num        (<<<1,1>>> serial numbering)
+//   voxelization_cuda.cu:64-103   assign_point_to_voxel / assign_voxel_coors
+//   voxelization_cuda.cu:231-373  hard_voxelize_gpu (4 cudaDeviceSynchronize + D2H of voxel_num)
+// Semantics restated from voxelization_cpu.cpp:46-101 (the serial definition):
+//   * voxels are numbered in order of FIRST APPEARANCE in the point list;
+//   * only the first max_voxels distinct voxels exist, later ones are dropped with their points;
+//   * a voxel keeps its first max_points points, in input order.
+//
+// Parallel formulation (integer-only, latency/sort bound, not HBM bound):
+//   key = linear voxel id (sentinel for out-of-range)          1 kernel
+//   stable radix sort (key, point index)                       primitives.hip
+//     -> a segment of equal keys lists a voxel's points in input order: slot = j - seg_start,
+//        and its head is the voxel's first point
+//   mark heads; scatter "is first point of a voxel" back to point order; scan it
+//     -> voxel id = number of voxel-opening points before this one  (first-appearance order)
+//   one pass writes voxels / coors / num_points (unused slots written as zeros, so the output
+//   buffers need no pre-zeroing; the reference's Python side zero-fills 32 MB per call).
+#include "common.h"
+
+namespace bevamd {
+
+struct VoxGrid {
+  float vx, vy, vz;
+  float minx, miny, minz;
+  int gx, gy, gz;
+};
+
+// voxelization_cuda.cu:37,43,50 — c = floor((p - min) / size), fp32 subtract then fp32 divide
+// (NOT a multiply by the reciprocal: the quotient decides the voxel index bit-exactly).
+__device__ __forceinline__ bool voxel_coord(const float* __restrict__ p, const VoxGrid& g, int& cx, int& cy,
+                                            int& cz) {
+  float fx = floorf(__fdiv_rn(__fsub_rn(p[0], g.minx), g.vx));
+  float fy = floorf(__fdiv_rn(__fsub_rn(p[1], g.miny), g.vy));
+  float fz = floorf(__fdiv_rn(__fsub_rn(p[2], g.minz), g.vz));
+  bool ok = (fx >= 0.f) && (fx < (float)g.gx) && (fy >= 0.f) && (fy < (float)g.gy) && (fz >= 0.f) &&
+            (fz < (float)g.gz);  // NaN compares false -> dropped, like int(NaN) < 0 in the reference
+  cx = ok ? (int)fx : -1;
+  cy = ok ? (int)fy : -1;
+  cz = ok ? (int)fz : -1;
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ points, int n, int nfeat,
+                                                      VoxGrid g, uint32_t ncells, uint32_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int cx, cy, cz;
+  bool ok = voxel_coord(points + (size_t)i * nfeat, g, cx, cy, cz);
+  keys[i] = ok ? (uint32_t)((cx * g.gy + cy) * g.gz + cz) : ncells;
+  vals[i] = (uint32_t)i;
+}
+
+// dynamic_voxelize (voxelization_cuda.cu:25-61): per-point coords, -1 when out of range.
+// The reference writes -1 only to the leading components it had reached when the test failed and
+// leaves the others at their previous value; callers test coors[:,0] == -1.  We write (-1,-1,-1),
+// which is what voxelization_cpu.cpp:33-38 does.
+__global__ __launch_bounds__(256) void dynamic_voxelize_kernel(const float* __restrict__ points, int n,
+                                                               int nfeat, VoxGrid g, int* __restrict__ coors) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int cx, cy, cz;
+  voxel_coord(points + (size_t)i * nfeat, g, cx, cy, cz);
+  coors[(size_t)i * 3 + 0] = cx;
+  coors[(size_t)i * 3 + 1] = cy;
+  coors[(size_t)i * 3 + 2] = cz;
+}
+
+__global__ __launch_bounds__(256) void vox_heads_kernel(const uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ idx, int n, uint32_t ncells,
+                                                        uint32_t* __restrict__ head_flag,
+                                                        uint32_t* __restrict__ is_first /*zeroed, point order*/) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t k = keys[j];
+  bool head = k < ncells && (j == 0 || keys[j - 1] != k);
+  head_flag[j] = head ? 1u : 0u;
+  if (head) is_first[idx[j]] = 1u;  // stable sort: the head is the voxel's earliest point
+}
+
+// per segment: start position, voxel id (= rank of its first point among voxel-opening points)
+__global__ __launch_bounds__(256) void vox_segments_kernel(const uint32_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ idx,
+                                                           const uint32_t* __restrict__ head_scan,
+                                                           const uint32_t* __restrict__ first_scan, int n,
+                                                           uint32_t ncells, uint32_t* __restrict__ seg_start,
+                                                           uint32_t* __restrict__ seg_vid) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t k = keys[j];
+  if (k >= ncells) return;
+  const bool head = (j == 0 || keys[j - 1] != k);
+  const uint32_t seg = head_scan[j] + (head ? 1u : 0u) - 1u;  // head_scan is exclusive
+  if (head) {
+    seg_start[seg] = (uint32_t)j;
+    seg_vid[seg] = first_scan[idx[j]];
+  }
+  // the last valid row closes the last segment: seg_start[nseg] = number of valid rows
+  if (j == n - 1 || keys[j + 1] >= ncells) seg_start[seg + 1] = (uint32_t)(j + 1);
+}
+
+// one thread per (sorted row, feature): copies the point into its slot; the head row also writes
+// coords / count and zero-fills the voxel's unused slots.
+__global__ __launch_bounds__(256) void vox_scatter_kernel(
+    const float* __restrict__ points, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ head_flag, const uint32_t* __restrict__ head_scan,
+    const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_vid, int n, int nfeat, VoxGrid g,
+    uint32_t ncells, int max_points, int max_voxels, float* __restrict__ voxels, int* __restrict__ coors,
+    int* __restrict__ num_points_per_voxel) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t k = keys[j];
+  if (k >= ncells) return;
+  const uint32_t hf = head_flag[j];
+  const uint32_t seg = head_scan[j] + hf - 1u;
+  const uint32_t vid = seg_vid[seg];
+  if (vid >= (uint32_t)max_voxels) return;
+  const uint32_t start = seg_start[seg];
+  const int slot = (int)((uint32_t)j - start);
+  float* vbase = voxels + (size_t)vid * max_points * nfeat;
+  if (slot < max_points) {
+    const float* p = points + (size_t)idx[j] * nfeat;
+    float* d = vbase + (size_t)slot * nfeat;
+    for (int f = 0; f < nfeat; ++f) d[f] = p[f];
+  }
+  if (hf) {
+    int len = (int)(seg_start[seg + 1] - start);
+    int cnt = len < max_points ? len : max_points;
+    num_points_per_voxel[vid] = cnt;
+    int cz = (int)(k % (uint32_t)g.gz);
+    uint32_t t = k / (uint32_t)g.gz;
+    int cy = (int)(t % (uint32_t)g.gy);
+    int cx = (int)(t / (uint32_t)g.gy);
+    coors[(size_t)vid * 3 + 0] = cx;
+    coors[(size_t)vid * 3 + 1] = cy;
+    coors[(size_t)vid * 3 + 2] = cz;
+    float* z = vbase + (size_t)cnt * nfeat;
+    for (int e = 0; e < (max_points - cnt) * nfeat; ++e) z[e] = 0.f;
+  }
+}
+
+__global__ void vox_count_kernel(const uint32_t* __restrict__ nseg, int max_voxels, int* __restrict__ voxel_num) {
+  uint32_t s = *nseg;
+  *voxel_num = (int)(s < (uint32_t)max_voxels ? s : (uint32_t)max_voxels);
+}
+
+// voxelize + mean reduce (bevfusion.py:169-197 with voxelize_reduce): per created voxel,
+// feats[vid,:] = sum_{slot<cnt} point / cnt, coords4[vid] = (batch_idx, cx, cy, cz).
+// One thread per head row walks its (<= max_points) points in input order.
+__global__ __launch_bounds__(256) void vox_mean_kernel(
+    const float* __restrict__ points, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ head_flag, const uint32_t* __restrict__ head_scan,
+    const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ seg_vid, int n, int nfeat, VoxGrid g,
+    uint32_t ncells, int max_points, int max_voxels, int batch_idx, float* __restrict__ feats,
+    int* __restrict__ coords4, int* __restrict__ num_points_per_voxel) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  uint32_t k = keys[j];
+  if (k >= ncells || !head_flag[j]) return;
+  const uint32_t seg = head_scan[j];
+  const uint32_t vid = seg_vid[seg];
+  if (vid >= (uint32_t)max_voxels) return;
+  int len = (int)(seg_start[seg + 1] - (uint32_t)j);
+  int cnt = len < max_points ? len : max_points;
+  const float inv_cnt = (float)cnt;
+  for (int f = 0; f < nfeat; ++f) {
+    float s = 0.f;
+    for (int r = 0; r < cnt; ++r) s += points[(size_t)idx[j + r] * nfeat + f];
+    feats[(size_t)vid * nfeat + f] = __fdiv_rn(s, inv_cnt);
+  }
+  if (num_points_per_voxel) num_points_per_voxel[vid] = cnt;
+  int cz = (int)(k % (uint32_t)g.gz);
+  uint32_t t = k / (uint32_t)g.gz;
+  int cy = (int)(t % (uint32_t)g.gy);
+  int cx = (int)(t / (uint32_t)g.gy);
+  ((int4*)coords4)[vid] = make_int4(batch_idx, cx, cy, cz);
+}
+
+static size_t voxelize_ws_bytes(size_t n) {
+  size_t a = align_up(n * sizeof(uint32_t), 256);
+  size_t a1 = align_up((n + 1) * sizeof(uint32_t), 256);
+  size_t s1 = radix_sort_workspace_bytes(n), s2 = scan_workspace_bytes(n);
+  // keys_a, vals_a, keys_s, idx_s, head_flag, head_scan, is_first(+scan in place), seg_start(+1), seg_vid, nseg
+  return 7 * a + 2 * a1 + 256 + align_up(s1 > s2 ? s1 : s2, 256);
+}
+
+struct VoxBuffers {
+  uint32_t *keys_a, *vals_a, *keys_s, *idx_s, *head_flag, *head_scan, *first, *seg_start, *seg_vid, *nseg;
+  void* sws; size_t sws_bytes;
+};
+
+static int make_grid(const float* voxel_size, const float* coors_range, VoxGrid& g) {
+  BEVAMD_REQUIRE(voxel_size && coors_range, "voxelize: voxel_size / coors_range are null (host pointers)");
+  g.vx = voxel_size[0]; g.vy = voxel_size[1]; g.vz = voxel_size[2];
+  g.minx = coors_range[0]; g.miny = coors_range[1]; g.minz = coors_range[2];
+  BEVAMD_REQUIRE(g.vx > 0 && g.vy > 0 && g.vz > 0, "voxelize: voxel_size must be positive");
+  // voxelization_cuda.cu:255-257: grid = round((max - min) / size), fp32
+  g.gx = (int)roundf((coors_range[3] - coors_range[0]) / g.vx);
+  g.gy = (int)roundf((coors_range[4] - coors_range[1]) / g.vy);
+  g.gz = (int)roundf((coors_range[5] - coors_range[2]) / g.vz);
+  BEVAMD_REQUIRE(g.gx > 0 && g.gy > 0 && g.gz > 0, "voxelize: empty grid %d x %d x %d", g.gx, g.gy, g.gz);
+  BEVAMD_REQUIRE((unsigned long long)g.gx * g.gy * g.gz < 0xFFFFFFF0ull, "voxelize: grid has >= 2^32 cells");
+  return BEVAMD_OK;
+}
+
+// shared front half: keys -> sort -> heads -> scans -> segments.  Leaves everything in vb.
+static int voxel_segments(const float* points, int n, int nfeat, const VoxGrid& g, uint32_t ncells, VoxBuffers& vb,
+                          void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (ws == nullptr || ws_bytes < voxelize_ws_bytes((size_t)n)) {
+    set_error("voxelize: workspace too small (%zu < %zu)", ws_bytes, voxelize_ws_bytes((size_t)n));
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  Carver cv(ws, ws_bytes);
+  vb.keys_a = cv.take<uint32_t>(n);
+  vb.vals_a = cv.take<uint32_t>(n);
+  vb.keys_s = cv.take<uint32_t>(n);
+  vb.idx_s = cv.take<uint32_t>(n);
+  vb.head_flag = cv.take<uint32_t>(n);
+  vb.head_scan = cv.take<uint32_t>(n);
+  vb.first = cv.take<uint32_t>(n);
+  vb.seg_start = cv.take<uint32_t>((size_t)n + 1);
+  vb.seg_vid = cv.take<uint32_t>((size_t)n + 1);
+  vb.nseg = cv.take<uint32_t>(1);
+  vb.sws = cv.base + cv.off;
+  vb.sws_bytes = ws_bytes - cv.off;
+
+  dim3 grid(cdiv(n, 256)), block(256);
+  vox_key_kernel<<<grid, block, 0, stream>>>(points, n, nfeat, g, ncells, vb.keys_a, vb.vals_a);
+  BEVAMD_LAUNCH_CHECK("vox_key");
+  int rc = radix_sort_pairs_u32(vb.keys_a, vb.vals_a, vb.keys_s, vb.idx_s, (size_t)n, bits_for((uint64_t)ncells + 1),
+                                vb.sws, vb.sws_bytes, stream);
+  if (rc) return rc;
+  BEVAMD_HIP_CHECK(hipMemsetAsync(vb.first, 0, (size_t)n * sizeof(uint32_t), stream));
+  vox_heads_kernel<<<grid, block, 0, stream>>>(vb.keys_s, vb.idx_s, n, ncells, vb.head_flag, vb.first);
+  BEVAMD_LAUNCH_CHECK("vox_heads");
+  rc = exclusive_scan_u32(vb.head_flag, vb.head_scan, (size_t)n, vb.nseg, vb.sws, vb.sws_bytes, stream);
+  if (rc) return rc;
+  rc = exclusive_scan_u32(vb.first, vb.first, (size_t)n, nullptr, vb.sws, vb.sws_bytes, stream);
+  if (rc) return rc;
+  vox_segments_kernel<<<grid, block, 0, stream>>>(vb.keys_s, vb.idx_s, vb.head_scan, vb.first, n, ncells,
+                                                  vb.seg_start, vb.seg_vid);
+  BEVAMD_LAUNCH_CHECK("vox_segments");
+  return BEVAMD_OK;
+}
+
+}  // namespace bevamd
+
+using namespace bevamd;
+
+extern "C" {
+
+size_t bevamd_hard_voxelize_workspace_bytes(int num_points) {
+  return voxelize_ws_bytes((size_t)(num_points > 0 ? num_points : 1));
+}
+
+int bevamd_hard_voxelize(const float* points, float* voxels, int* coors, int* num_points_per_voxel,
+                         const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                         int num_points, int num_features, int ndim, int deterministic, int* voxel_num_dev,
+                         int* voxel_num_host, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)deterministic;  // both modes produce the deterministic result
+  BEVAMD_REQUIRE(ndim == 3, "hard_voxelize: NDim=%d unsupported (only 3)", ndim);
+  BEVAMD_REQUIRE(num_points >= 0 && num_features >= 3, "hard_voxelize: need num_features >= 3 (got %d)", num_features);
+  BEVAMD_REQUIRE(max_points > 0 && max_voxels > 0, "hard_voxelize: max_points/max_voxels must be > 0");
+  BEVAMD_REQUIRE(voxel_num_dev != nullptr, "hard_voxelize: voxel_num_dev is null");
+  VoxGrid g;
+  int rc = make_grid(voxel_size, coors_range, g);
+  if (rc) return rc;
+  if (num_points == 0) {
+    BEVAMD_HIP_CHECK(hipMemsetAsync(voxel_num_dev, 0, sizeof(int), stream));
+    if (voxel_num_host) { BEVAMD_HIP_CHECK(hipStreamSynchronize(stream)); *voxel_num_host = 0; }
+    return BEVAMD_OK;
+  }
+  BEVAMD_REQUIRE(points && voxels && coors && num_points_per_voxel, "hard_voxelize: null buffer");
+  const uint32_t ncells = (uint32_t)((unsigned long long)g.gx * g.gy * g.gz);
+  VoxBuffers vb;
+  rc = voxel_segments(points, num_points, num_features, g, ncells, vb, ws, ws_bytes, stream);
+  if (rc) return rc;
+  vox_scatter_kernel<<<dim3(cdiv(num_points, 256)), dim3(256), 0, stream>>>(
+      points, vb.keys_s, vb.idx_s, vb.head_flag, vb.head_scan, vb.seg_start, vb.seg_vid, num_points, num_features, g,
+      ncells, max_points, max_voxels, voxels, coors, num_points_per_voxel);
+  BEVAMD_LAUNCH_CHECK("vox_scatter");
+  vox_count_kernel<<<1, 1, 0, stream>>>(vb.nseg, max_voxels, voxel_num_dev);
+  BEVAMD_LAUNCH_CHECK("vox_count");
+  if (voxel_num_host) {
+    BEVAMD_HIP_CHECK(hipMemcpyAsync(voxel_num_host, voxel_num_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    BEVAMD_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return BEVAMD_OK;
+}
+
+int bevamd_dynamic_voxelize(const float* points, int* coors, const float* voxel_size, const float* coors_range,
+                            int num_points, int num_features, int ndim, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(ndim == 3, "dynamic_voxelize: NDim=%d unsupported (only 3)", ndim);
+  BEVAMD_REQUIRE(num_points >= 0 && num_features >= 3, "dynamic_voxelize: need num_features >= 3");
+  VoxGrid g;
+  int rc = make_grid(voxel_size, coors_range, g);
+  if (rc) return rc;
+  if (num_points == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(points && coors, "dynamic_voxelize: null buffer");
+  dynamic_voxelize_kernel<<<dim3(cdiv(num_points, 256)), dim3(256), 0, stream>>>(points, num_points, num_features, g,
+                                                                                 coors);
+  BEVAMD_LAUNCH_CHECK("dynamic_voxelize");
+  return BEVAMD_OK;
+}
+
+int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* num_points_per_voxel,
+                         const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                         int num_points, int num_features, int batch_idx, int* voxel_num_dev, void* ws,
+                         size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(num_points >= 0 && num_features >= 3, "voxelize_mean: need num_features >= 3");
+  BEVAMD_REQUIRE(max_points > 0 && max_voxels > 0, "voxelize_mean: max_points/max_voxels must be > 0");
+  BEVAMD_REQUIRE(voxel_num_dev != nullptr, "voxelize_mean: voxel_num_dev is null");
+  VoxGrid g;
+  int rc = make_grid(voxel_size, coors_range, g);
+  if (rc) return rc;
+  if (num_points == 0) {
+    BEVAMD_HIP_CHECK(hipMemsetAsync(voxel_num_dev, 0, sizeof(int), stream));
+    return BEVAMD_OK;
+  }
+  BEVAMD_REQUIRE(points && feats && coords4, "voxelize_mean: null buffer");
+  const uint32_t ncells = (uint32_t)((unsigned long long)g.gx * g.gy * g.gz);
+  VoxBuffers vb;
+  rc = voxel_segments(points, num_points, num_features, g, ncells, vb, ws, ws_bytes, stream);
+  if (rc) return rc;
+  vox_mean_kernel<<<dim3(cdiv(num_points, 256)), dim3(256), 0, stream>>>(
+      points, vb.keys_s, vb.idx_s, vb.head_flag, vb.head_scan, vb.seg_start, vb.seg_vid, num_points, num_features, g,
+      ncells, max_points, max_voxels, batch_idx, feats, coords4, num_points_per_voxel);
+  BEVAMD_LAUNCH_CHECK("vox_mean");
+  vox_count_kernel<<<1, 1, 0, stream>>>(vb.nseg, max_voxels, voxel_num_dev);
+  BEVAMD_LAUNCH_CHECK("vox_count");
+  return BEVAMD_OK;
+}
+
+}  // extern "C"

@@ -105,11 +105,57 @@ int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* 
                                   const uint32_t* cell_start, float* out, int n, int c, int b, int d,
                                   int h, int w, void* stream);
 
+/* Tuning hook of the same kernel family (bench sweeps only): variant 0 = shipped default,
+ * 1/2 = one wave per cell (4/8 loads in flight), 3..7 = workgroup-cooperative flavours. */
+int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint32_t* order,
+                                        const uint32_t* cell_start, float* out, int n, int c, int b,
+                                        int d, int h, int w, int variant, void* stream);
+
 /* Native backward (row-parallel): x_grad[order[j], :] = out_grad[cell(ranks_sorted[j]), :],
  * zeros for dropped rows.  Every row of x_grad [n,c] is written once. */
 int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order,
                                   const uint32_t* ranks_sorted, float* x_grad, int n, int c, int b,
                                   int d, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * voxelization  (reference: mmdet3d/ops/voxel)
+ * ------------------------------------------------------------------------- */
+
+/* Replaces voxel_layer.hard_voxelize
+ *   (mmdet3d/ops/voxel/src/voxelization.cpp:6-11 -> voxelization.h:58-81 ->
+ *    voxelization_cuda.cu:231-373 hard_voxelize_gpu; semantics of voxelization_cpu.cpp:46-101).
+ * points [num_points, num_features] fp32 (xyz first); outputs sized by the caller for max_voxels:
+ * voxels [max_voxels, max_points, num_features] fp32, coors [max_voxels, 3] int32 (x, y, z),
+ * num_points_per_voxel [max_voxels] int32.  Rows [0, voxel_num) are fully written (unused point
+ * slots as zeros), so the buffers need NOT be pre-zeroed; rows >= voxel_num are left untouched.
+ * voxel_size: HOST float[3]; coors_range: HOST float[6] (xyz min, xyz max).
+ * Voxels are numbered in order of first appearance in `points`; at most max_voxels voxels and
+ * max_points points per voxel (input order) are kept.  `deterministic` is accepted for signature
+ * parity; the result is always the deterministic one.
+ * voxel_num_dev [1] (device) always receives the count.  If voxel_num_host != NULL the call also
+ * synchronises `stream` and stores the count there — the reference returns a host int
+ * (voxelization_cuda.cu:369-372); pass NULL to stay asynchronous. */
+size_t bevamd_hard_voxelize_workspace_bytes(int num_points);
+int bevamd_hard_voxelize(const float* points, float* voxels, int* coors, int* num_points_per_voxel,
+                         const float* voxel_size, const float* coors_range, int max_points,
+                         int max_voxels, int num_points, int num_features, int ndim, int deterministic,
+                         int* voxel_num_dev, int* voxel_num_host, void* ws, size_t ws_bytes, void* stream);
+
+/* Replaces voxel_layer.dynamic_voxelize (voxelization_cuda.cu:25-61, 485-...): coors [num_points,3]
+ * int32 = floor((p - min) / size), or (-1,-1,-1) for points outside the range. */
+int bevamd_dynamic_voxelize(const float* points, int* coors, const float* voxel_size,
+                            const float* coors_range, int num_points, int num_features, int ndim,
+                            void* stream);
+
+/* Fused BEVFusion.voxelize step for one sample (models/fusion_models/bevfusion.py:169-197 with
+ * voxelize_reduce): hard voxelization + mean over the kept points + batch-index column, without
+ * materialising voxels[max_voxels, max_points, F]:
+ *   feats [max_voxels, num_features] = sum(points of voxel, input order) / count
+ *   coords4 [max_voxels, 4] int32 = (batch_idx, x, y, z);  num_points_per_voxel optional (NULL ok). */
+int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* num_points_per_voxel,
+                         const float* voxel_size, const float* coors_range, int max_points,
+                         int max_voxels, int num_points, int num_features, int batch_idx,
+                         int* voxel_num_dev, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * device primitives (exposed for tests; used by every precompute path)

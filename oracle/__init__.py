@@ -82,6 +82,7 @@ def bev_pool_intervals(ranks_sorted):
     n = ranks_sorted.shape[0]
     starts = np.empty(max(n, 1), dtype=np.int32)
     lengths = np.empty(max(n, 1), dtype=np.int32)
+    lib().oracle_bev_pool_intervals.restype = ctypes.c_int64
     k = lib().oracle_bev_pool_intervals(_p(ranks_sorted), _i64(n), _p(starts), _p(lengths))
     return starts[:k].copy(), lengths[:k].copy()
 
@@ -133,3 +134,55 @@ def bev_pool(feats, coords, B, D, H, W, dtype=np.float64):
     out = bev_pool_forward_sorted(x, pro["geom_sorted"], pro["interval_starts"], pro["interval_lengths"], B, D, H, W,
                                   dtype=dtype)
     return np.ascontiguousarray(out.transpose(0, 4, 1, 2, 3))
+
+
+# --------------------------------------------------------------------------------------------
+# hard voxelization
+# --------------------------------------------------------------------------------------------
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """voxelization_cpu.cpp:8-44 -> coors [N,3] int32 (x,y,z) or -1."""
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    n, f = points.shape
+    vs = np.ascontiguousarray(voxel_size, dtype=np.float32)
+    cr = np.ascontiguousarray(coors_range, dtype=np.float32)
+    coors = np.empty((n, 3), dtype=np.int32)
+    lib().oracle_dynamic_voxelize(_p(points), _i64(n), _i64(f), _p(vs), _p(cr), _p(coors))
+    return coors
+
+
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    """voxelization_cpu.cpp:46-101 (+ voxelize.py:52-71 allocation/slicing) ->
+    (voxels [M,max_points,F], coors [M,3] int32, num_points_per_voxel [M] int32)."""
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    n, f = points.shape
+    vs = np.ascontiguousarray(voxel_size, dtype=np.float32)
+    cr = np.ascontiguousarray(coors_range, dtype=np.float32)
+    voxels = np.zeros((max_voxels, max_points, f), dtype=np.float32)
+    coors = np.zeros((max_voxels, 3), dtype=np.int32)
+    npv = np.zeros((max_voxels,), dtype=np.int32)
+    fn = lib().oracle_hard_voxelize
+    fn.restype = ctypes.c_int32
+    m = fn(_p(points), _i64(n), _i64(f), _p(vs), _p(cr), ctypes.c_int32(max_points), ctypes.c_int32(max_voxels),
+           _p(voxels), _p(coors), _p(npv))
+    return voxels[:m].copy(), coors[:m].copy(), npv[:m].copy()
+
+
+def voxel_mean(voxels, num_points_per_voxel):
+    """bevfusion.py:192-195: voxels.sum(1) / count (fp32, slot order)."""
+    voxels = np.ascontiguousarray(voxels, dtype=np.float32)
+    npv = np.ascontiguousarray(num_points_per_voxel, dtype=np.int32)
+    m, mp, f = voxels.shape
+    feats = np.empty((m, f), dtype=np.float32)
+    lib().oracle_voxel_mean(_p(voxels), _p(npv), _i64(m), _i64(mp), _i64(f), _p(feats))
+    return feats
+
+
+def voxelize_batch(points_list, voxel_size, coors_range, max_points, max_voxels):
+    """bevfusion.py:169-197: per-sample hard voxelize, batch index prepended to coords, mean reduce."""
+    feats, coords, sizes = [], [], []
+    for k, pts in enumerate(points_list):
+        v, c, n = hard_voxelize(pts, voxel_size, coors_range, max_points, max_voxels)
+        feats.append(voxel_mean(v, n))
+        coords.append(np.concatenate([np.full((c.shape[0], 1), k, np.int32), c], 1))
+        sizes.append(n)
+    return np.concatenate(feats), np.concatenate(coords), np.concatenate(sizes)
