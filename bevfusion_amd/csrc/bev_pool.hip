@@ -539,7 +539,6 @@ static int prepare_tail(PrepBuffers& pb, int n, BevDims s, uint32_t ncells, uint
 
 // variant: 0 = default (tuned), 1 = wave-per-cell U4, 2 = wave-per-cell U8,
 //          3 = coop NW4 U4, 4 = coop NW4 U8, 5 = coop NW8 U4, 6 = coop NW8 U2, 7 = coop NW4 U2
-#define BEVAMD_FWD_CELLS_DEFAULT_VARIANT 3
 template <typename VecT, int VEC>
 static int launch_cells_vec(const void* x, const uint32_t* order, const uint32_t* cell_start, uint32_t ncells,
                             float* out, int lpr, int rpi, BevDims s, int variant, hipStream_t stream) {
@@ -699,7 +698,9 @@ int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint
   const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
   BevDims s{b, d, h, w, c};
   const int vec = x_is_bf16 ? 8 : 4;
-  if (variant == 0) variant = BEVAMD_FWD_CELLS_DEFAULT_VARIANT;
+  // measured on MI355X (tools/sweep_bev_pool.py, profiles/): one wave per cell wins everywhere; 8 loads in
+  // flight pay off for fp32 rows on a single-frame grid (131 vs 150 us), 4 otherwise.
+  if (variant == 0) variant = (!x_is_bf16 && ncells <= 200000u) ? 2 : 1;
   if (vec_path_ok(c, vec, x, out)) {
     int lpr = c / vec, rpi = 64 / lpr;
     return x_is_bf16 ? launch_cells_vec<U4, 8>(x, order, cell_start, ncells, out, lpr, rpi, s, variant, stream)

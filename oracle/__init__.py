@@ -186,3 +186,96 @@ def voxelize_batch(points_list, voxel_size, coors_range, max_points, max_voxels)
         coords.append(np.concatenate([np.full((c.shape[0], 1), k, np.int32), c], 1))
         sizes.append(n)
     return np.concatenate(feats), np.concatenate(coords), np.concatenate(sizes)
+
+
+# --------------------------------------------------------------------------------------------
+# spconv: rulebook + sparse convolution
+# --------------------------------------------------------------------------------------------
+def _i32arr(v):
+    return np.ascontiguousarray(v, dtype=np.int32)
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """spconv/ops.py:20-31."""
+    return [(input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+            for i in range(len(input_size))]
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, order="cuda"):
+    """spconv_ops.h:27-141 (getIndicePair<3>) on CPU semantics.
+    indices [N,4] int32 (b,x,y,z).  Returns (out_indices [M,4], indice_pairs [K,2,N] (-1 padded),
+    indice_num [K], out_shape).
+    order="cpu":  output rows of a strided conv in first-appearance order (geometry.h:181-187);
+    order="cuda": rows renumbered by ascending linear index b*vol + x*Y*Z + y*Z + z, which is what the
+                  CUDA path produces (torch::_unique at spconv_ops.h:130, indice.cu.h:112-145).  D8."""
+    indices = _i32arr(indices)
+    n = indices.shape[0]
+    ks, st, pd, dl = _i32arr(ksize), _i32arr(stride), _i32arr(padding), _i32arr(dilation)
+    K = int(np.prod(ks))
+    pairs = np.full((K, 2, max(n, 1)), -1, dtype=np.int32)
+    num = np.zeros(K, dtype=np.int32)
+    if subm:
+        shape = _i32arr(spatial_shape)
+        lib().oracle_subm_indice_pairs(_p(indices), _i64(n), _p(shape), _p(ks), _p(dl), _p(pairs), _p(num))
+        return indices.copy(), pairs[:, :, :n] if n else pairs[:, :, :0], num, list(spatial_shape)
+    out_shape = get_conv_output_size(list(spatial_shape), list(ks), list(st), list(pd), list(dl))
+    oshape = _i32arr(out_shape)
+    out_inds = np.zeros((max(n * K, 1), 4), dtype=np.int32)
+    fn = lib().oracle_conv_indice_pairs
+    fn.restype = ctypes.c_int64
+    m = fn(_p(indices), _i64(n), _p(ks), _p(st), _p(pd), _p(dl), _p(oshape), _p(out_inds), _p(pairs), _p(num))
+    out_inds = out_inds[:m].copy()
+    pairs = pairs[:, :, :n] if n else pairs[:, :, :0]
+    if order == "cuda" and m > 0:
+        lin = ((out_inds[:, 0].astype(np.int64) * out_shape[0] + out_inds[:, 1]) * out_shape[1] + out_inds[:, 2]) \
+            * out_shape[2] + out_inds[:, 3]
+        perm = np.argsort(lin, kind="stable")          # new row r holds old row perm[r]
+        inv = np.empty(m, dtype=np.int32)
+        inv[perm] = np.arange(m, dtype=np.int32)
+        out_inds = out_inds[perm]
+        pairs = pairs.copy()
+        sel = pairs[:, 1, :] >= 0
+        pairs[:, 1, :][sel] = inv[pairs[:, 1, :][sel]]
+    return out_inds, pairs, num, out_shape
+
+
+def indice_conv(features, filters, indice_pairs, indice_num, num_act_out, inverse=False):
+    """spconv_ops.h:260-361, float64 accumulation.  filters [kx,ky,kz,Cin,Cout]. -> [M, Cout] float64."""
+    features = np.ascontiguousarray(features, dtype=np.float32)
+    filters = np.ascontiguousarray(filters, dtype=np.float32)
+    pairs = _i32arr(indice_pairs)
+    num = _i32arr(indice_num)
+    K, _, L = pairs.shape
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    out = np.empty((num_act_out, cout), dtype=np.float64)
+    lib().oracle_indice_conv_f64(_p(features), _p(filters), _p(pairs), _p(num), _i64(K), _i64(L), _i64(num_act_out),
+                                 _i64(cin), _i64(cout), ctypes.c_int32(int(inverse)), _p(out))
+    return out
+
+
+def indice_conv_backward(features, filters, out_grad, indice_pairs, indice_num, inverse=False):
+    """spconv_ops.h:363-456, float64 accumulation -> (in_grad [N,Cin], filter_grad like filters)."""
+    features = np.ascontiguousarray(features, dtype=np.float32)
+    filters = np.ascontiguousarray(filters, dtype=np.float32)
+    out_grad = np.ascontiguousarray(out_grad, dtype=np.float32)
+    pairs = _i32arr(indice_pairs)
+    num = _i32arr(indice_num)
+    K, _, L = pairs.shape
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    gi = np.empty((features.shape[0], cin), dtype=np.float64)
+    gw = np.empty((K, cin, cout), dtype=np.float64)
+    lib().oracle_indice_conv_backward_f64(_p(features), _p(filters), _p(out_grad), _p(pairs), _p(num), _i64(K), _i64(L),
+                                          _i64(features.shape[0]), _i64(cin), _i64(cout), ctypes.c_int32(int(inverse)),
+                                          _p(gi), _p(gw))
+    return gi, gw.reshape(filters.shape)
+
+
+def pairs_as_sets(indice_pairs, indice_num):
+    """Canonical form of a rulebook: per offset, the sorted list of (in,out) pairs — the CUDA path
+    fills each offset's list in atomicAdd order (indice.cu.h:62,195), so only the SET is defined."""
+    out = []
+    for k in range(indice_pairs.shape[0]):
+        m = int(indice_num[k])
+        pr = np.stack([indice_pairs[k, 0, :m], indice_pairs[k, 1, :m]], 1)
+        out.append(pr[np.lexsort((pr[:, 0], pr[:, 1]))] if m else pr.reshape(0, 2))
+    return out
