@@ -35,6 +35,19 @@ _SIGNATURES = {
     "bevamd_hard_voxelize": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, Z, P]),
     "bevamd_dynamic_voxelize": (I, [P, P, P, P, I, I, I, P]),
     "bevamd_voxelize_mean": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, Z, P]),
+    # spconv
+    "bevamd_spconv_rulebook_workspace_bytes": (Z, [I, P, P, I]),
+    "bevamd_spconv_max_outputs": (I, [I, P, P, I]),
+    "bevamd_spconv_build_rulebook": (I, [P, I, I, P, P, P, P, P, P, I, P, I, P, I, P, P, P, Z, P]),
+    "bevamd_spconv_pairs_workspace_bytes": (Z, [I, I]),
+    "bevamd_spconv_pairs_from_nbr": (I, [P, I, I, I, P, I, P, P, Z, P]),
+    "bevamd_spconv_nbr_from_pairs": (I, [P, I, P, I, I, P, I, P]),
+    "bevamd_spconv_transpose_nbr": (I, [P, I, I, I, P, I, P]),
+    "bevamd_spconv_prepared_filter_elems": (Z, [I, I, I, I, I]),
+    "bevamd_spconv_prepare_filters": (I, [P, I, I, I, I, I, P, P]),
+    "bevamd_spconv_conv_forward": (I, [P, I, P, P, I, I, P, I, I, I, P, P, P, P, P, I, P]),
+    "bevamd_spconv_wgrad_workspace_bytes": (Z, [I, I, I]),
+    "bevamd_spconv_conv_wgrad": (I, [P, P, I, P, I, I, I, I, I, P, P, Z, P]),
     # primitives
     "bevamd_scan_workspace_bytes": (Z, [Z]),
     "bevamd_exclusive_scan_u32": (I, [P, P, Z, P, P, Z, P]),
@@ -104,6 +117,11 @@ def stream_ptr(device=None):
 def float3(values):
     arr = (c_float * 3)(*[float(v) for v in values])
     return arr
+
+
+def ints(values):
+    vals = [int(v) for v in values]
+    return (c_int * len(vals))(*vals)
 
 
 def floats(values):

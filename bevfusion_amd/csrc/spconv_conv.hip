@@ -1,0 +1,411 @@
+// Sparse 3D convolution for gfx950: output-stationary implicit GEMM on MFMA.
+//
+// Replaces (reference, /root/reference/mmdet3d/ops/spconv):
+//   include/spconv/spconv_ops.h:260-361   indiceConv<T>: per kernel offset gather -> torch::mm_out ->
+//                                         scatter-add (up to 3 launches x 27 offsets, a D2H sync, and
+//                                         output rows read-modify-written once per offset)
+//   include/spconv/reordering.cu.h:21-157 gather / scatterAdd kernels
+//   include/spconv/spconv_ops.h:363-456   indiceConvBackward<T>
+//
+// One launch per convolution.  A wavefront owns 16*MT output rows and all output channels; for each
+// kernel offset k it gathers the rows nbr[k][o] straight into MFMA A-fragments (16-byte loads, no
+// staging buffer), multiplies by W[k] from a pre-transposed filter image and accumulates in fp32
+// registers across ALL offsets; the finished tile is written once, with bias / BatchNorm scale+shift /
+// residual / ReLU applied in the epilogue.  Offsets with no neighbour in the whole tile are skipped
+// with one ballot.  No atomics, no scatter, fixed summation order (offset-major, then channel) ->
+// bit-reproducible.
+//
+//   16-bit (fp16 / bf16): v_mfma_f32_16x16x32  — lane l holds A[row l&15][8 ch of group l>>4]
+//   fp32                : v_mfma_f32_16x16x4   — exact fp32 FMA chain (no TF32-like path on gfx950);
+//                         one float4 load feeds 4 MFMAs (k-slot permutation shared by A and B)
+//
+// MFMA is used for nothing else on this path (the op is gather/L2-bound).
+#include "common.h"
+
+namespace bevamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum DType { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
+
+struct alignas(16) Raw16 { uint32_t w[4]; };
+
+template <int DT> struct Elem;
+template <> struct Elem<DT_F32> {
+  typedef float T;
+  static constexpr int VEC = 4;   // elements per 16-byte fragment load
+  static constexpr int CH = 16;   // input channels consumed per chunk (4 lane groups x VEC)
+  __device__ static float to_f32(float v) { return v; }
+  __device__ static float from_f32(float v) { return v; }
+};
+template <> struct Elem<DT_F16> {
+  typedef _Float16 T;
+  static constexpr int VEC = 8;
+  static constexpr int CH = 32;
+  __device__ static float to_f32(_Float16 v) { return (float)v; }
+  __device__ static _Float16 from_f32(float v) { return (_Float16)v; }
+};
+template <> struct Elem<DT_BF16> {
+  typedef uint16_t T;  // raw bf16 bits
+  static constexpr int VEC = 8;
+  static constexpr int CH = 32;
+  __device__ static float to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+  __device__ static uint16_t from_f32(float v) {  // round to nearest even
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+};
+
+template <int DT>
+__device__ __forceinline__ void mfma_step(const Raw16& a, const Raw16& b, f32x4& acc) {
+  if constexpr (DT == DT_F16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)&a, *(const f16x8*)&b, acc, 0, 0, 0);
+  } else if constexpr (DT == DT_BF16) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&a, *(const bf16x8*)&b, acc, 0, 0, 0);
+  } else {
+    const float* af = (const float*)&a;
+    const float* bf = (const float*)&b;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bf[t], acc, 0, 0, 0);
+  }
+}
+
+// 16 bytes (VEC elements) of a feature row starting at channel c; zero past `cin` / for row < 0.
+template <int DT>
+__device__ __forceinline__ Raw16 load_a(const typename Elem<DT>::T* __restrict__ feat, int row, int cin, int c,
+                                        bool vec_ok) {
+  typedef typename Elem<DT>::T T;
+  constexpr int VEC = Elem<DT>::VEC;
+  Raw16 r;
+  r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0u;
+  if (row < 0 || c >= cin) return r;
+  const T* p = feat + (size_t)row * cin + c;
+  if (vec_ok) {
+    r = *(const Raw16*)p;
+  } else {
+    T* e = (T*)&r;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      if (c + j < cin) e[j] = p[j];
+  }
+  return r;
+}
+
+struct Epilogue {
+  const void* bias;       // [cout], same dtype as features (conv.py:215-216), or null
+  const float* scale;     // [cout] fp32, or null   } folded BatchNorm: y = y * scale + shift
+  const float* shift;     // [cout] fp32, or null   }
+  const void* residual;   // [m, cout], same dtype, or null
+  int relu;
+};
+
+// wt: prepared filters [cout_pad][K * cin_pad] (see prepare kernel), zero padded.
+template <int DT, int NT, int MT>
+__global__ __launch_bounds__(256) void spconv_fwd_kernel(
+    const typename Elem<DT>::T* __restrict__ feat, const typename Elem<DT>::T* __restrict__ wt,
+    const int* __restrict__ nbr, int nbr_stride, int m_cap, const int* __restrict__ m_dev, int K, int cin,
+    int cin_pad, int cout, typename Elem<DT>::T* __restrict__ out, Epilogue ep) {
+  typedef typename Elem<DT>::T T;
+  constexpr int VEC = Elem<DT>::VEC;
+  constexpr int CH = Elem<DT>::CH;
+  const int m = m_dev ? *m_dev : m_cap;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row0 = wave * 16 * MT;
+  if (row0 >= m) return;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15;  // A row / B column inside a 16x16 tile
+  const int g = lane >> 4;  // k-group
+  const bool vec_ok = (cin % VEC) == 0;
+  const size_t wrow = (size_t)K * cin_pad;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k = 0; k < K; ++k) {
+    int nb[MT];
+    bool any = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int row = row0 + mt * 16 + r;
+      nb[mt] = row < m ? nbr[(size_t)k * nbr_stride + row] : -1;
+      any |= nb[mt] >= 0;
+    }
+    if (!__any(any)) continue;  // no output row of this tile has a neighbour at offset k
+    const T* wk = wt + (size_t)k * cin_pad;
+    for (int c0 = 0; c0 < cin_pad; c0 += CH) {
+      const int c = c0 + g * VEC;
+      Raw16 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = load_a<DT>(feat, nb[mt], cin, c, vec_ok);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const Raw16 b = *(const Raw16*)(wk + (size_t)(nt * 16 + r) * wrow + c);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mfma_step<DT>(a[mt], b, acc[mt][nt]);
+      }
+    }
+  }
+
+  // C/D layout of the 16x16 MFMA: column = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + r;
+      if (col >= cout) continue;
+      float bias = ep.bias ? Elem<DT>::to_f32(((const T*)ep.bias)[col]) : 0.f;
+      float sc = ep.scale ? ep.scale[col] : 1.f;
+      float sh = ep.shift ? ep.shift[col] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = row0 + mt * 16 + g * 4 + j;
+        if (row >= m) continue;
+        float v = acc[mt][nt][j];
+        if (ep.bias) v = Elem<DT>::to_f32(Elem<DT>::from_f32(v)) + bias;  // reference adds bias after the cast
+        if (ep.scale || ep.shift) v = v * sc + sh;
+        if (ep.residual) v += Elem<DT>::to_f32(((const T*)ep.residual)[(size_t)row * cout + col]);
+        if (ep.relu) v = v > 0.f ? v : 0.f;
+        out[(size_t)row * cout + col] = Elem<DT>::from_f32(v);
+      }
+    }
+  }
+}
+
+// filters [K][cin][cout] (reference layout [kx,ky,kz,cin,cout], conv.py:100)
+//   -> wt [cout_pad][K][cin_pad], zero padded; transpose_io swaps the roles of cin/cout
+//      (wt'[ci][k][co] = W[k][ci][co]) for the input-gradient pass.
+template <int DT>
+__global__ __launch_bounds__(256) void spconv_prepare_filters_kernel(const typename Elem<DT>::T* __restrict__ w, int K,
+                                                                     int cin, int cout, int rows_pad, int cols_pad,
+                                                                     int transpose_io,
+                                                                     typename Elem<DT>::T* __restrict__ wt) {
+  // rows = output channels of this pass, cols = input channels of this pass
+  const int rows = transpose_io ? cin : cout;
+  const int cols = transpose_io ? cout : cin;
+  size_t total = (size_t)rows_pad * K * cols_pad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % cols_pad);
+    size_t t = i / cols_pad;
+    int k = (int)(t % K);
+    int rr = (int)(t / K);
+    typename Elem<DT>::T v = Elem<DT>::from_f32(0.f);
+    if (rr < rows && c < cols) {
+      int ci = transpose_io ? rr : c, co = transpose_io ? c : rr;
+      v = w[((size_t)k * cin + ci) * cout + co];
+    }
+    wt[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// filter gradient: gW[k][ci][co] = sum over pairs (i,o) of offset k of feat[i][ci] * gout[o][co]
+// One workgroup per (offset, slab of output rows); threads own (ci, co) entries, rows staged in LDS;
+// partial sums land with fp32 atomics (order of arrival varies: the only non-bit-reproducible kernel
+// of the op, as is the reference's GEMM-with-split-K on GPUs).
+// ---------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void spconv_wgrad_kernel(const typename Elem<DT>::T* __restrict__ feat,
+                                                           const typename Elem<DT>::T* __restrict__ gout,
+                                                           const int* __restrict__ nbr, int nbr_stride, int m, int K,
+                                                           int cin, int cout, int rows_per_block,
+                                                           float* __restrict__ gw) {
+  extern __shared__ float lds[];  // [ROWS][cin] then [ROWS][cout]
+  constexpr int ROWS = 32;
+  float* fa = lds;
+  float* fb = lds + ROWS * cin;
+  const int k = blockIdx.y;
+  const int rbeg = blockIdx.x * rows_per_block;
+  const int rend = rbeg + rows_per_block < m ? rbeg + rows_per_block : m;
+  const int nent = cin * cout;
+  constexpr int MAXE = 64;  // entries per thread: supports cin*cout <= 16384
+  float acc[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
+  for (int r0 = rbeg; r0 < rend; r0 += ROWS) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < ROWS * cin; t += 256) {
+      int rr = t / cin, c = t - rr * cin;
+      int o = r0 + rr;
+      int i = o < rend ? nbr[(size_t)k * nbr_stride + o] : -1;
+      fa[t] = i >= 0 ? Elem<DT>::to_f32(feat[(size_t)i * cin + c]) : 0.f;
+    }
+    for (int t = threadIdx.x; t < ROWS * cout; t += 256) {
+      int rr = t / cout, c = t - rr * cout;
+      int o = r0 + rr;
+      int i = o < rend ? nbr[(size_t)k * nbr_stride + o] : -1;
+      fb[t] = i >= 0 ? Elem<DT>::to_f32(gout[(size_t)o * cout + c]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      int idx = threadIdx.x + e * 256;
+      if (idx < nent) {
+        int ci = idx / cout, co = idx - ci * cout;
+        float s = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < ROWS; ++rr) s += fa[rr * cin + ci] * fb[rr * cout + co];
+        acc[e] += s;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    int idx = threadIdx.x + e * 256;
+    if (idx < nent && acc[e] != 0.f) atomicAdd(&gw[(size_t)k * nent + idx], acc[e]);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, size_t n,
+                                                            typename Elem<DT>::T* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dst[i] = Elem<DT>::from_f32(src[i]);
+}
+
+static int round_up(int x, int a) { return (x + a - 1) / a * a; }
+// output-channel tiles per wave are instantiated for 1, 2, 4, 8 (x16 channels); the prepared filter
+// image is padded to that many rows so that every B-fragment load stays in bounds.
+static int rows_padded(int rows) {
+  int nt = (rows + 15) / 16;
+  int sel = nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 8 ? 8 : nt;
+  return sel * 16;
+}
+
+static int elem_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+static int chunk_of(int dt) { return dt == DT_F32 ? 16 : 32; }
+
+template <int DT>
+static int launch_fwd(const void* feat, const void* wt, const int* nbr, int nbr_stride, int m_cap, const int* m_dev,
+                      int K, int cin, int cout, void* out, const Epilogue& ep, hipStream_t stream) {
+  typedef typename Elem<DT>::T T;
+  const int cin_pad = round_up(cin, Elem<DT>::CH);
+  const int ntiles = (cout + 15) / 16;
+  // rows per wave: amortise the filter reads over more rows when there are plenty of rows
+  const int mt = m_cap >= 65536 ? 2 : 1;
+  const int rows_per_block = 4 * 16 * mt;
+  dim3 grid(cdiv(m_cap, rows_per_block)), block(256);
+#define BEVAMD_SPCONV(NT, MT)                                                                                    \
+  spconv_fwd_kernel<DT, NT, MT><<<grid, block, 0, stream>>>((const T*)feat, (const T*)wt, nbr, nbr_stride, m_cap, \
+                                                           m_dev, K, cin, cin_pad, cout, (T*)out, ep)
+#define BEVAMD_SPCONV_MT(NT) \
+  do { if (mt == 2) BEVAMD_SPCONV(NT, 2); else BEVAMD_SPCONV(NT, 1); } while (0)
+  if (ntiles <= 1) BEVAMD_SPCONV_MT(1);
+  else if (ntiles <= 2) BEVAMD_SPCONV_MT(2);
+  else if (ntiles <= 4) BEVAMD_SPCONV_MT(4);
+  else if (ntiles <= 8) BEVAMD_SPCONV_MT(8);
+  else {
+    set_error("spconv_conv_forward: cout=%d > 128 is not supported", cout);
+    return BEVAMD_ERR_UNSUPPORTED;
+  }
+#undef BEVAMD_SPCONV_MT
+#undef BEVAMD_SPCONV
+  BEVAMD_LAUNCH_CHECK("spconv_fwd");
+  return BEVAMD_OK;
+}
+
+}  // namespace bevamd
+
+using namespace bevamd;
+
+extern "C" {
+
+/* number of ELEMENTS of the prepared filter image for a conv with K offsets, cin -> cout */
+size_t bevamd_spconv_prepared_filter_elems(int dtype, int kernel_volume, int cin, int cout, int transpose_io) {
+  int rows = transpose_io ? cin : cout, cols = transpose_io ? cout : cin;
+  return (size_t)rows_padded(rows) * kernel_volume * round_up(cols, chunk_of(dtype));
+}
+
+int bevamd_spconv_prepare_filters(const void* filters, int dtype, int kernel_volume, int cin, int cout,
+                                  int transpose_io, void* prepared, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype >= 0 && dtype <= 2, "spconv_prepare_filters: bad dtype %d", dtype);
+  BEVAMD_REQUIRE(kernel_volume > 0 && cin > 0 && cout > 0, "spconv_prepare_filters: bad sizes");
+  BEVAMD_REQUIRE(filters && prepared, "spconv_prepare_filters: null buffer");
+  int rows = transpose_io ? cin : cout, cols = transpose_io ? cout : cin;
+  int rows_pad = rows_padded(rows), cols_pad = round_up(cols, chunk_of(dtype));
+  size_t total = (size_t)rows_pad * kernel_volume * cols_pad;
+  dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+  switch (dtype) {
+    case DT_F32: spconv_prepare_filters_kernel<DT_F32><<<grid, block, 0, stream>>>((const float*)filters, kernel_volume, cin, cout, rows_pad, cols_pad, transpose_io, (float*)prepared); break;
+    case DT_F16: spconv_prepare_filters_kernel<DT_F16><<<grid, block, 0, stream>>>((const _Float16*)filters, kernel_volume, cin, cout, rows_pad, cols_pad, transpose_io, (_Float16*)prepared); break;
+    default:     spconv_prepare_filters_kernel<DT_BF16><<<grid, block, 0, stream>>>((const uint16_t*)filters, kernel_volume, cin, cout, rows_pad, cols_pad, transpose_io, (uint16_t*)prepared); break;
+  }
+  BEVAMD_LAUNCH_CHECK("spconv_prepare_filters");
+  return BEVAMD_OK;
+}
+
+/* out[o,:] = epilogue( sum_k features[nbr[k][o], :] @ W[k] ).  `prepared` comes from
+ * bevamd_spconv_prepare_filters(transpose_io=0).  num_out rows (or *num_out_dev if non-null, with
+ * num_out as the launch bound).  Epilogue operands may be NULL. */
+int bevamd_spconv_conv_forward(const void* features, int dtype, const void* prepared, const int* nbr, int nbr_stride,
+                               int num_out, const int* num_out_dev, int kernel_volume, int cin, int cout, void* out,
+                               const void* bias, const float* bn_scale, const float* bn_shift, const void* residual,
+                               int relu, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype >= 0 && dtype <= 2, "spconv_conv_forward: bad dtype %d", dtype);
+  BEVAMD_REQUIRE(kernel_volume > 0 && cin > 0 && cout > 0 && num_out >= 0, "spconv_conv_forward: bad sizes");
+  if (num_out == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(features && prepared && nbr && out, "spconv_conv_forward: null buffer");
+  BEVAMD_REQUIRE(nbr_stride >= num_out, "spconv_conv_forward: nbr_stride %d < num_out %d", nbr_stride, num_out);
+  Epilogue ep{bias, bn_scale, bn_shift, residual, relu};
+  switch (dtype) {
+    case DT_F32: return launch_fwd<DT_F32>(features, prepared, nbr, nbr_stride, num_out, num_out_dev, kernel_volume, cin, cout, out, ep, stream);
+    case DT_F16: return launch_fwd<DT_F16>(features, prepared, nbr, nbr_stride, num_out, num_out_dev, kernel_volume, cin, cout, out, ep, stream);
+    default:     return launch_fwd<DT_BF16>(features, prepared, nbr, nbr_stride, num_out, num_out_dev, kernel_volume, cin, cout, out, ep, stream);
+  }
+}
+
+/* filter_grad [K, cin, cout] (same dtype as features) = sum over the rulebook of features^T @ out_grad.
+ * nbr is the FORWARD table (nbr[k][o] = input row).  ws: K*cin*cout fp32 accumulators. */
+size_t bevamd_spconv_wgrad_workspace_bytes(int kernel_volume, int cin, int cout) {
+  return align_up((size_t)kernel_volume * cin * cout * sizeof(float), 256);
+}
+
+int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dtype, const int* nbr, int nbr_stride,
+                             int num_out, int kernel_volume, int cin, int cout, void* filter_grad, void* ws,
+                             size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype >= 0 && dtype <= 2, "spconv_conv_wgrad: bad dtype %d", dtype);
+  BEVAMD_REQUIRE(kernel_volume > 0 && cin > 0 && cout > 0 && num_out >= 0, "spconv_conv_wgrad: bad sizes");
+  BEVAMD_REQUIRE(filter_grad != nullptr, "spconv_conv_wgrad: filter_grad is null");
+  BEVAMD_REQUIRE((long long)cin * cout <= 16384, "spconv_conv_wgrad: cin*cout=%d > 16384 unsupported", cin * cout);
+  const size_t nw = (size_t)kernel_volume * cin * cout;
+  float* acc = dtype == DT_F32 ? (float*)filter_grad : (float*)ws;
+  if (dtype != DT_F32) {
+    if (!ws || ws_bytes < bevamd_spconv_wgrad_workspace_bytes(kernel_volume, cin, cout)) {
+      set_error("spconv_conv_wgrad: workspace too small");
+      return BEVAMD_ERR_WORKSPACE;
+    }
+  }
+  BEVAMD_HIP_CHECK(hipMemsetAsync(acc, 0, nw * sizeof(float), stream));
+  if (num_out > 0) {
+    BEVAMD_REQUIRE(features && out_grad && nbr, "spconv_conv_wgrad: null input");
+    // slabs of output rows: enough workgroups to fill 256 CUs, each amortising its atomics
+    int rows_per_block = 32 * ((num_out + 32 * 64 - 1) / (32 * 64));
+    if (rows_per_block < 32) rows_per_block = 32;
+    dim3 grid(cdiv(num_out, rows_per_block), kernel_volume), block(256);
+    size_t lds = (size_t)32 * (cin + cout) * sizeof(float);
+    switch (dtype) {
+      case DT_F32: spconv_wgrad_kernel<DT_F32><<<grid, block, lds, stream>>>((const float*)features, (const float*)out_grad, nbr, nbr_stride, num_out, kernel_volume, cin, cout, rows_per_block, acc); break;
+      case DT_F16: spconv_wgrad_kernel<DT_F16><<<grid, block, lds, stream>>>((const _Float16*)features, (const _Float16*)out_grad, nbr, nbr_stride, num_out, kernel_volume, cin, cout, rows_per_block, acc); break;
+      default:     spconv_wgrad_kernel<DT_BF16><<<grid, block, lds, stream>>>((const uint16_t*)features, (const uint16_t*)out_grad, nbr, nbr_stride, num_out, kernel_volume, cin, cout, rows_per_block, acc); break;
+    }
+    BEVAMD_LAUNCH_CHECK("spconv_wgrad");
+  }
+  if (dtype != DT_F32) {
+    dim3 grid((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), block(256);
+    if (dtype == DT_F16) cast_from_f32_kernel<DT_F16><<<grid, block, 0, stream>>>(acc, nw, (_Float16*)filter_grad);
+    else cast_from_f32_kernel<DT_BF16><<<grid, block, 0, stream>>>(acc, nw, (uint16_t*)filter_grad);
+    BEVAMD_LAUNCH_CHECK("spconv_wgrad_cast");
+  }
+  return BEVAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,319 @@
+"""spconv ops — host-side mirror of `mmdet3d/ops/spconv/ops.py` + the pybind module `sparse_conv_ext`
+(spconv/src/all.cc:21-51) over the HIP C ABI.
+
+Two layers:
+  * `Rulebook` + `build_rulebook` / `sparse_conv` / `sparse_conv_backward`: the native, output-stationary
+    path the modules use (one launch per convolution, rulebooks cached, no per-offset GEMM loop);
+  * `sparse_conv_ext.*` and the reference-named helpers (`get_indice_pairs`, `indice_conv`,
+    `indice_conv_backward`, ...) with the reference's exact signatures and array shapes, for drop-in use.
+"""
+import torch
+
+from .. import _capi
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _dtype_code(t):
+    if t.dtype not in _DT:
+        raise RuntimeError(f"spconv: unsupported dtype {t.dtype} (fp32 / fp16 / bf16)")
+    return _DT[t.dtype]
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: the HIP extension has no CPU path")
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """ops.py:20-31."""
+    ndim = len(input_size)
+    output_size = []
+    for i in range(ndim):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        if kernel_size[i] == -1:
+            output_size.append(1)
+        else:
+            output_size.append(size)
+    return output_size
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    """ops.py:34-42."""
+    ndim = len(input_size)
+    output_size = []
+    for i in range(ndim):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        size = (input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i]
+        output_size.append(size)
+    return output_size
+
+
+def _as_list(v, ndim):
+    if not isinstance(v, (list, tuple)):
+        return [int(v)] * ndim
+    return [int(t) for t in v]
+
+
+# --------------------------------------------------------------------------------------------
+# native rulebook
+# --------------------------------------------------------------------------------------------
+class Rulebook:
+    """Output-stationary rulebook of one sparse convolution.
+
+    nbr [K, stride] int32: nbr[k, o] = input row feeding output row o through kernel offset k, or -1.
+    `indice_pairs()` materialises the reference-shaped arrays on demand."""
+
+    def __init__(self, out_indices, nbr, num_out, num_in, kernel_volume, subm, out_spatial_shape):
+        self.out_indices = out_indices
+        self.nbr = nbr
+        self.num_out = int(num_out)
+        self.num_in = int(num_in)
+        self.kernel_volume = int(kernel_volume)
+        self.subm = bool(subm)
+        self.out_spatial_shape = list(out_spatial_shape)
+        self._nbr_t = None
+        self._pairs = None
+
+    @property
+    def nbr_stride(self):
+        return self.nbr.shape[1]
+
+    def nbr_transposed(self):
+        """Input-stationary view (rows = inputs) for the input-gradient pass."""
+        if self._nbr_t is None:
+            if self.subm:
+                # submanifold symmetry: in = out + (k - c)  <=>  out = in + ((K-1-k) - c)
+                self._nbr_t = self.nbr.flip(0).contiguous()
+            else:
+                lib = _capi.load()
+                t = torch.empty((self.kernel_volume, max(self.num_in, 1)), dtype=torch.int32, device=self.nbr.device)
+                with torch.cuda.device(self.nbr.device):
+                    rc = lib.bevamd_spconv_transpose_nbr(_capi.ptr(self.nbr), self.nbr_stride, self.num_out,
+                                                         self.kernel_volume, _capi.ptr(t), t.shape[1],
+                                                         _capi.stream_ptr(self.nbr.device))
+                _capi.check(rc, "spconv_transpose_nbr")
+                self._nbr_t = t
+        return self._nbr_t
+
+    def indice_pairs(self):
+        """(indice_pairs [K,2,num_in] int32 -1 padded, indice_num [K] int32) as spconv_ops.h:56-59."""
+        if self._pairs is None:
+            lib = _capi.load()
+            dev = self.nbr.device
+            # third dimension = number of INPUT rows, as the reference allocates it (spconv_ops.h:56-58); an
+            # input row appears at most once per offset, so no offset can hold more pairs than that
+            K, L = self.kernel_volume, max(self.num_in, 1)
+            pairs = torch.empty((K, 2, L), dtype=torch.int32, device=dev)
+            num = torch.empty((K,), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                wsb = lib.bevamd_spconv_pairs_workspace_bytes(self.num_out, K)
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                rc = lib.bevamd_spconv_pairs_from_nbr(_capi.ptr(self.nbr), self.nbr_stride, self.num_out, K,
+                                                      _capi.ptr(pairs), L, _capi.ptr(num), _capi.ptr(ws), wsb,
+                                                      _capi.stream_ptr(dev))
+            _capi.check(rc, "spconv_pairs_from_nbr")
+            if self.num_in == 0:
+                pairs = pairs[:, :, :0]
+            self._pairs = (pairs, num)
+        return self._pairs
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, subm=False):
+    """Native counterpart of `get_indice_pairs`: returns a `Rulebook` (and syncs once, for strided convs,
+    to learn the number of active outputs — tensor shapes need it on the host)."""
+    _require_cuda(indices, "indices")
+    lib = _capi.load()
+    ndim = indices.shape[1] - 1
+    if ndim != 3:
+        raise NotImplementedError("only 3D sparse convolutions are implemented (BEVFusion uses no 2D/4D spconv)")
+    ksize, stride, padding, dilation = (_as_list(v, 3) for v in (ksize, stride, padding, dilation))
+    if any(d != 1 for d in dilation):
+        raise NotImplementedError("dilation != 1 is not supported")
+    indices = indices.contiguous()
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    n = indices.shape[0]
+    dev = indices.device
+    K = ksize[0] * ksize[1] * ksize[2]
+    in_shape = [int(s) for s in spatial_shape]
+    out_shape = in_shape if subm else get_conv_output_size(in_shape, ksize, stride, padding, dilation)
+    ks, st = _capi.ints(ksize), _capi.ints(stride)
+    import ctypes
+
+    host = ctypes.c_int(0)
+    count_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        cap = max(int(lib.bevamd_spconv_max_outputs(n, ks, st, int(bool(subm)))), 1)
+        if not subm:
+            vol = batch_size * out_shape[0] * out_shape[1] * out_shape[2]
+            cap = max(min(cap, vol), 1)
+        nbr = torch.empty((K, cap), dtype=torch.int32, device=dev)
+        out_indices = indices if subm else torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        wsb = lib.bevamd_spconv_rulebook_workspace_bytes(n, ks, st, int(bool(subm)))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.bevamd_spconv_build_rulebook(
+            _capi.ptr(indices), n, int(batch_size), _capi.ints(in_shape), _capi.ints(out_shape), ks, st,
+            _capi.ints(padding), _capi.ints(dilation), int(bool(subm)), _capi.ptr(out_indices), cap, _capi.ptr(nbr), cap,
+            _capi.ptr(count_dev), ctypes.byref(host), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+    _capi.check(rc, "spconv_build_rulebook")
+    m = int(host.value)
+    if not subm:
+        out_indices = out_indices[:m]
+    return Rulebook(out_indices, nbr, m, n, K, subm, out_shape)
+
+
+_prepared_cache = {}
+
+
+def prepare_filters(filters, transpose_io=False):
+    """MFMA-friendly filter image (cached per (storage, version, dtype, transpose))."""
+    lib = _capi.load()
+    key = (filters.data_ptr(), filters._version, filters.dtype, tuple(filters.shape), bool(transpose_io), filters.device)
+    hit = _prepared_cache.get(key)
+    if hit is not None:
+        return hit
+    if len(_prepared_cache) > 256:
+        _prepared_cache.clear()
+    f = filters.detach().contiguous()
+    cin, cout = f.shape[-2], f.shape[-1]
+    K = f.numel() // (cin * cout)
+    dt = _dtype_code(f)
+    with torch.cuda.device(f.device):
+        elems = lib.bevamd_spconv_prepared_filter_elems(dt, K, cin, cout, int(transpose_io))
+        out = torch.empty(elems, dtype=f.dtype, device=f.device)
+        rc = lib.bevamd_spconv_prepare_filters(_capi.ptr(f), dt, K, cin, cout, int(transpose_io), _capi.ptr(out),
+                                               _capi.stream_ptr(f.device))
+    _capi.check(rc, "spconv_prepare_filters")
+    _prepared_cache[key] = out
+    return out
+
+
+def sparse_conv(features, filters, nbr, num_out, bias=None, bn_scale=None, bn_shift=None, residual=None, relu=False,
+                prepared=None, transpose_io=False):
+    """out[o] = epilogue(sum_k features[nbr[k, o]] @ W[k]) — one fused launch.  filters [kx,ky,kz,Cin,Cout]."""
+    _require_cuda(features, "features")
+    lib = _capi.load()
+    features = features.contiguous()
+    filters = filters.to(features.dtype) if filters.dtype != features.dtype else filters
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    if transpose_io:
+        cin, cout = cout, cin
+    K = nbr.shape[0]
+    if features.shape[1] != cin:
+        raise RuntimeError(f"features have {features.shape[1]} channels, filters expect {cin}")
+    if prepared is None:
+        prepared = prepare_filters(filters, transpose_io)
+    out = torch.empty((num_out, cout), dtype=features.dtype, device=features.device)
+    if num_out == 0:
+        return out
+    dt = _dtype_code(features)
+    if bias is not None:
+        bias = bias.to(features.dtype).contiguous()
+    if residual is not None:
+        residual = residual.to(features.dtype).contiguous()
+    with torch.cuda.device(features.device):
+        rc = lib.bevamd_spconv_conv_forward(
+            _capi.ptr(features), dt, _capi.ptr(prepared), _capi.ptr(nbr), nbr.shape[1], int(num_out), None, K, cin, cout,
+            _capi.ptr(out), _capi.ptr(bias), _capi.ptr(bn_scale), _capi.ptr(bn_shift), _capi.ptr(residual), int(bool(relu)),
+            _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_conv_forward")
+    return out
+
+
+def sparse_conv_backward(features, filters, out_grad, rulebook_nbr, nbr_t, num_in):
+    """(in_grad [num_in, Cin], filter_grad like filters) for out = sparse_conv(features, filters, nbr)."""
+    lib = _capi.load()
+    features = features.contiguous()
+    out_grad = out_grad.contiguous().to(features.dtype)
+    filters = filters.to(features.dtype) if filters.dtype != features.dtype else filters
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    K = rulebook_nbr.shape[0]
+    num_out = out_grad.shape[0]
+    # input gradient: the same fused kernel on (out_grad, W^T, input-stationary table)
+    in_grad = sparse_conv(out_grad, filters, nbr_t, num_in, transpose_io=True)
+    # filter gradient
+    fgrad = torch.empty_like(filters.contiguous())
+    dt = _dtype_code(features)
+    with torch.cuda.device(features.device):
+        wsb = lib.bevamd_spconv_wgrad_workspace_bytes(K, cin, cout)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=features.device)
+        rc = lib.bevamd_spconv_conv_wgrad(_capi.ptr(features), _capi.ptr(out_grad), dt, _capi.ptr(rulebook_nbr),
+                                          rulebook_nbr.shape[1], num_out, K, cin, cout, _capi.ptr(fgrad), _capi.ptr(ws), wsb,
+                                          _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_conv_wgrad")
+    return in_grad, fgrad
+
+
+# --------------------------------------------------------------------------------------------
+# reference-named API (ops.py:45-211) and the pybind module's functions (all.cc:21-51)
+# --------------------------------------------------------------------------------------------
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
+                     subm=False, transpose=False, grid=None):
+    """ops.py:45-125 -> (out_indices [M,4], indice_pairs [K,2,N] int32, indice_num [K] int32)."""
+    if transpose:
+        raise NotImplementedError("transposed sparse convolution is not implemented (no BEVFusion config uses it)")
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+    pairs, num = rb.indice_pairs()
+    return rb.out_indices, pairs, num
+
+
+def _nbr_from_pairs(indice_pairs, indice_num, num_rows, inverse):
+    lib = _capi.load()
+    indice_pairs = indice_pairs.contiguous()
+    indice_num = indice_num.contiguous().to(indice_pairs.device)
+    K, _, L = indice_pairs.shape
+    nbr = torch.empty((K, max(num_rows, 1)), dtype=torch.int32, device=indice_pairs.device)
+    with torch.cuda.device(indice_pairs.device):
+        rc = lib.bevamd_spconv_nbr_from_pairs(_capi.ptr(indice_pairs), L, _capi.ptr(indice_num), K, int(bool(inverse)),
+                                              _capi.ptr(nbr), nbr.shape[1], _capi.stream_ptr(indice_pairs.device))
+    _capi.check(rc, "spconv_nbr_from_pairs")
+    return nbr
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
+    """ops.py:128-163 / spconv_ops.h:260-361 on reference-shaped pairs."""
+    if filters.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise NotImplementedError
+    nbr = _nbr_from_pairs(indice_pairs, indice_pair_num, num_activate_out, inverse)
+    return sparse_conv(features, filters, nbr, int(num_activate_out))
+
+
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
+    """ops.py:185-211 / spconv_ops.h:363-456 -> [in_grad, filter_grad]."""
+    num_out = out_bp.shape[0]
+    nbr = _nbr_from_pairs(indice_pairs, indice_pair_num, num_out, inverse)
+    nbr_t = _nbr_from_pairs(indice_pairs, indice_pair_num, features.shape[0], not inverse)
+    return list(sparse_conv_backward(features, filters, out_bp, nbr, nbr_t, features.shape[0]))
+
+
+class _SparseConvExt:
+    """Drop-in for the pybind module `sparse_conv_ext` (3D entries of all.cc:21-51)."""
+
+    @staticmethod
+    def get_indice_pairs_3d(indices, batch_size, out_shape, spatial_shape, ksize, stride, padding, dilation,
+                            out_padding, subm, transpose):
+        return list(get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding,
+                                     bool(subm), bool(transpose)))
+
+    @staticmethod
+    def indice_conv_fp32(features, filters, indice_pairs, indice_num, num_act_out, inverse, subm):
+        return indice_conv(features.float(), filters.float(), indice_pairs, indice_num, num_act_out, bool(inverse), bool(subm))
+
+    @staticmethod
+    def indice_conv_half(features, filters, indice_pairs, indice_num, num_act_out, inverse, subm):
+        return indice_conv(features.half(), filters.half(), indice_pairs, indice_num, num_act_out, bool(inverse), bool(subm))
+
+    @staticmethod
+    def indice_conv_backward_fp32(features, filters, out_grad, indice_pairs, indice_num, inverse, subm):
+        return indice_conv_backward(features.float(), filters.float(), out_grad.float(), indice_pairs, indice_num,
+                                    bool(inverse), bool(subm))
+
+    @staticmethod
+    def indice_conv_backward_half(features, filters, out_grad, indice_pairs, indice_num, inverse, subm):
+        return indice_conv_backward(features.half(), filters.half(), out_grad.half(), indice_pairs, indice_num,
+                                    bool(inverse), bool(subm))
+
+
+sparse_conv_ext = _SparseConvExt()

@@ -158,6 +158,74 @@ int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* n
                          int* voxel_num_dev, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * spconv: rulebook + sparse convolution  (reference: mmdet3d/ops/spconv)
+ * ------------------------------------------------------------------------- *
+ * Geometry arrays (in_shape, out_shape, ksize, stride, padding, dilation) are HOST int[3].
+ * indices: [n, 4] int32 (batch, x, y, z) as in SparseConvTensor.indices (structure.py:21-37).
+ * Offsets are numbered offset = (kx*Ky + ky)*Kz + kz, k = in - out*stride + pad (geometry.h:67-69).
+ * dtype codes: 0 = fp32, 1 = fp16, 2 = bf16. */
+
+/* The native rulebook is OUTPUT-STATIONARY: nbr [kernel_volume, nbr_stride] int32,
+ * nbr[k][o] = input row that feeds output row o through offset k, or -1.
+ *
+ * bevamd_spconv_build_rulebook replaces sparse_conv_ext.get_indice_pairs_3d
+ *   (spconv/src/all.cc:21-51 -> spconv_ops.h:27-141 getIndicePair<3>; kernels indice.cu.h:22-203).
+ * subm != 0: out rows == in rows (out_indices may be NULL or == indices); stride is forced to 1 and
+ *   padding to ksize/2 as spconv_ops.h:78-81 does.
+ * subm == 0: out_indices [out_cap, 4] receives the active outputs in ASCENDING linear index
+ *   (b, x, y, z) — the row order of the reference's CUDA path (torch::_unique, spconv_ops.h:130).
+ *   out_cap / nbr_stride must be >= bevamd_spconv_max_outputs(...) unless the caller knows better.
+ * num_out_dev [1] always receives the row count; num_out_host (optional) makes the call
+ * synchronise and return it to the host.  transpose / dilation != 1 are not supported. */
+size_t bevamd_spconv_rulebook_workspace_bytes(int n, const int* ksize, const int* stride, int subm);
+int bevamd_spconv_max_outputs(int n, const int* ksize, const int* stride, int subm);
+int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, const int* in_shape,
+                                 const int* out_shape, const int* ksize, const int* stride,
+                                 const int* padding, const int* dilation, int subm, int* out_indices,
+                                 int out_cap, int* nbr, int nbr_stride, int* num_out_dev,
+                                 int* num_out_host, void* ws, size_t ws_bytes, void* stream);
+
+/* The reference's rulebook arrays (spconv_ops.h:56-59): indice_pairs [K, 2, pairs_len] int32 (-1
+ * padded; [k][0] = input rows, [k][1] = output rows), indice_num [K].  Pairs of one offset are listed
+ * by ascending output row (the reference's CUDA order is atomicAdd order, i.e. unspecified). */
+size_t bevamd_spconv_pairs_workspace_bytes(int m, int kernel_volume);
+int bevamd_spconv_pairs_from_nbr(const int* nbr, int nbr_stride, int m, int kernel_volume,
+                                 int* indice_pairs, int pairs_len, int* indice_num, void* ws,
+                                 size_t ws_bytes, void* stream);
+/* ...and back, for callers that hold reference-shaped pairs (the drop-in indice_conv entry points).
+ * inverse != 0 swaps the two pair columns (spconv_ops.h:317,348). */
+int bevamd_spconv_nbr_from_pairs(const int* indice_pairs, int pairs_len, const int* indice_num,
+                                 int kernel_volume, int inverse, int* nbr, int nbr_stride, void* stream);
+/* input-stationary view: nbr_t[k][nbr[k][o]] = o (nbr_t pre-filled with -1 by the call). */
+int bevamd_spconv_transpose_nbr(const int* nbr, int nbr_stride, int m, int kernel_volume, int* nbr_t,
+                                int nbr_t_stride, void* stream);
+
+/* Filters [kx,ky,kz,cin,cout] (conv.py:100) -> MFMA-friendly image [cout_pad][K][cin_pad], zero
+ * padded.  transpose_io != 0 prepares W^T (cin and cout swap roles) for the input-gradient pass. */
+size_t bevamd_spconv_prepared_filter_elems(int dtype, int kernel_volume, int cin, int cout, int transpose_io);
+int bevamd_spconv_prepare_filters(const void* filters, int dtype, int kernel_volume, int cin, int cout,
+                                  int transpose_io, void* prepared, void* stream);
+
+/* Replaces sparse_conv_ext.indice_conv_{fp32,half} (all.cc:28-31 -> spconv_ops.h:260-361) and the
+ * gather / mm_out / scatter-add loop it runs per offset:
+ *   out[o, :] = epilogue( sum_k features[nbr[k][o], :] @ W[k] ),  fp32 accumulation, one launch.
+ * Optional epilogue (NULL to skip): bias [cout] (features' dtype), folded BatchNorm bn_scale /
+ * bn_shift [cout] fp32, residual [num_out, cout] (features' dtype), relu flag.
+ * Rows: num_out, or *num_out_dev when non-NULL (num_out then bounds the launch).  cout <= 128. */
+int bevamd_spconv_conv_forward(const void* features, int dtype, const void* prepared, const int* nbr,
+                               int nbr_stride, int num_out, const int* num_out_dev, int kernel_volume,
+                               int cin, int cout, void* out, const void* bias, const float* bn_scale,
+                               const float* bn_shift, const void* residual, int relu, void* stream);
+
+/* Filter-gradient half of sparse_conv_ext.indice_conv_backward_{fp32,half} (spconv_ops.h:363-456):
+ *   filter_grad[k] = sum over pairs of features[i]^T @ out_grad[o]   (fp32 accumulation).
+ * The input-gradient half is bevamd_spconv_conv_forward on (out_grad, prepared W^T, nbr_t). */
+size_t bevamd_spconv_wgrad_workspace_bytes(int kernel_volume, int cin, int cout);
+int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dtype, const int* nbr,
+                             int nbr_stride, int num_out, int kernel_volume, int cin, int cout,
+                             void* filter_grad, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * device primitives (exposed for tests; used by every precompute path)
  * ------------------------------------------------------------------------- */
 size_t bevamd_scan_workspace_bytes(size_t n);
