@@ -164,18 +164,11 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
     return Rulebook(out_indices, nbr, m, n, K, subm, out_shape)
 
 
-_prepared_cache = {}
-
-
 def prepare_filters(filters, transpose_io=False):
-    """MFMA-friendly filter image (cached per (storage, version, dtype, transpose))."""
+    """MFMA-friendly filter image [Cout_pad][K][Cin_pad] of `filters` [kx,ky,kz,Cin,Cout] (a ~microsecond
+    kernel).  Not cached here: a (data_ptr, version) key is unsafe across tensor lifetimes; modules cache it
+    against their own Parameter (see conv.py)."""
     lib = _capi.load()
-    key = (filters.data_ptr(), filters._version, filters.dtype, tuple(filters.shape), bool(transpose_io), filters.device)
-    hit = _prepared_cache.get(key)
-    if hit is not None:
-        return hit
-    if len(_prepared_cache) > 256:
-        _prepared_cache.clear()
     f = filters.detach().contiguous()
     cin, cout = f.shape[-2], f.shape[-1]
     K = f.numel() // (cin * cout)
@@ -186,7 +179,6 @@ def prepare_filters(filters, transpose_io=False):
         rc = lib.bevamd_spconv_prepare_filters(_capi.ptr(f), dt, K, cin, cout, int(transpose_io), _capi.ptr(out),
                                                _capi.stream_ptr(f.device))
     _capi.check(rc, "spconv_prepare_filters")
-    _prepared_cache[key] = out
     return out
 
 

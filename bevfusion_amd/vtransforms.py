@@ -1,0 +1,306 @@
+"""Camera -> BEV view transforms — mirror of `mmdet3d/models/vtransforms/{base,lss,depth_lss}.py`.
+
+Same class names, constructor kwargs, attributes (`dx, bx, nx, frustum, D, C`), sub-module names (`depthnet`,
+`dtransform`, `downsample`) and therefore state-dict keys; registered as VTRANSFORMS entries `LSSTransform` and
+`DepthLSSTransform`, so the reference's YAML configs build them unchanged.
+
+What changed underneath (`BaseTransform.bev_pool`, base.py:141-176):
+  * index computation + batch index + range mask + rank + sort + interval search happen in ONE device pipeline
+    (`BevPoolPlan.from_geometry`) with no boolean gather of the feature volume and no host sync; with
+    `cache_geometry=True` (static calibration at inference) it is done once and reused;
+  * the reduction reads the feature rows through the sort permutation (no `feats[indices]` copy) and writes
+    every BEV cell once; the result is returned as a channels-last VIEW of that buffer ([B, C*D, H, W] values
+    identical to the reference's `torch.cat(x.unbind(dim=2), 1)`).
+Reference defects handled as SURVEY.md lists them: D2 (`get_cam_feats` arity) and D3 (DepthLSSTransform gets
+scalar 1-channel depth, no height expansion — the semantics the released checkpoint's `Conv2d(1, 8, 1)` needs).
+"""
+from typing import Tuple
+
+import torch
+from torch import nn
+
+from .bev_pool import BevPoolPlan
+from .registry import register_everywhere
+
+__all__ = ["BaseTransform", "BaseDepthTransform", "LSSTransform", "DepthLSSTransform", "gen_dx_bx"]
+
+
+def gen_dx_bx(xbound, ybound, zbound):
+    """base.py:15-21."""
+    dx = torch.Tensor([row[2] for row in [xbound, ybound, zbound]])
+    bx = torch.Tensor([row[0] + row[2] / 2.0 for row in [xbound, ybound, zbound]])
+    nx = torch.LongTensor([(row[1] - row[0]) / row[2] for row in [xbound, ybound, zbound]])
+    return dx, bx, nx
+
+
+def _fp32(*tensors):
+    """mmcv's @force_fp32: half/bf16 tensor arguments are cast to float."""
+    return [t.float() if torch.is_tensor(t) and t.is_floating_point() and t.dtype != torch.float32 else t for t in tensors]
+
+
+class BaseTransform(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, image_size: Tuple[int, int], feature_size: Tuple[int, int],
+                 xbound: Tuple[float, float, float], ybound: Tuple[float, float, float],
+                 zbound: Tuple[float, float, float], dbound: Tuple[float, float, float], use_points="lidar",
+                 depth_input="scalar", height_expand=True, add_depth_features=True) -> None:
+        super().__init__()
+        self.in_channels = in_channels
+        self.image_size = image_size
+        self.feature_size = feature_size
+        self.xbound = xbound
+        self.ybound = ybound
+        self.zbound = zbound
+        self.dbound = dbound
+        self.use_points = use_points
+        assert use_points in ["radar", "lidar"]
+        self.depth_input = depth_input
+        assert depth_input in ["scalar", "one-hot"]
+        self.height_expand = height_expand
+        self.add_depth_features = add_depth_features
+
+        dx, bx, nx = gen_dx_bx(self.xbound, self.ybound, self.zbound)
+        self.dx = nn.Parameter(dx, requires_grad=False)
+        self.bx = nn.Parameter(bx, requires_grad=False)
+        self.nx = nn.Parameter(nx, requires_grad=False)
+
+        self.C = out_channels
+        self.frustum = self.create_frustum()
+        self.D = self.frustum.shape[0]
+        self.fp16_enabled = False
+        # MI355X-native knobs (not in the reference): reuse the bev_pool precompute across frames
+        self.cache_geometry = False
+        self._plan = None
+
+    def create_frustum(self):
+        """base.py:66-89."""
+        iH, iW = self.image_size
+        fH, fW = self.feature_size
+        ds = torch.arange(*self.dbound, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+        D, _, _ = ds.shape
+        xs = torch.linspace(0, iW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+        ys = torch.linspace(0, iH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+        frustum = torch.stack((xs, ys, ds), -1)
+        return nn.Parameter(frustum, requires_grad=False)
+
+    def get_geometry(self, camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs):
+        """base.py:92-135 -> [B, N, D, fH, fW, 3] frustum points in the lidar frame."""
+        camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans = _fp32(
+            camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans)
+        B, N, _ = camera2lidar_trans.shape
+        # undo post-transformation
+        points = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
+        points = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(points.unsqueeze(-1))
+        # cam_to_lidar
+        points = torch.cat((points[:, :, :, :, :, :2] * points[:, :, :, :, :, 2:3], points[:, :, :, :, :, 2:3]), 5)
+        combine = camera2lidar_rots.matmul(torch.inverse(intrins))
+        points = combine.view(B, N, 1, 1, 1, 3, 3).matmul(points).squeeze(-1)
+        points += camera2lidar_trans.view(B, N, 1, 1, 1, 3)
+        if "extra_rots" in kwargs:
+            extra_rots = _fp32(kwargs["extra_rots"])[0]
+            points = extra_rots.view(B, 1, 1, 1, 1, 3, 3).repeat(1, N, 1, 1, 1, 1, 1).matmul(points.unsqueeze(-1)).squeeze(-1)
+        if "extra_trans" in kwargs:
+            extra_trans = _fp32(kwargs["extra_trans"])[0]
+            points += extra_trans.view(B, 1, 1, 1, 1, 3).repeat(1, N, 1, 1, 1, 1)
+        return points
+
+    def get_cam_feats(self, x, *args):
+        raise NotImplementedError
+
+    # -- the hot path ---------------------------------------------------------------------------------
+    def make_plan(self, geom_feats, B):
+        """bev_pool precompute for this geometry (base.py:149-169 + bev_pool.py:83-93 + :39-46)."""
+        origin = (self.bx - self.dx / 2.0).detach().cpu().tolist()
+        return BevPoolPlan.from_geometry(geom_feats.reshape(-1, 3), B, origin, self.dx.detach().cpu().tolist(),
+                                         self.nx.detach().cpu().tolist())
+
+    def bev_pool(self, geom_feats, x):
+        """base.py:141-176: [B,N,D,H,W,3] geometry + [B,N,D,H,W,C] features -> [B, C*nz, nx, ny]."""
+        geom_feats, x = _fp32(geom_feats, x)
+        B, N, D, H, W, C = x.shape
+        Nprime = B * N * D * H * W
+        x = x.reshape(Nprime, C)
+        plan = self._plan if (self.cache_geometry and self._plan is not None and self._plan.n == Nprime
+                              and self._plan.B == B) else None
+        if plan is None:
+            plan = self.make_plan(geom_feats, B)
+            if self.cache_geometry:
+                self._plan = plan
+        out = plan.forward(x)                       # [B, nz, nx, ny, C] fp32
+        out = out.permute(0, 4, 1, 2, 3)            # [B, C, nz, nx, ny] view
+        # collapse Z (reference: torch.cat(x.unbind(dim=2), 1))
+        if out.shape[2] == 1:
+            return out[:, :, 0]                     # channels-last view, no copy
+        return torch.cat(out.unbind(dim=2), 1)
+
+    def _split_mats(self, camera2ego, lidar2ego, camera_intrinsics, camera2lidar, img_aug_matrix, lidar_aug_matrix):
+        intrins = camera_intrinsics[..., :3, :3]
+        post_rots = img_aug_matrix[..., :3, :3]
+        post_trans = img_aug_matrix[..., :3, 3]
+        camera2lidar_rots = camera2lidar[..., :3, :3]
+        camera2lidar_trans = camera2lidar[..., :3, 3]
+        extra_rots = lidar_aug_matrix[..., :3, :3]
+        extra_trans = lidar_aug_matrix[..., :3, 3]
+        return intrins, post_rots, post_trans, camera2lidar_rots, camera2lidar_trans, extra_rots, extra_trans
+
+    def forward(self, img, points, radar, camera2ego, lidar2ego, lidar2camera, lidar2image, camera_intrinsics,
+                camera2lidar, img_aug_matrix, lidar_aug_matrix, **kwargs):
+        """base.py:178-235."""
+        intrins, post_rots, post_trans, c2l_rots, c2l_trans, extra_rots, extra_trans = self._split_mats(
+            camera2ego, lidar2ego, camera_intrinsics, camera2lidar, img_aug_matrix, lidar_aug_matrix)
+        geom = self.get_geometry(c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots=extra_rots,
+                                 extra_trans=extra_trans)
+        mats_dict = {"intrin_mats": camera_intrinsics, "ida_mats": img_aug_matrix, "bda_mat": lidar_aug_matrix,
+                     "sensor2ego_mats": camera2ego}
+        x = self.get_cam_feats(img, mats_dict)
+        use_depth = False
+        if type(x) == tuple:
+            x, depth = x
+            use_depth = True
+        x = self.bev_pool(geom, x)
+        if use_depth:
+            return x, depth
+        return x
+
+
+class BaseDepthTransform(BaseTransform):
+    def depth_raster(self, img, points, lidar2image, img_aug_matrix, lidar_aug_matrix):
+        """base.py:269-329 for depth_input='scalar' without extra features: project every LiDAR point into every
+        camera and write its range at the truncated pixel -> [B, N, 1, iH, iW].  One scatter per sample for all
+        cameras (the reference loops over cameras with boolean indexing); colliding points are last-writer-wins
+        in both."""
+        batch_size = len(points)
+        n_cam = img.shape[1]
+        iH, iW = self.image_size
+        depth = torch.zeros(batch_size, n_cam, 1, iH, iW, device=points[0].device)
+        for b in range(batch_size):
+            cur_coords = points[b][:, :3].float()
+            cur_img_aug_matrix = img_aug_matrix[b].float()
+            cur_lidar_aug_matrix = lidar_aug_matrix[b].float()
+            cur_lidar2image = lidar2image[b].float()
+            # inverse aug
+            cur_coords = cur_coords - cur_lidar_aug_matrix[:3, 3]
+            cur_coords = torch.inverse(cur_lidar_aug_matrix[:3, :3]).matmul(cur_coords.transpose(1, 0))
+            # lidar2image
+            cur_coords = cur_lidar2image[:, :3, :3].matmul(cur_coords)
+            cur_coords += cur_lidar2image[:, :3, 3].reshape(-1, 3, 1)
+            # get 2d coords
+            dist = cur_coords[:, 2, :]
+            cur_coords[:, 2, :] = torch.clamp(cur_coords[:, 2, :], 1e-5, 1e5)
+            cur_coords[:, :2, :] /= cur_coords[:, 2:3, :]
+            # imgaug
+            cur_coords = cur_img_aug_matrix[:, :3, :3].matmul(cur_coords)
+            cur_coords += cur_img_aug_matrix[:, :3, 3].reshape(-1, 3, 1)
+            cur_coords = cur_coords[:, :2, :].transpose(1, 2)
+            cur_coords = cur_coords[..., [1, 0]]  # (row, col)
+            on_img = ((cur_coords[..., 0] < iH) & (cur_coords[..., 0] >= 0) & (cur_coords[..., 1] < iW)
+                      & (cur_coords[..., 1] >= 0))
+            pix = cur_coords.long()                                   # truncation (base.py:317)
+            cam = torch.arange(n_cam, device=pix.device).view(-1, 1).expand_as(on_img)
+            lin = (cam * iH + pix[..., 0]) * iW + pix[..., 1]
+            depth[b].view(-1)[lin[on_img]] = dist[on_img]
+        return depth
+
+    def forward(self, img, points, radar, sensor2ego, lidar2ego, lidar2camera, lidar2image, cam_intrinsic,
+                camera2lidar, img_aug_matrix, lidar_aug_matrix, metas=None, **kwargs):
+        """base.py:240-361."""
+        intrins, post_rots, post_trans, c2l_rots, c2l_trans, extra_rots, extra_trans = self._split_mats(
+            sensor2ego, lidar2ego, cam_intrinsic, camera2lidar, img_aug_matrix, lidar_aug_matrix)
+        if self.use_points == "radar":
+            points = radar
+        if self.height_expand or self.add_depth_features or self.depth_input != "scalar":
+            raise NotImplementedError("only scalar 1-channel depth input is implemented (what DepthLSSTransform's "
+                                      "Conv2d(1, 8, 1) stem and the released checkpoint use; SURVEY.md D3)")
+        depth = self.depth_raster(img, points, lidar2image, img_aug_matrix, lidar_aug_matrix)
+        geom = self.get_geometry(c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots=extra_rots,
+                                 extra_trans=extra_trans)
+        mats_dict = {"intrin_mats": intrins, "ida_mats": img_aug_matrix, "bda_mat": lidar_aug_matrix,
+                     "sensor2ego_mats": sensor2ego}
+        x = self.get_cam_feats(img, depth, mats_dict)
+        use_depth = False
+        if type(x) == tuple:
+            x, depth = x
+            use_depth = True
+        x = self.bev_pool(geom, x)
+        if use_depth:
+            return x, depth
+        return x
+
+
+def _downsample_block(out_channels, downsample):
+    if downsample > 1:
+        assert downsample == 2, downsample
+        return nn.Sequential(
+            nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU(True),
+            nn.Conv2d(out_channels, out_channels, 3, stride=downsample, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels), nn.ReLU(True),
+            nn.Conv2d(out_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU(True))
+    return nn.Identity()
+
+
+class LSSTransform(BaseTransform):
+    """lss.py:13-86."""
+
+    def __init__(self, in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound,
+                 downsample: int = 1) -> None:
+        super().__init__(in_channels=in_channels, out_channels=out_channels, image_size=image_size,
+                         feature_size=feature_size, xbound=xbound, ybound=ybound, zbound=zbound, dbound=dbound)
+        self.depthnet = nn.Conv2d(in_channels, self.D + self.C, 1)
+        self.downsample = _downsample_block(out_channels, downsample)
+
+    def get_cam_feats(self, x, *args):
+        (x,) = _fp32(x)
+        B, N, C, fH, fW = x.shape
+        x = x.view(B * N, C, fH, fW)
+        x = self.depthnet(x)
+        depth = x[:, : self.D].softmax(dim=1)
+        x = depth.unsqueeze(1) * x[:, self.D: (self.D + self.C)].unsqueeze(2)
+        x = x.view(B, N, self.C, self.D, fH, fW)
+        x = x.permute(0, 1, 3, 4, 5, 2)
+        return x
+
+    def forward(self, *args, **kwargs):
+        x = super().forward(*args, **kwargs)
+        x = self.downsample(x)
+        return x
+
+
+class DepthLSSTransform(BaseDepthTransform):
+    """depth_lss.py:14-102."""
+
+    def __init__(self, in_channels, out_channels, image_size, feature_size, xbound, ybound, zbound, dbound,
+                 downsample: int = 1) -> None:
+        super().__init__(in_channels=in_channels, out_channels=out_channels, image_size=image_size,
+                         feature_size=feature_size, xbound=xbound, ybound=ybound, zbound=zbound, dbound=dbound,
+                         depth_input="scalar", height_expand=False, add_depth_features=False)
+        self.dtransform = nn.Sequential(
+            nn.Conv2d(1, 8, 1), nn.BatchNorm2d(8), nn.ReLU(True),
+            nn.Conv2d(8, 32, 5, stride=4, padding=2), nn.BatchNorm2d(32), nn.ReLU(True),
+            nn.Conv2d(32, 64, 5, stride=2, padding=2), nn.BatchNorm2d(64), nn.ReLU(True))
+        self.depthnet = nn.Sequential(
+            nn.Conv2d(in_channels + 64, in_channels, 3, padding=1), nn.BatchNorm2d(in_channels), nn.ReLU(True),
+            nn.Conv2d(in_channels, in_channels, 3, padding=1), nn.BatchNorm2d(in_channels), nn.ReLU(True),
+            nn.Conv2d(in_channels, self.D + self.C, 1))
+        self.downsample = _downsample_block(out_channels, downsample)
+
+    def get_cam_feats(self, x, d, *args):
+        x, d = _fp32(x, d)
+        B, N, C, fH, fW = x.shape
+        d = d.view(B * N, *d.shape[2:])
+        x = x.view(B * N, C, fH, fW)
+        d = self.dtransform(d)
+        x = torch.cat([d, x], dim=1)
+        x = self.depthnet(x)
+        depth = x[:, : self.D].softmax(dim=1)
+        x = depth.unsqueeze(1) * x[:, self.D: (self.D + self.C)].unsqueeze(2)
+        x = x.view(B, N, self.C, self.D, fH, fW)
+        x = x.permute(0, 1, 3, 4, 5, 2)
+        return x
+
+    def forward(self, *args, **kwargs):
+        x = super().forward(*args, **kwargs)
+        x = self.downsample(x)
+        return x
+
+
+register_everywhere("vtransform", LSSTransform)
+register_everywhere("vtransform", DepthLSSTransform)

@@ -1,0 +1,105 @@
+"""CPU: host-side mirrors of the reference interface — configs load unchanged, registries resolve the
+reference's type names, module trees / state-dict keys / geometry formulas match."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bevfusion_amd import synth
+from bevfusion_amd.config import build_hot_path, load_config, recursive_eval
+from bevfusion_amd.registry import BACKBONES, CONV_LAYERS, VTRANSFORMS, build_conv_layer, build_norm_layer
+from bevfusion_amd.sparse_encoder import SparseEncoder
+from bevfusion_amd.vtransforms import DepthLSSTransform, LSSTransform, gen_dx_bx
+
+REF_CONFIGS = "/root/reference/configs"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="/root/reference not present (GPU box)")
+
+
+@needs_ref
+def test_every_reference_config_loads():
+    files = sorted(glob.glob(REF_CONFIGS + "/**/*.yaml", recursive=True))
+    assert len(files) >= 20
+    for f in files:
+        cfg = load_config(f)
+        assert isinstance(cfg, dict)
+        assert "${" not in repr(cfg), f           # every expression evaluated
+
+
+@needs_ref
+def test_flagship_config_builds_the_hot_path_modules():
+    cfg = load_config(REF_CONFIGS + "/nuscenes/det/transfusion/secfpn/camera+lidar/swint_v0p075/convfuser.yaml")
+    assert cfg["model"]["encoders"]["camera"]["vtransform"]["feature_size"] == [32, 88]   # ${[image_size[0]//8, ...]}
+    hp = build_hot_path(cfg)
+    vt = hp["vtransform"]
+    assert isinstance(vt, DepthLSSTransform) and vt.D == 118 and vt.C == 80 and vt.nx.tolist() == [360, 360, 1]
+    assert hp["voxelize"].max_voxels == (120000, 160000) and hp["voxelize"].grid_size.tolist() == [1440, 1440, 40]
+    enc = hp["lidar_backbone"]
+    assert isinstance(enc, SparseEncoder) and list(enc.sparse_shape) == [1440, 1440, 41]
+    w = enc.state_dict()
+    assert tuple(w["conv_input.0.weight"].shape) == (3, 3, 3, 5, 16)            # [kx,ky,kz,Cin,Cout] (conv.py:100)
+    assert tuple(w["conv_out.0.weight"].shape) == (1, 1, 3, 128, 128)
+    assert "encoder_layers.encoder_layer1.0.conv1.weight" in w and "encoder_layers.encoder_layer1.0.bn2.running_var" in w
+    # camera-only LSS config (BASELINE config 1 family)
+    cfg2 = load_config(REF_CONFIGS + "/nuscenes/det/centerhead/lssfpn/camera/256x704/swint/default.yaml")
+    vt2 = build_hot_path(cfg2)["vtransform"]
+    assert isinstance(vt2, LSSTransform)
+
+
+def test_recursive_eval_semantics():
+    cfg = {"a": [256, 704], "b": "${[a[0] // 8, a[1] // 8]}", "c": {"d": "${b}", "e": "${a[0] * 2}"}, "s": "${'x' + 'y'}"}
+    from bevfusion_amd.config import _attrify, _plain
+
+    out = _plain(recursive_eval(_attrify(cfg)))
+    assert out["b"] == [32, 88] and out["c"]["d"] == [32, 88] and out["c"]["e"] == 512 and out["s"] == "xy"
+
+
+def test_registries_resolve_reference_type_names():
+    assert "SubMConv3d" in CONV_LAYERS and "SparseConv3d" in CONV_LAYERS
+    assert "SparseEncoder" in BACKBONES and "DepthLSSTransform" in VTRANSFORMS and "LSSTransform" in VTRANSFORMS
+    conv = build_conv_layer(dict(type="SubMConv3d", indice_key="subm1"), 5, 16, 3, stride=1, padding=1, bias=False)
+    assert conv.subm and conv.indice_key == "subm1" and conv.bias is None and conv.padding == [1, 1, 1]
+    name, bn = build_norm_layer(dict(type="BN1d", eps=1e-3, momentum=0.01), 16)
+    assert name == "bn" and isinstance(bn, torch.nn.BatchNorm1d) and bn.eps == 1e-3 and bn.momentum == 0.01
+
+
+def test_sparse_encoder_tree_matches_reference_layout():
+    cfg = synth.CL_CONFIG
+    enc = SparseEncoder(5, list(cfg["sparse_shape"]), order=["conv", "norm", "act"], output_channels=128,
+                        encoder_channels=[[16, 16, 32], [32, 32, 64], [64, 64, 128], [128, 128]],
+                        encoder_paddings=[[0, 0, 1], [0, 0, 1], [0, 0, [1, 1, 0]], [0, 0]], block_type="basicblock")
+    from bevfusion_amd import spconv
+
+    convs = [m for m in enc.modules() if isinstance(m, spconv.SparseConvolution)]
+    assert len(convs) == 21 and sum(c.subm for c in convs) == 17          # 17 SubM + 4 strided
+    assert enc.encoder_layers.encoder_layer3[2][0].padding == [1, 1, 0]
+    assert enc.conv_out[0].kernel_size == [1, 1, 3] and enc.conv_out[0].stride == [1, 1, 2]
+    assert enc.conv_input[0].indice_key == "subm1" and enc.encoder_layers.encoder_layer1[0].conv1.indice_key is None
+
+
+def test_vtransform_geometry_matches_numpy_restatement():
+    """torch `get_geometry` (module) == numpy restatement used by the synthetic rig (both follow base.py:92-135)."""
+    cfg = synth.LSS_SMALL_CONFIG
+    vt = LSSTransform(256, 80, cfg["image_size"], cfg["feature_size"], cfg["xbound"], cfg["ybound"], cfg["zbound"],
+                      cfg["dbound"])
+    dx, bx, nx = gen_dx_bx(cfg["xbound"], cfg["ybound"], cfg["zbound"])
+    sdx, sbx, snx = synth.gen_dx_bx(cfg["xbound"], cfg["ybound"], cfg["zbound"])
+    assert np.array_equal(dx.numpy(), sdx) and np.array_equal(bx.numpy(), sbx) and nx.tolist() == snx.tolist()
+    fr = synth.create_frustum(cfg["image_size"], cfg["feature_size"], cfg["dbound"])
+    assert np.array_equal(vt.frustum.numpy(), fr) and vt.D == fr.shape[0] == 59
+    rig = synth.camera_rig(3)
+    t = lambda a: torch.from_numpy(a)[None]
+    geom = vt.get_geometry(t(rig["camera2lidar_rots"]), t(rig["camera2lidar_trans"]), t(rig["intrins"]),
+                           t(rig["post_rots"]), t(rig["post_trans"]))
+    ref = synth.get_geometry(fr, rig, batch=1)
+    assert geom.shape == ref.shape
+    assert np.max(np.abs(geom.numpy() - ref)) < 2e-3                       # metres; fp32 matmul order differs
+
+
+def test_product_has_no_oracle_import():
+    """The oracle is test infrastructure: nothing under bevfusion_amd/ may import it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bevfusion_amd")
+    for f in glob.glob(root + "/**/*.py", recursive=True):
+        src = open(f).read()
+        assert "import oracle" not in src and "from oracle" not in src, f
