@@ -57,10 +57,12 @@ def create_frustum(image_size, feature_size, dbound):
     """vtransforms/base.py:66-89 -> [D, fH, fW, 3] fp32 (u, v, depth)."""
     iH, iW = image_size
     fH, fW = feature_size
-    ds = np.arange(dbound[0], dbound[1], dbound[2], dtype=np.float32)
+    import torch  # the reference builds these with torch.arange / torch.linspace; numpy's differ by 1 ulp
+
+    ds = torch.arange(*dbound, dtype=torch.float).numpy()
     D = ds.shape[0]
-    xs = np.linspace(0, iW - 1, fW, dtype=np.float32)
-    ys = np.linspace(0, iH - 1, fH, dtype=np.float32)
+    xs = torch.linspace(0, iW - 1, fW, dtype=torch.float).numpy()
+    ys = torch.linspace(0, iH - 1, fH, dtype=torch.float).numpy()
     fr = np.empty((D, fH, fW, 3), dtype=np.float32)
     fr[..., 0] = xs[None, None, :]
     fr[..., 1] = ys[None, :, None]
