@@ -11,7 +11,7 @@ def scatter_nd(indices, updates, shape):
     flatted_indices = indices.view(-1, ndim)
     slices = [flatted_indices[:, i] for i in range(ndim)]
     slices += [Ellipsis]
-    ret[slices] = updates.view(*output_shape)
+    ret[tuple(slices)] = updates.view(*output_shape)
     return ret
 
 

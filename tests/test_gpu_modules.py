@@ -103,10 +103,14 @@ def test_depth_lss_transform_forward_flagship_shapes(dev):
         ref = _reference_bev_pool_torch(vt, geom, feats)
         assert tuple(pooled.shape) == (B, 80, 360, 360)
         assert float((pooled.double() - ref).abs().max()) <= 1e-4
+        # static calibration: the precompute is built once and reused; same bits as a fresh plan
         vt.cache_geometry = True
-        a = vt(img, pts, None, metas=None, **mats)
-        b = vt(img, pts, None, metas=None, **mats)     # second call reuses the plan
-        assert torch.equal(a, b) and torch.allclose(a, out, atol=1e-6)
+        a = vt.bev_pool(geom, feats)
+        plan = vt._plan
+        b = vt.bev_pool(geom, feats)
+        assert vt._plan is plan and torch.equal(a, b) and torch.equal(a, pooled)
+        # (whole-module outputs are not compared bit-for-bit: the depth raster is last-writer-wins on
+        #  colliding LiDAR points, in the reference as here)
 
 
 # ---- SparseEncoder with the oracle substituted for the native ops -------------------------------------------
@@ -134,7 +138,7 @@ def _oracle_conv(features, filters, rb):
 
 def _small_encoder(dev, dtype):
     torch.manual_seed(1)
-    enc = SparseEncoder(5, [40, 40, 17], order=["conv", "norm", "act"], output_channels=32,
+    enc = SparseEncoder(5, [40, 40, 41], order=["conv", "norm", "act"], output_channels=32,
                         encoder_channels=[[16, 16, 32], [32, 32, 64], [64, 64, 64], [64, 64]],
                         encoder_paddings=[[0, 0, 1], [0, 0, 1], [0, 0, [1, 1, 0]], [0, 0]], block_type="basicblock")
     for m in enc.modules():                       # non-trivial BN statistics
@@ -149,7 +153,7 @@ def _small_encoder(dev, dtype):
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 3e-2)])
 def test_sparse_encoder_vs_oracle_substitution(dev, monkeypatch, dtype, tol):
     rng = np.random.default_rng(0)
-    B, shape = 2, (40, 40, 17)
+    B, shape = 2, (40, 40, 41)
     idx = []
     for b in range(B):
         lin = rng.choice(int(np.prod(shape)), size=2500, replace=False)
