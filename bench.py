@@ -215,11 +215,7 @@ def main():
             ev[3].record()
         state["n_voxels"] = vf.shape[0]
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
+    from bevfusion_amd.sharding import barrier, max_over_ranks
 
     for _ in range(args.warmup):
         step()
@@ -236,12 +232,7 @@ def main():
     stage_ms = [float(np.mean([e[s].elapsed_time(e[s + 1]) for e in evs])) for s in range(NSTAGE)]
     kern_ms = stage_ms[0]  # the bev_pool stage is exactly one kernel launch
 
-    if world > 1:
-        import torch.distributed as dist
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, device=dev)  # slowest rank defines the step time
 
     if rank == 0:
         frames = args.steps * world
