@@ -205,15 +205,16 @@ def main():
         plan.launch_forward(feats, bev)                                   # camera: bev_pool
         if ev:
             ev[1].record()
-        vf, vc, _ = voxelize_batch([pts], cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                   cfg["max_voxels"][1])                  # LiDAR: voxelize + mean
+        # LiDAR: voxelize + mean into capacity-sized buffers, voxel count stays on the device (no host sync)
+        vf, vc, _, cnt = voxelize_batch([pts], cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
+                                        cfg["max_voxels"][1], sync=False)
         if ev:
             ev[2].record()
         with torch.no_grad():
-            state["lidar_bev"] = enc(vf.to(sp_dtype), vc, B)              # LiDAR: sparse encoder
+            state["lidar_bev"] = enc(vf[0], vc[0], B, num_voxels=cnt)     # LiDAR: sparse encoder (fused inference path)
         if ev:
             ev[3].record()
-        state["n_voxels"] = vf.shape[0]
+        state["n_voxels_dev"] = cnt
 
     from bevfusion_amd.sharding import barrier, max_over_ranks
 
@@ -230,6 +231,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stage_ms = [float(np.mean([e[s].elapsed_time(e[s + 1]) for e in evs])) for s in range(NSTAGE)]
+    state["n_voxels"] = int(state["n_voxels_dev"].reshape(-1)[0])
+    assert tuple(state["lidar_bev"].shape) == (B, 256, 180, 180)
     kern_ms = stage_ms[0]  # the bev_pool stage is exactly one kernel launch
 
     elapsed = max_over_ranks(elapsed, device=dev)  # slowest rank defines the step time

@@ -36,9 +36,15 @@ _SIGNATURES = {
     "bevamd_dynamic_voxelize": (I, [P, P, P, P, I, I, I, P]),
     "bevamd_voxelize_mean": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, Z, P]),
     # spconv
-    "bevamd_spconv_rulebook_workspace_bytes": (Z, [I, P, P, I]),
+    "bevamd_spconv_rulebook_workspace_bytes": (Z, [I, I, P, I]),
+    "bevamd_spconv_hash_index_bytes": (Z, [I]),
+    "bevamd_spconv_rank_index_bytes": (Z, [I, P]),
+    "bevamd_spconv_hash_index_build": (I, [P, I, P, I, P, P, Z, P]),
+    "bevamd_spconv_downsample": (I, [P, I, P, I, P, P, P, P, P, P, I, P, P, Z, P]),
+    "bevamd_spconv_neighbors": (I, [P, I, P, I, P, P, P, P, P, I, I, P, I, P, I, P]),
     "bevamd_spconv_max_outputs": (I, [I, P, P, I]),
     "bevamd_spconv_build_rulebook": (I, [P, I, I, P, P, P, P, P, P, I, P, I, P, I, P, P, P, Z, P]),
+    "bevamd_spconv_dense_bev": (I, [P, I, I, I, I, P, I, I, P, P, P]),
     "bevamd_spconv_pairs_workspace_bytes": (Z, [I, I]),
     "bevamd_spconv_pairs_from_nbr": (I, [P, I, I, I, P, I, P, P, Z, P]),
     "bevamd_spconv_nbr_from_pairs": (I, [P, I, P, I, I, P, I, P]),
@@ -46,6 +52,10 @@ _SIGNATURES = {
     "bevamd_spconv_prepared_filter_elems": (Z, [I, I, I, I, I]),
     "bevamd_spconv_prepare_filters": (I, [P, I, I, I, I, I, P, P]),
     "bevamd_spconv_conv_forward": (I, [P, I, P, P, I, I, P, I, I, I, P, P, P, P, P, I, P]),
+    "bevamd_spconv_tiled_supported": (I, [I, I, I]),
+    "bevamd_spconv_filter_image_elems": (Z, [I, I, I, I]),
+    "bevamd_spconv_make_filter_image": (I, [P, I, I, I, I, I, P, P]),
+    "bevamd_spconv_conv_forward_tiled": (I, [P, I, I, I, P, P, I, I, P, I, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_wgrad_workspace_bytes": (Z, [I, I, I]),
     "bevamd_spconv_conv_wgrad": (I, [P, P, I, P, I, I, I, I, I, P, P, Z, P]),
     # primitives

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_kernel(const uin
   }
 }
 
-constexpr size_t SCAN_SINGLE_BLOCK_MAX = 1u << 18;
+constexpr size_t SCAN_SINGLE_BLOCK_MAX = 1u << 14;  // above this one workgroup's serial trips cost more than two extra launches
 
 size_t scan_workspace_bytes(size_t n) {
   size_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;

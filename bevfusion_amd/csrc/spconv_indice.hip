@@ -13,10 +13,13 @@
 //     ~2.5 MB for 160 k voxels) instead of a dense grid that must be filled with -1 every call;
 //   * the rulebook is OUTPUT-STATIONARY: nbr[k][o] = input row feeding output row o through kernel
 //     offset k (or -1).  The fused convolution walks it without scatter-add or atomics;
-//   * strided conv: every input emits its <= prod(ceil(k/s)) candidate output keys, one stable radix
-//     sort + head flags gives the unique outputs in ascending linear index — exactly the row order of
-//     the reference's CUDA path (torch::_unique) — and the same hash answers "which input sits at
-//     out*stride - pad + k";
+//   * strided conv: every input sets the bits of the <= prod(ceil(k/s)) output cells it touches in a
+//     bitmap over the output grid (1 bit per cell: 1.4 MB at 720x720x21); a popcount prefix over the
+//     bitmap words numbers the active outputs in ascending linear index — exactly the row order of the
+//     reference's CUDA path (torch::_unique, spconv_ops.h:130) — with no sort.  The (bits, prefix)
+//     words are kept as a RANK INDEX of the output set: "which row sits at cell c" is one 8-byte load
+//     + popcount, which the next layers use instead of building a hash;
+//   * every count may stay on the device (n_dev / num_out_dev): nothing here needs a host sync;
 //   * the reference's (indice_pairs [K,2,N], indice_num [K]) arrays are derived from nbr by a
 //     per-offset stream compaction (deterministic: pairs ordered by output row; the reference's CUDA
 //     order is atomicAdd order, i.e. unspecified).
@@ -37,15 +40,18 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
   return k;
 }
 
-__global__ __launch_bounds__(256) void sp_hash_insert_kernel(const int* __restrict__ indices, int n, ConvGeom g,
+__global__ __launch_bounds__(256) void sp_hash_insert_kernel(const int* __restrict__ indices, int n_cap,
+                                                             const int* __restrict__ n_dev, ConvGeom g,
                                                              uint32_t* __restrict__ hkeys, int* __restrict__ hvals,
                                                              uint32_t mask) {
   int i = blockIdx.x * 256 + threadIdx.x;
+  int n = n_dev ? *n_dev : n_cap;
+  if (n > n_cap) n = n_cap;
   if (i >= n) return;
   const int4 c = ((const int4*)indices)[i];  // (b, x, y, z)
   uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + c.y) * g.in_shape[1] + c.z) * g.in_shape[2] + c.w);
   uint32_t slot = hash_u32(key) & mask;
-  while (true) {
+  for (uint32_t probe = 0; probe <= mask; ++probe) {  // bounded: a full table drops the row instead of spinning
     uint32_t prev = atomicCAS(&hkeys[slot], HASH_EMPTY, key);
     if (prev == HASH_EMPTY || prev == key) { hvals[slot] = i; return; }
     slot = (slot + 1) & mask;
@@ -55,52 +61,87 @@ __global__ __launch_bounds__(256) void sp_hash_insert_kernel(const int* __restri
 __device__ __forceinline__ int hash_lookup(const uint32_t* __restrict__ hkeys, const int* __restrict__ hvals,
                                            uint32_t mask, uint32_t key) {
   uint32_t slot = hash_u32(key) & mask;
-  while (true) {
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
     uint32_t k = hkeys[slot];
     if (k == key) return hvals[slot];
     if (k == HASH_EMPTY) return -1;
     slot = (slot + 1) & mask;
   }
+  return -1;
 }
 
-// nbr[k][o] for o in [0, m): input row at out*stride - pad + k, via the hash.  `m_dev` (optional)
-// bounds the rows when the count lives on the device.
+// 16-byte fill (launched like any other kernel, so it is captured into HIP graphs as a kernel node)
+__global__ __launch_bounds__(256) void sp_fill_kernel(uint4* __restrict__ p, size_t n16, uint32_t v) {
+  const uint4 val = make_uint4(v, v, v, v);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = val;
+}
+
+static int fill_u32(void* p, size_t bytes, uint32_t v, hipStream_t stream) {  // bytes % 16 == 0, p 16-byte aligned
+  const size_t n16 = bytes / 16;
+  if (n16 == 0) return BEVAMD_OK;
+  const size_t blocks = (n16 + 255) / 256;
+  sp_fill_kernel<<<dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream>>>((uint4*)p, n16, v);
+  BEVAMD_LAUNCH_CHECK("sp_fill");
+  return BEVAMD_OK;
+}
+
+// ---- rank index: words[w] = (bits of cells 32w..32w+31, number of set bits before word w) ----------
+__device__ __forceinline__ int rank_lookup(const uint2* __restrict__ words, uint32_t key) {
+  const uint2 w = words[key >> 5];
+  const uint32_t b = 1u << (key & 31);
+  return (w.x & b) ? (int)(w.y + __popc(w.x & (b - 1u))) : -1;
+}
+
+enum { INDEX_HASH = 0, INDEX_RANK = 1 };
+
+struct IndexRef {  // how to find the row of an input cell
+  const uint32_t* hkeys;
+  const int* hvals;
+  uint32_t mask;
+  const uint2* words;
+};
+
+template <int KIND>
+__device__ __forceinline__ int index_lookup(const IndexRef& ix, uint32_t key) {
+  if constexpr (KIND == INDEX_HASH) return hash_lookup(ix.hkeys, ix.hvals, ix.mask, key);
+  else return rank_lookup(ix.words, key);
+}
+
+// nbr[k][o] for o in [0, m): input row at out*stride - pad + k.  `m_dev` (optional) bounds the rows when
+// the count lives on the device.
+template <int KIND>
 __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out_indices, int m_cap,
-                                                     const int* __restrict__ m_dev, ConvGeom g,
-                                                     const uint32_t* __restrict__ hkeys,
-                                                     const int* __restrict__ hvals, uint32_t mask,
+                                                     const int* __restrict__ m_dev, ConvGeom g, IndexRef ix,
                                                      int* __restrict__ nbr, int nbr_stride) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
-  const int m = m_dev ? *m_dev : m_cap;
+  int m = m_dev ? *m_dev : m_cap;
+  if (m > m_cap) m = m_cap;
   if (o >= m) return;
   const int4 c = ((const int4*)out_indices)[o];
   const int kz = k % g.ksize[2];
   const int ky = (k / g.ksize[2]) % g.ksize[1];
   const int kx = k / (g.ksize[2] * g.ksize[1]);
-  const int ix = c.y * g.stride[0] - g.pad[0] + kx;
+  const int ix_ = c.y * g.stride[0] - g.pad[0] + kx;
   const int iy = c.z * g.stride[1] - g.pad[1] + ky;
   const int iz = c.w * g.stride[2] - g.pad[2] + kz;
   int r = -1;
-  if (ix >= 0 && ix < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && iz >= 0 && iz < g.in_shape[2]) {
-    uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
-    r = hash_lookup(hkeys, hvals, mask, key);
+  if (ix_ >= 0 && ix_ < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && iz >= 0 && iz < g.in_shape[2]) {
+    uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
+    r = index_lookup<KIND>(ix, key);
   }
   nbr[(size_t)k * nbr_stride + o] = r;
 }
 
-// strided conv, pass 1: input j emits the linear keys of the outputs it touches, at most `bound` of
-// them (bound = prod ceil(k/s)), padded with the sentinel.
-__global__ __launch_bounds__(256) void sp_candidates_kernel(const int* __restrict__ indices, int n, ConvGeom g,
-                                                            int bound, uint32_t sentinel,
-                                                            uint32_t* __restrict__ cand,
-                                                            uint32_t* __restrict__ vals) {
-  int j = blockIdx.x * 256 + threadIdx.x;
+// strided conv, pass 1: input j sets the bit of every output cell it touches
+__global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restrict__ indices, int n_cap,
+                                                              const int* __restrict__ n_dev, ConvGeom g,
+                                                              uint2* __restrict__ words) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  int n = n_dev ? *n_dev : n_cap;
+  if (n > n_cap) n = n_cap;
   if (j >= n) return;
   const int4 c = ((const int4*)indices)[j];
-  uint32_t* dst = cand + (size_t)j * bound;
-  uint32_t* vd = vals + (size_t)j * bound;
-  int cnt = 0;
   for (int kx = 0; kx < g.ksize[0]; ++kx) {
     int tx = c.y + g.pad[0] - kx;
     if (tx < 0 || tx % g.stride[0]) continue;
@@ -116,35 +157,87 @@ __global__ __launch_bounds__(256) void sp_candidates_kernel(const int* __restric
         if (tz < 0 || tz % g.stride[2]) continue;
         int oz = tz / g.stride[2];
         if (oz >= g.out_shape[2]) continue;
-        if (cnt < bound)
-          dst[cnt] = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
-        ++cnt;
+        uint32_t key = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
+        const uint32_t bit = 1u << (key & 31);
+        uint32_t* wp = &words[key >> 5].x;
+        if (!(__builtin_nontemporal_load(wp) & bit)) atomicOr(wp, bit);   // most cells are hit by several inputs
       }
     }
   }
-  for (int t = cnt < bound ? cnt : bound; t < bound; ++t) dst[t] = sentinel;
-  for (int t = 0; t < bound; ++t) vd[t] = 0;
 }
 
-__global__ __launch_bounds__(256) void sp_unique_heads_kernel(const uint32_t* __restrict__ keys, size_t n,
-                                                              uint32_t sentinel, uint32_t* __restrict__ flags) {
-  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  uint32_t k = keys[j];
-  flags[j] = (k < sentinel && (j == 0 || keys[j - 1] != k)) ? 1u : 0u;
+constexpr int RANK_TILE = 2048;  // bitmap words per workgroup in the popcount scan
+
+__device__ __forceinline__ unsigned block_exclusive_scan_256u(unsigned v, unsigned* lds_wave /*[4]*/, unsigned* total) {
+  const unsigned inc = wave_inclusive_scan(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 63) lds_wave[w] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned t = lds_wave[i];
+    if (i < w) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void sp_write_out_indices_kernel(const uint32_t* __restrict__ keys,
-                                                                   const uint32_t* __restrict__ flags,
-                                                                   const uint32_t* __restrict__ scan, size_t n,
-                                                                   ConvGeom g, int* __restrict__ out_indices) {
-  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n || !flags[j]) return;
-  uint32_t k = keys[j];
-  int oz = (int)(k % (uint32_t)g.out_shape[2]); k /= (uint32_t)g.out_shape[2];
-  int oy = (int)(k % (uint32_t)g.out_shape[1]); k /= (uint32_t)g.out_shape[1];
-  int ox = (int)(k % (uint32_t)g.out_shape[0]); k /= (uint32_t)g.out_shape[0];
-  ((int4*)out_indices)[scan[j]] = make_int4((int)k, ox, oy, oz);
+__global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint2* __restrict__ words, size_t nwords,
+                                                                uint32_t* __restrict__ tile_sums) {
+  __shared__ unsigned lds_wave[4];
+  const size_t base = (size_t)blockIdx.x * RANK_TILE;
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < RANK_TILE / 256; ++i) {
+    const size_t w = base + (size_t)i * 256 + threadIdx.x;
+    if (w < nwords) s += __popc(words[w].x);
+  }
+  unsigned tot;
+  block_exclusive_scan_256u(s, lds_wave, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// prefix of every word + the coordinates of every active output, in ascending linear index
+__global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restrict__ words, size_t nwords,
+                                                                 const uint32_t* __restrict__ tile_scan, ConvGeom g,
+                                                                 int* __restrict__ out_indices, int out_cap) {
+  __shared__ unsigned lds_wave[4];
+  constexpr int PER = RANK_TILE / 256;  // consecutive words per thread
+  const size_t w0 = (size_t)blockIdx.x * RANK_TILE + (size_t)threadIdx.x * PER;
+  uint32_t bits[PER];
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    bits[i] = w0 + i < nwords ? words[w0 + i].x : 0u;
+    s += __popc(bits[i]);
+  }
+  unsigned tot;
+  unsigned run = tile_scan[blockIdx.x] + block_exclusive_scan_256u(s, lds_wave, &tot);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (w0 + i >= nwords) break;
+    words[w0 + i].y = run;
+    uint32_t b = bits[i];
+    while (b) {
+      const int t = __ffs(b) - 1;
+      b &= b - 1;
+      if (out_indices && run < (unsigned)out_cap) {
+        uint32_t k = (uint32_t)((w0 + i) * 32 + t);
+        int oz = (int)(k % (uint32_t)g.out_shape[2]); k /= (uint32_t)g.out_shape[2];
+        int oy = (int)(k % (uint32_t)g.out_shape[1]); k /= (uint32_t)g.out_shape[1];
+        int ox = (int)(k % (uint32_t)g.out_shape[0]); k /= (uint32_t)g.out_shape[0];
+        ((int4*)out_indices)[run] = make_int4((int)k, ox, oy, oz);
+      }
+      ++run;
+    }
+  }
+}
+
+__global__ void sp_clamp_count_kernel(int* count, int cap) {
+  if (*count > cap) *count = cap;
 }
 
 // reference-shaped rulebook from nbr: per offset, compact (in,out) pairs ordered by out row
@@ -201,6 +294,31 @@ __global__ __launch_bounds__(256) void sp_transpose_nbr_kernel(const int* __rest
   if (i >= 0) nbr_t[(size_t)k * nbr_t_stride + i] = o;
 }
 
+// Dense BEV tail of SparseEncoder (sparse_encoder.py:126-131: out.dense() -> permute(0,1,4,2,3) -> view):
+// out[b][c*Z + z][x][y] = features[row(b,x,y,z)][c], zeros where no voxel is active.  Written as a GATHER over
+// the output (every element stored exactly once, 128-byte runs along y) instead of zero-fill + scatter.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void sp_dense_bev_kernel(const T* __restrict__ feat, int pitch, int C, IndexRef ix,
+                                                           int X, int Y, int Z, T* __restrict__ out) {
+  extern __shared__ int rows[];  // [Z][64]
+  const int b = blockIdx.z, h = blockIdx.y, w0 = blockIdx.x * 64;
+  for (int t = threadIdx.x; t < 64 * Z; t += 256) {
+    const int d = t >> 6, w = w0 + (t & 63);
+    int r = -1;
+    if (w < Y) r = index_lookup<KIND>(ix, (uint32_t)((((long long)b * X + h) * Y + w) * Z + d));
+    rows[t] = r;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w = w0 + lane;
+  const int CZ = C * Z;
+  for (int idx = wave; idx < CZ; idx += 4) {
+    const int c = idx / Z, d = idx - c * Z;
+    const int r = rows[d * 64 + lane];
+    T v = r >= 0 ? feat[(size_t)r * pitch + c] : (T)0;
+    if (w < Y) out[(((size_t)b * CZ + idx) * X + h) * Y + w] = v;
+  }
+}
+
 static int make_geom(int batch, const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
                      const int* pad, const int* dil, int subm, ConvGeom& g) {
   BEVAMD_REQUIRE(in_shape && out_shape && ksize && stride && pad, "spconv: null geometry (host pointers)");
@@ -237,25 +355,179 @@ static int conv_bound(const ConvGeom& g) {
   return b;
 }
 
+static size_t grid_words(int batch, const int* shape) {
+  unsigned long long v = (unsigned long long)(batch > 0 ? batch : 1) * shape[0] * shape[1] * shape[2];
+  return (size_t)((v + 31) / 32);
+}
+
+static size_t rank_index_bytes(int batch, const int* shape) {
+  const size_t nw = grid_words(batch, shape), nt = (nw + RANK_TILE - 1) / RANK_TILE;
+  return align_up(nw * 8, 256) + align_up((nt + 1) * 4, 256) + align_up(scan_workspace_bytes(nt + 1), 256) + 256;
+}
+
+static int hash_build(const int* indices, int n_cap, const int* n_dev, const ConvGeom& g, void* index, size_t bytes,
+                      hipStream_t stream) {
+  const uint32_t cap = hash_capacity((size_t)n_cap);
+  if (!index || bytes < (size_t)cap * 8) {
+    set_error("spconv hash index: buffer too small (%zu < %zu)", bytes, (size_t)cap * 8);
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  uint32_t* hkeys = (uint32_t*)index;
+  int* hvals = (int*)(hkeys + cap);
+  int frc = fill_u32(hkeys, (size_t)cap * 4, HASH_EMPTY, stream);
+  if (frc) return frc;
+  if (n_cap > 0) {
+    sp_hash_insert_kernel<<<dim3(cdiv(n_cap, 256)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, hkeys, hvals, cap - 1);
+    BEVAMD_LAUNCH_CHECK("sp_hash_insert");
+  }
+  return BEVAMD_OK;
+}
+
+static IndexRef hash_ref(const void* index, int n_cap) {
+  const uint32_t cap = hash_capacity((size_t)n_cap);
+  IndexRef r;
+  r.hkeys = (const uint32_t*)index;
+  r.hvals = (const int*)(r.hkeys + cap);
+  r.mask = cap - 1;
+  r.words = nullptr;
+  return r;
+}
+
+static IndexRef rank_ref(const void* index) {
+  IndexRef r;
+  r.hkeys = nullptr;
+  r.hvals = nullptr;
+  r.mask = 0;
+  r.words = (const uint2*)index;
+  return r;
+}
+
+// active outputs of a strided convolution, ascending linear index, + their rank index
+static int downsample(const int* indices, int n_cap, const int* n_dev, const ConvGeom& g, int* out_indices, int out_cap,
+                      int* num_out_dev, void* out_index, size_t bytes, hipStream_t stream) {
+  const size_t need = rank_index_bytes(g.batch, g.out_shape);
+  if (!out_index || bytes < need) {
+    set_error("spconv rank index: buffer too small (%zu < %zu)", bytes, need);
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  const size_t nw = grid_words(g.batch, g.out_shape), nt = (nw + RANK_TILE - 1) / RANK_TILE;
+  Carver cv(out_index, bytes);
+  uint2* words = cv.take<uint2>(nw);
+  uint32_t* tile_sums = cv.take<uint32_t>(nt + 1);
+  void* sws = cv.base + cv.off;
+  int frc = fill_u32(words, align_up(nw * 8, 16), 0u, stream);  // the Carver keeps 256-byte slack behind `words`
+  if (frc) return frc;
+  if (n_cap > 0) {
+    sp_mark_outputs_kernel<<<dim3(cdiv(n_cap, 256)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words);
+    BEVAMD_LAUNCH_CHECK("sp_mark_outputs");
+  }
+  sp_rank_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums);
+  BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
+  int rc = exclusive_scan_u32(tile_sums, tile_sums, nt, (uint32_t*)num_out_dev, sws, bytes - cv.off, stream);
+  if (rc) return rc;
+  sp_rank_apply_emit_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, g, out_indices, out_cap);
+  BEVAMD_LAUNCH_CHECK("sp_rank_apply_emit");
+  sp_clamp_count_kernel<<<1, 1, 0, stream>>>(num_out_dev, out_cap);
+  BEVAMD_LAUNCH_CHECK("sp_clamp_count");
+  return BEVAMD_OK;
+}
+
+static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const ConvGeom& g, int kind, const IndexRef& ix,
+                     int* nbr, int nbr_stride, hipStream_t stream) {
+  if (m_cap <= 0) return BEVAMD_OK;
+  dim3 grid(cdiv(m_cap, 256), g.K), block(256);
+  if (kind == INDEX_HASH) sp_nbr_kernel<INDEX_HASH><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
+  else sp_nbr_kernel<INDEX_RANK><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
+  BEVAMD_LAUNCH_CHECK("sp_nbr");
+  return BEVAMD_OK;
+}
+
 }  // namespace bevamd
 
 using namespace bevamd;
 
 extern "C" {
 
-// workspace for bevamd_spconv_build_rulebook (n = number of active inputs)
-size_t bevamd_spconv_rulebook_workspace_bytes(int n, const int* ksize, const int* stride, int subm) {
-  if (n < 1) n = 1;
-  size_t cap = hash_capacity((size_t)n);
-  size_t b = 2 * align_up(cap * 4, 256);
-  if (!subm && ksize && stride) {
-    size_t bound = 1;
-    for (int i = 0; i < 3; ++i) bound *= (size_t)((ksize[i] + stride[i] - 1) / stride[i]);
-    size_t nc = (size_t)n * bound;
-    b += 6 * align_up(nc * 4, 256);  // cand a/b, vals a/b, flags, scan
-    size_t s1 = radix_sort_workspace_bytes(nc), s2 = scan_workspace_bytes(nc);
-    b += align_up(s1 > s2 ? s1 : s2, 256);
+/* ---- granular, sync-free building blocks ------------------------------------------------------------- */
+
+size_t bevamd_spconv_hash_index_bytes(int n_cap) { return (size_t)hash_capacity((size_t)(n_cap > 0 ? n_cap : 1)) * 8; }
+
+size_t bevamd_spconv_rank_index_bytes(int batch_size, const int* shape) {
+  if (!shape || batch_size <= 0) return 0;
+  return rank_index_bytes(batch_size, shape);
+}
+
+int bevamd_spconv_hash_index_build(const int* indices, int n_cap, const int* n_dev, int batch_size, const int* shape,
+                                   void* index, size_t index_bytes, void* stream_) {
+  ConvGeom g;
+  const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+  int rc = make_geom(batch_size, shape, shape, one, one, zero, nullptr, 1, g);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n_cap >= 0 && (indices || n_cap == 0), "spconv_hash_index_build: bad input");
+  return hash_build(indices, n_cap, n_dev, g, index, index_bytes, (hipStream_t)stream_);
+}
+
+int bevamd_spconv_downsample(const int* indices, int n_cap, const int* n_dev, int batch_size, const int* in_shape,
+                             const int* out_shape, const int* ksize, const int* stride, const int* padding,
+                             int* out_indices, int out_cap, int* num_out_dev, void* out_index, size_t out_index_bytes,
+                             void* stream_) {
+  ConvGeom g;
+  int rc = make_geom(batch_size, in_shape, out_shape, ksize, stride, padding, nullptr, 0, g);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n_cap >= 0 && (indices || n_cap == 0), "spconv_downsample: bad input");
+  BEVAMD_REQUIRE(num_out_dev && out_indices && out_cap >= 1, "spconv_downsample: null output / out_cap < 1");
+  return downsample(indices, n_cap, n_dev, g, out_indices, out_cap, num_out_dev, out_index, out_index_bytes,
+                    (hipStream_t)stream_);
+}
+
+int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev, int batch_size, const int* in_shape,
+                            const int* out_shape, const int* ksize, const int* stride, const int* padding, int subm,
+                            int index_kind, const void* in_index, int in_index_n_cap, int* nbr, int nbr_stride,
+                            void* stream_) {
+  ConvGeom g;
+  int rc = make_geom(batch_size, in_shape, out_shape, ksize, stride, padding, nullptr, subm, g);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(index_kind == INDEX_HASH || index_kind == INDEX_RANK, "spconv_neighbors: index_kind %d", index_kind);
+  BEVAMD_REQUIRE(m_cap >= 0 && nbr_stride >= m_cap, "spconv_neighbors: nbr_stride %d < m_cap %d", nbr_stride, m_cap);
+  if (m_cap == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(out_indices && in_index && nbr, "spconv_neighbors: null buffer");
+  const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(in_index, in_index_n_cap) : rank_ref(in_index);
+  return neighbors(out_indices, m_cap, m_dev, g, index_kind, ix, nbr, nbr_stride, (hipStream_t)stream_);
+}
+
+int bevamd_spconv_dense_bev(const void* features, int elem_bytes, int pitch, int channels, int index_kind,
+                            const void* index, int index_n_cap, int batch_size, const int* shape, void* out,
+                            void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "spconv_dense_bev: elem_bytes %d", elem_bytes);
+  BEVAMD_REQUIRE(index_kind == INDEX_HASH || index_kind == INDEX_RANK, "spconv_dense_bev: index_kind %d", index_kind);
+  BEVAMD_REQUIRE(shape && batch_size > 0 && channels > 0 && pitch >= channels, "spconv_dense_bev: bad sizes");
+  BEVAMD_REQUIRE(features && index && out, "spconv_dense_bev: null buffer");
+  const int X = shape[0], Y = shape[1], Z = shape[2];
+  BEVAMD_REQUIRE(X > 0 && Y > 0 && Z > 0 && Z <= 512 && X <= 65535 && batch_size <= 65535, "spconv_dense_bev: bad shape");
+  BEVAMD_REQUIRE((unsigned long long)batch_size * X * Y * Z < 0xFFFFFFF0ull, "spconv_dense_bev: batch * volume must be < 2^32 - 16");
+  const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(index, index_n_cap) : rank_ref(index);
+  dim3 grid(cdiv(Y, 64), X, batch_size), block(256);
+  const size_t lds = (size_t)64 * Z * sizeof(int);
+#define BEVAMD_DENSE(T, KIND) \
+  sp_dense_bev_kernel<T, KIND><<<grid, block, lds, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out)
+  if (elem_bytes == 2) {
+    if (index_kind == INDEX_HASH) BEVAMD_DENSE(uint16_t, INDEX_HASH); else BEVAMD_DENSE(uint16_t, INDEX_RANK);
+  } else {
+    if (index_kind == INDEX_HASH) BEVAMD_DENSE(uint32_t, INDEX_HASH); else BEVAMD_DENSE(uint32_t, INDEX_RANK);
   }
+#undef BEVAMD_DENSE
+  BEVAMD_LAUNCH_CHECK("sp_dense_bev");
+  return BEVAMD_OK;
+}
+
+/* ---- one-call rulebook (any input row order; optional host count) ------------------------------------- */
+
+// workspace for bevamd_spconv_build_rulebook (n = number of active inputs)
+size_t bevamd_spconv_rulebook_workspace_bytes(int n, int batch_size, const int* out_shape, int subm) {
+  if (n < 1) n = 1;
+  size_t b = align_up((size_t)hash_capacity((size_t)n) * 8, 256);
+  if (!subm && out_shape && batch_size > 0) b += rank_index_bytes(batch_size, out_shape);
   return b + 1024;
 }
 
@@ -285,24 +557,20 @@ int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, cons
     return BEVAMD_OK;
   }
   BEVAMD_REQUIRE(indices && nbr && (subm || out_indices), "spconv_build_rulebook: null buffer");
-  size_t need = bevamd_spconv_rulebook_workspace_bytes(n, ksize, stride, subm);
+  size_t need = bevamd_spconv_rulebook_workspace_bytes(n, batch_size, g.out_shape, subm);
   if (!ws || ws_bytes < need) {
     set_error("spconv_build_rulebook: workspace too small (%zu < %zu)", ws_bytes, need);
     return BEVAMD_ERR_WORKSPACE;
   }
-  Carver cv(ws, ws_bytes);
-  const uint32_t cap = hash_capacity((size_t)n);
-  uint32_t* hkeys = cv.take<uint32_t>(cap);
-  int* hvals = cv.take<int>(cap);
-  BEVAMD_HIP_CHECK(hipMemsetAsync(hkeys, 0xFF, (size_t)cap * 4, stream));
-  sp_hash_insert_kernel<<<dim3(cdiv(n, 256)), dim3(256), 0, stream>>>(indices, n, g, hkeys, hvals, cap - 1);
-  BEVAMD_LAUNCH_CHECK("sp_hash_insert");
+  const size_t hbytes = align_up((size_t)hash_capacity((size_t)n) * 8, 256);
+  rc = hash_build(indices, n, nullptr, g, ws, hbytes, stream);
+  if (rc) return rc;
+  const IndexRef ix = hash_ref(ws, n);
 
   if (subm) {
     BEVAMD_REQUIRE(nbr_stride >= n, "spconv_build_rulebook: nbr_stride %d < n %d", nbr_stride, n);
-    sp_nbr_kernel<<<dim3(cdiv(n, 256), g.K), dim3(256), 0, stream>>>(indices, n, nullptr, g, hkeys, hvals, cap - 1,
-                                                                     nbr, nbr_stride);
-    BEVAMD_LAUNCH_CHECK("sp_nbr(subm)");
+    rc = neighbors(indices, n, nullptr, g, INDEX_HASH, ix, nbr, nbr_stride, stream);
+    if (rc) return rc;
     if (out_indices && out_indices != indices)
       BEVAMD_HIP_CHECK(hipMemcpyAsync(out_indices, indices, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToDevice, stream));
     sp_set_int_kernel<<<1, 1, 0, stream>>>(num_out_dev, n);
@@ -311,37 +579,15 @@ int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, cons
     return BEVAMD_OK;
   }
 
-  const int bound = conv_bound(g);
-  const size_t nc = (size_t)n * bound;
-  uint32_t* cand_a = cv.take<uint32_t>(nc);
-  uint32_t* vals_a = cv.take<uint32_t>(nc);
-  uint32_t* cand_s = cv.take<uint32_t>(nc);
-  uint32_t* vals_s = cv.take<uint32_t>(nc);
-  uint32_t* flags = cv.take<uint32_t>(nc);
-  uint32_t* scan = cv.take<uint32_t>(nc);
-  void* sws = cv.base + cv.off;
-  size_t sws_bytes = ws_bytes - cv.off;
-  const uint32_t sentinel =
-      (uint32_t)((unsigned long long)g.batch * g.out_shape[0] * g.out_shape[1] * g.out_shape[2]);
-  sp_candidates_kernel<<<dim3(cdiv(n, 256)), dim3(256), 0, stream>>>(indices, n, g, bound, sentinel, cand_a, vals_a);
-  BEVAMD_LAUNCH_CHECK("sp_candidates");
-  rc = radix_sort_pairs_u32(cand_a, vals_a, cand_s, vals_s, nc, bits_for((uint64_t)sentinel + 1), sws, sws_bytes,
-                            stream);
-  if (rc) return rc;
-  sp_unique_heads_kernel<<<dim3(cdiv((long long)nc, 256)), dim3(256), 0, stream>>>(cand_s, nc, sentinel, flags);
-  BEVAMD_LAUNCH_CHECK("sp_unique_heads");
-  rc = exclusive_scan_u32(flags, scan, nc, (uint32_t*)num_out_dev, sws, sws_bytes, stream);
-  if (rc) return rc;
   BEVAMD_REQUIRE((long long)out_cap >= 1, "spconv_build_rulebook: out_cap must be >= 1");
-  sp_write_out_indices_kernel<<<dim3(cdiv((long long)nc, 256)), dim3(256), 0, stream>>>(cand_s, flags, scan, nc, g,
-                                                                                       out_indices);
-  BEVAMD_LAUNCH_CHECK("sp_write_out_indices");
+  rc = downsample(indices, n, nullptr, g, out_indices, out_cap, num_out_dev, (char*)ws + hbytes, ws_bytes - hbytes, stream);
+  if (rc) return rc;
   // rows are bounded by out_cap on the launch side and by *num_out_dev on the device side
-  const int m_cap = out_cap < (long long)nc ? out_cap : (int)nc;
+  const long long most = (long long)n * conv_bound(g);
+  const int m_cap = out_cap < most ? out_cap : (int)most;
   BEVAMD_REQUIRE(nbr_stride >= m_cap, "spconv_build_rulebook: nbr_stride %d < out_cap %d", nbr_stride, m_cap);
-  sp_nbr_kernel<<<dim3(cdiv(m_cap, 256), g.K), dim3(256), 0, stream>>>(out_indices, m_cap, num_out_dev, g, hkeys,
-                                                                       hvals, cap - 1, nbr, nbr_stride);
-  BEVAMD_LAUNCH_CHECK("sp_nbr(conv)");
+  rc = neighbors(out_indices, m_cap, num_out_dev, g, INDEX_HASH, ix, nbr, nbr_stride, stream);
+  if (rc) return rc;
   if (num_out_host) {
     BEVAMD_HIP_CHECK(hipMemcpyAsync(num_out_host, num_out_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
     BEVAMD_HIP_CHECK(hipStreamSynchronize(stream));

@@ -1,0 +1,392 @@
+// Tiled sparse-convolution forward for gfx950, 16-bit features (fp16 / bf16), fp32 accumulate.
+//
+// Same operator as spconv_conv.hip (reference: spconv_ops.h:260-361 indiceConv<T>, one launch per
+// convolution, output-stationary rulebook nbr[k][o]) with the inner loop rebuilt around what bounds it
+// on MI355X — the row gather and its latency, not the MFMA rate:
+//
+//   * the reduction dimension is the FLATTENED (offset, input channel) axis, cut into 32-wide chunks;
+//     with Cin = 16 a chunk spans two kernel offsets, with Cin = 8 four, so small-channel layers do not
+//     multiply zeros (a lane group g of an MFMA operand carries 8 consecutive channels of ONE offset);
+//   * the filter is pre-arranged into MFMA-fragment order ("filter image", 1 KiB per (chunk, 16 output
+//     channels)): staging it into LDS is a linear copy and every B-fragment read is one conflict-free
+//     ds_read_b128 at lane*16;
+//   * RESIDENT kernel (filter image <= 64 KiB): the whole image lives in LDS, a workgroup is persistent
+//     over row tiles, no barrier in the main loop;  STREAM kernel: the image of one step is double-
+//     buffered in LDS (global -> registers issued before the MFMAs, written after them, one barrier);
+//   * rows are gathered with raw buffer loads: a missing neighbour (-1) becomes an out-of-range offset
+//     that returns zeros, so the loop is branch-free and the loads of step s+1 and the indices of step
+//     s+2 are in flight while step s multiplies;
+//   * operands are swapped (D^T = W^T * X^T): a lane ends up with 4 consecutive output channels of one
+//     row -> 8-byte stores, 16-byte epilogue-vector loads;
+//   * blockIdx is remapped so that each XCD (own L2) walks a contiguous range of row tiles;
+//   * the row count may live on the device (`m_dev`): launches are sized by capacity and never need a
+//     host sync.
+// Summation order is fixed (step-major, then chunk) -> bit-reproducible.
+#pragma once
+#include "common.h"
+
+namespace bevamd {
+namespace tile {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { T_F16 = 1, T_BF16 = 2 };  // same codes as the C ABI's dtype
+
+template <int DT> struct Num;
+template <> struct Num<T_F16> {
+  typedef _Float16 T;
+  __device__ static float to_f32(_Float16 v) { return (float)v; }
+  __device__ static _Float16 from_f32(float v) { return (_Float16)v; }
+};
+template <> struct Num<T_BF16> {
+  typedef uint16_t T;
+  __device__ static float to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+  __device__ static uint16_t from_f32(float v) {  // round to nearest even
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma(const u32x4& w, const u32x4& x, f32x4 acc) {
+  if constexpr (DT == T_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+
+struct Args {
+  const void* feat;     // [n_in, feat_stride] 16-bit
+  const void* wimg;     // filter image (see make_filter_image)
+  const int* nbr;       // [K, nbr_stride]
+  const int* m_dev;     // optional device row count
+  void* out;            // [m, out_stride] 16-bit
+  const void* bias;     // [cout] 16-bit or null
+  const float* scale;   // [cout] fp32 or null  } folded BatchNorm
+  const float* shift;   // [cout] fp32 or null  }
+  const void* residual; // [m, res_stride] 16-bit or null
+  // dense tail (optional): out_dense[b][c*dz + z][x][y] = value, rows addressed through out_indices
+  int feat_stride, n_in, nbr_stride, m_cap, K, cout, out_stride, res_stride, relu;
+};
+
+constexpr unsigned OOB = 0x80000000u;  // buffer offset that is always out of range (feature bytes < 2 GiB)
+
+// steps of the reduction: CINP >= 32 -> one kernel offset per step, CINP/32 chunks;
+//                         CINP <  32 -> 32/CINP kernel offsets per step, one chunk.
+template <int CINP> struct Steps {
+  static constexpr int CPO = CINP >= 32 ? CINP / 32 : 1;      // chunks per step
+  static constexpr int OPS = CINP >= 32 ? 1 : 32 / CINP;      // kernel offsets per step
+  __host__ __device__ static int nsteps(int K) { return (K + OPS - 1) / OPS; }
+};
+
+// kernel offset and byte offset inside the feature row that lane group g reads in step s
+template <int CINP>
+__device__ __forceinline__ void lane_slot(int s, int g, int& k, unsigned& byte_off) {
+  if constexpr (CINP >= 32) {
+    k = s;
+    byte_off = (unsigned)g * 16u;
+  } else {
+    constexpr int OPS = 32 / CINP, GPO = 4 / OPS;  // lane groups per offset
+    k = s * OPS + g / GPO;
+    byte_off = (unsigned)(g % GPO) * 16u;
+  }
+}
+
+// 4 consecutive output channels [col0, col0+4) of one row.  Rounding points follow the unfused reference
+// pipeline (the conv result, the bias add, BatchNorm and the residual add are each a stored 16-bit tensor).
+template <int DT>
+__device__ __forceinline__ void epilogue_store(const Args& a, int row, int col0, f32x4 v) {
+  typedef typename Num<DT>::T T;
+  if (col0 >= a.cout) return;
+  float x[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(v[j]));
+  T* op = (T*)a.out + (size_t)row * a.out_stride + col0;
+  const bool fast = col0 + 4 <= a.cout && ((a.out_stride | a.res_stride) & 3) == 0;  // wave-uniform except at the cout edge
+  if (fast) {
+    if (a.bias) {
+      const uint2 raw = *(const uint2*)((const T*)a.bias + col0);
+      const T* b = (const T*)&raw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(x[j] + Num<DT>::to_f32(b[j])));
+    }
+    if (a.scale) {
+      const float4 sc = *(const float4*)(a.scale + col0), sh = *(const float4*)(a.shift + col0);
+      x[0] = x[0] * sc.x + sh.x; x[1] = x[1] * sc.y + sh.y; x[2] = x[2] * sc.z + sh.z; x[3] = x[3] * sc.w + sh.w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(x[j]));
+    }
+    if (a.residual) {
+      const uint2 raw = *(const uint2*)((const T*)a.residual + (size_t)row * a.res_stride + col0);
+      const T* r = (const T*)&raw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(x[j] + Num<DT>::to_f32(r[j])));
+    }
+    T p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = Num<DT>::from_f32(a.relu && x[j] < 0.f ? 0.f : x[j]);
+    *(uint2*)op = *(const uint2*)p;
+    return;
+  }
+  for (int j = 0; j < 4; ++j) {
+    if (col0 + j >= a.cout) break;
+    float y = x[j];
+    if (a.bias) y = Num<DT>::to_f32(Num<DT>::from_f32(y + Num<DT>::to_f32(((const T*)a.bias)[col0 + j])));
+    if (a.scale) y = Num<DT>::to_f32(Num<DT>::from_f32(y * a.scale[col0 + j] + a.shift[col0 + j]));
+    if (a.residual) y = Num<DT>::to_f32(Num<DT>::from_f32(y + Num<DT>::to_f32(((const T*)a.residual)[(size_t)row * a.res_stride + col0 + j])));
+    if (a.relu && y < 0.f) y = 0.f;
+    op[j] = Num<DT>::from_f32(y);
+  }
+}
+
+// One wave, one tile of 16*MT output rows.  The reduction runs two steps per loop trip on two register sets
+// (A/B): while set A multiplies, the rows of the next step land in set B and the indices of the step after
+// that are being fetched — no register copies, no conditional loads, so hipcc keeps counted vmcnt waits and
+// the prefetches stay in flight across the back-edge.
+template <int DT, int CINP, int NT, int MT>
+struct WaveTile {
+  static constexpr int CPO = Steps<CINP>::CPO;
+  f32x4 acc[MT][NT];
+  int row0, m, lane, c, g, nsteps;
+  unsigned row_bytes;
+  __amdgpu_buffer_rsrc_t rs;
+
+  __device__ __forceinline__ void init(const Args& a, int row0_, int m_, int nsteps_) {
+    row0 = row0_;
+    m = m_;
+    nsteps = nsteps_;
+    lane = threadIdx.x & 63;
+    c = lane & 15;
+    g = lane >> 4;
+    row_bytes = (unsigned)a.feat_stride * 2u;
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat, 0, (unsigned)a.n_in * row_bytes, 0x00020000);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // raw neighbour indices of step s (address clamped into the table; validity is decided in gather())
+  __device__ __forceinline__ void load_nb(const Args& a, int s, int (&nb)[MT]) {
+    int k;
+    unsigned bo;
+    lane_slot<CINP>(s, g, k, bo);
+    const int kc = k < a.K ? k : a.K - 1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = row0 + mt * 16 + c;
+      const int rc = row < m ? row : m - 1;
+      nb[mt] = a.nbr[(size_t)kc * a.nbr_stride + rc];
+    }
+  }
+  __device__ __forceinline__ void gather(const Args& a, int s, const int (&nb)[MT], u32x4 (&dst)[MT][CPO]) {
+    int k;
+    unsigned bo;
+    lane_slot<CINP>(s, g, k, bo);
+    // callers pass s < nsteps (clamped); k can still fall off the end inside the last step when CINP < 32
+    const bool ok = CINP >= 32 || k < a.K;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const bool valid = ok && nb[mt] >= 0 && row0 + mt * 16 + c < m;
+      const unsigned voff = valid ? (unsigned)nb[mt] * row_bytes + bo : OOB;
+#pragma unroll
+      for (int cc = 0; cc < CPO; ++cc) dst[mt][cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)cc * 64u, 0, 0);
+    }
+  }
+  // multiply gathered rows by the step's filter fragments at `wl` (LDS)
+  __device__ __forceinline__ void multiply(const u32x4* __restrict__ wl, const u32x4 (&x)[MT][CPO]) {
+#pragma unroll
+    for (int cc = 0; cc < CPO; ++cc)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 b = wl[(cc * NT + nt) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma<DT>(b, x[mt][cc], acc[mt][nt]);
+      }
+  }
+  __device__ __forceinline__ void store(const Args& a) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = row0 + mt * 16 + c;
+      if (row >= m) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) epilogue_store<DT>(a, row, nt * 16 + g * 4, acc[mt][nt]);
+    }
+  }
+};
+
+// ---- RESIDENT: whole filter image in LDS, persistent over row tiles -----------------------------------
+template <int DT, int CINP, int NT, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void spconv_resident_kernel(Args a) {
+  extern __shared__ u32x4 lds[];
+  constexpr int CPO = Steps<CINP>::CPO;
+  constexpr int STEP = CPO * NT * 64;
+  const int nsteps = Steps<CINP>::nsteps(a.K);
+  const int total = nsteps * STEP;
+  for (int i = threadIdx.x; i < total; i += NW * 64) lds[i] = ((const u32x4*)a.wimg)[i];
+  __syncthreads();
+  const int m = a.m_dev ? (*a.m_dev < a.m_cap ? *a.m_dev : a.m_cap) : a.m_cap;
+  constexpr int ROWS = 16 * MT;
+  const int ntiles = (m + ROWS - 1) / ROWS;
+  const int nxb = gridDim.x >> 3;  // workgroups per XCD (grid is a multiple of 8; block b runs on XCD b % 8)
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per = (ntiles + 7) >> 3;
+  const int tend = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+  const int w = threadIdx.x >> 6;
+  for (int t = xcd * per + bix * NW + w; t < tend; t += nxb * NW) {
+    WaveTile<DT, CINP, NT, MT> wt;
+    wt.init(a, t * ROWS, m, nsteps);
+    int nbA[MT], nbB[MT];
+    u32x4 xA[MT][CPO], xB[MT][CPO];
+    const int last = nsteps - 1;
+    auto cl = [&](int st) { return st < last ? st : last; };  // clamped prefetches past the end are never multiplied
+    wt.load_nb(a, 0, nbA);
+    wt.load_nb(a, cl(1), nbB);
+    wt.gather(a, 0, nbA, xA);
+    wt.load_nb(a, cl(2), nbA);
+    for (int s = 0; s + 1 < nsteps; s += 2) {
+      wt.gather(a, s + 1, nbB, xB);
+      wt.load_nb(a, cl(s + 3), nbB);
+      wt.multiply(lds + (size_t)s * STEP, xA);
+      wt.gather(a, cl(s + 2), nbA, xA);
+      wt.load_nb(a, cl(s + 4), nbA);
+      wt.multiply(lds + (size_t)(s + 1) * STEP, xB);
+    }
+    if (nsteps & 1) wt.multiply(lds + (size_t)last * STEP, xA);
+    wt.store(a);
+  }
+}
+
+// ---- STREAM: one step's filter fragments double-buffered in LDS ----------------------------------------
+template <int DT, int CINP, int NT, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
+  extern __shared__ u32x4 lds[];
+  constexpr int CPO = Steps<CINP>::CPO;
+  constexpr int STEP = CPO * NT * 64;                    // u32x4 per step
+  constexpr int WPT = (STEP + NW * 64 - 1) / (NW * 64);  // staged u32x4 per thread
+  constexpr bool EXACT = STEP % (NW * 64) == 0;
+  const int nsteps = Steps<CINP>::nsteps(a.K);
+  const int m = a.m_dev ? (*a.m_dev < a.m_cap ? *a.m_dev : a.m_cap) : a.m_cap;
+  constexpr int BM = NW * 16 * MT;
+  const int nblk = (m + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per = (nblk + 7) >> 3;
+  const int tb = xcd * per + bix;
+  if (bix >= per || tb >= nblk) return;  // whole workgroup leaves together: no barrier is skipped
+  const int w = threadIdx.x >> 6;
+  const u32x4* wg = (const u32x4*)a.wimg;
+  WaveTile<DT, CINP, NT, MT> wt;
+  wt.init(a, tb * BM + w * 16 * MT, m, nsteps);
+  u32x4 wreg[WPT];
+  // filter fragments of step `st` (clamped) -> registers / registers -> LDS buffer `buf`
+  auto fetch_w = [&](int sc) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int e = threadIdx.x + i * NW * 64;
+      wreg[i] = (EXACT || e < STEP) ? wg[(size_t)sc * STEP + e] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto put_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int e = threadIdx.x + i * NW * 64;
+      if (EXACT || e < STEP) lds[buf * STEP + e] = wreg[i];
+    }
+  };
+  int nbA[MT], nbB[MT];
+  u32x4 xA[MT][CPO], xB[MT][CPO];
+  const int last = nsteps - 1;
+  auto cl = [&](int st) { return st < last ? st : last; };
+  fetch_w(0);
+  wt.load_nb(a, 0, nbA);
+  wt.load_nb(a, cl(1), nbB);
+  put_w(0);
+  wt.gather(a, 0, nbA, xA);
+  wt.load_nb(a, cl(2), nbA);
+  __syncthreads();
+  for (int s = 0; s + 1 < nsteps; s += 2) {
+    fetch_w(s + 1);
+    wt.gather(a, s + 1, nbB, xB);
+    wt.load_nb(a, cl(s + 3), nbB);
+    wt.multiply(lds, xA);  // step s from buffer 0
+    put_w(1);
+    __syncthreads();
+    fetch_w(cl(s + 2));
+    wt.gather(a, cl(s + 2), nbA, xA);
+    wt.load_nb(a, cl(s + 4), nbA);
+    wt.multiply(lds + STEP, xB);  // step s+1 from buffer 1
+    put_w(0);
+    __syncthreads();
+  }
+  if (nsteps & 1) wt.multiply(lds, xA);  // odd count: the last step sits in buffer 0
+  wt.store(a);
+}
+
+// ---- filter image ---------------------------------------------------------------------------------------
+// filters [K][cin][cout] (reference layout [kx,ky,kz,cin,cout], conv.py:100) -> image [step][cc][nt][lane][8]:
+// element e of lane (c = lane&15, g = lane>>4) is W[k][ci + e][nt*16 + c] with (k, ci) the slot of lane group
+// g in (step, cc); zero outside K / cin / cout.  transpose_io swaps the roles of cin and cout (input gradient).
+template <int DT, int CINP>
+__global__ __launch_bounds__(256) void spconv_filter_image_kernel(const typename Num<DT>::T* __restrict__ w, int K,
+                                                                  int cin, int cout, int nt_count, int transpose_io,
+                                                                  typename Num<DT>::T* __restrict__ img) {
+  constexpr int CPO = Steps<CINP>::CPO;
+  const int nsteps = Steps<CINP>::nsteps(K);
+  const size_t total = (size_t)nsteps * CPO * nt_count * 64 * 8;
+  const int rows = transpose_io ? cin : cout;   // output channels of this pass
+  const int cols = transpose_io ? cout : cin;   // reduction channels of this pass
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int e = (int)(i & 7);
+    const int lane = (int)((i >> 3) & 63);
+    size_t t = i >> 9;
+    const int nt = (int)(t % nt_count);
+    t /= nt_count;
+    const int cc = (int)(t % CPO);
+    const int s = (int)(t / CPO);
+    const int c = lane & 15, g = lane >> 4;
+    int k, ci;
+    if (CINP >= 32) {
+      k = s;
+      ci = cc * 32 + g * 8 + e;
+    } else {
+      constexpr int OPS = 32 / (CINP >= 32 ? 32 : CINP), GPO = 4 / OPS;
+      k = s * OPS + g / GPO;
+      ci = (g % GPO) * 8 + e;
+    }
+    const int co = nt * 16 + c;
+    typename Num<DT>::T v = Num<DT>::from_f32(0.f);
+    if (k < K && ci < cols && co < rows) {
+      const int wi = transpose_io ? co : ci, wo = transpose_io ? ci : co;
+      v = w[((size_t)k * cin + wi) * cout + wo];
+    }
+    img[i] = v;
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+static inline int pad_cin(int cin) { return cin <= 8 ? 8 : cin <= 16 ? 16 : cin <= 32 ? 32 : cin <= 64 ? 64 : cin <= 128 ? 128 : 0; }
+static inline int pad_nt(int cout) {
+  int nt = (cout + 15) / 16;
+  return nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 8 ? 8 : 0;
+}
+static inline size_t image_elems(int K, int cinp, int nt) {
+  const int cpo = cinp >= 32 ? cinp / 32 : 1, ops = cinp >= 32 ? 1 : 32 / cinp;
+  return (size_t)((K + ops - 1) / ops) * cpo * nt * 64 * 8;
+}
+
+// implemented once per dtype (spconv_tile_f16.hip / spconv_tile_bf16.hip)
+int launch_f16(const Args& a, int cinp, int nt, int variant, hipStream_t stream);
+int launch_bf16(const Args& a, int cinp, int nt, int variant, hipStream_t stream);
+int image_f16(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream);
+int image_bf16(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream);
+
+// variant encoding: 0 = auto; otherwise kind*100 + MT*10 + log2(NW)   (kind 1 = resident, 2 = stream)
+template <int DT>
+int launch_impl(const Args& a, int cinp, int nt, int variant, hipStream_t stream);
+
+}  // namespace tile
+}  // namespace bevamd

@@ -1,0 +1,71 @@
+// fp16 instantiation of the tiled sparse convolution (kernels: spconv_tile.h) + its C-ABI entry points.
+#include "spconv_tile_impl.h"
+
+namespace bevamd {
+namespace tile {
+int launch_f16(const Args& a, int cinp, int nt, int variant, hipStream_t stream) {
+  return launch_impl<T_F16>(a, cinp, nt, variant, stream);
+}
+int image_f16(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream) {
+  return image_impl<T_F16>(w, K, cin, cout, transpose_io, img, stream);
+}
+}  // namespace tile
+}  // namespace bevamd
+
+using namespace bevamd;
+
+extern "C" {
+
+/* 1 if (dtype, cin -> cout) is served by the tiled kernels (16-bit features, channels <= 128) */
+int bevamd_spconv_tiled_supported(int dtype, int cin, int cout) {
+  return (dtype == tile::T_F16 || dtype == tile::T_BF16) && cin > 0 && cout > 0 && tile::pad_cin(cin) && tile::pad_nt(cout);
+}
+
+/* ELEMENTS of the filter image of a K-offset cin -> cout convolution (transpose_io: input-gradient pass) */
+size_t bevamd_spconv_filter_image_elems(int kernel_volume, int cin, int cout, int transpose_io) {
+  const int rows = transpose_io ? cin : cout, cols = transpose_io ? cout : cin;
+  const int cinp = tile::pad_cin(cols), nt = tile::pad_nt(rows);
+  if (!cinp || !nt || kernel_volume <= 0) return 0;
+  return tile::image_elems(kernel_volume, cinp, nt);
+}
+
+int bevamd_spconv_make_filter_image(const void* filters, int dtype, int kernel_volume, int cin, int cout,
+                                    int transpose_io, void* image, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype == tile::T_F16 || dtype == tile::T_BF16, "spconv_make_filter_image: dtype %d is not 16-bit", dtype);
+  BEVAMD_REQUIRE(kernel_volume > 0 && cin > 0 && cout > 0, "spconv_make_filter_image: bad sizes");
+  BEVAMD_REQUIRE(filters && image, "spconv_make_filter_image: null buffer");
+  return dtype == tile::T_F16 ? tile::image_f16(filters, kernel_volume, cin, cout, transpose_io, image, stream)
+                              : tile::image_bf16(filters, kernel_volume, cin, cout, transpose_io, image, stream);
+}
+
+int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_stride, int num_in, const void* image,
+                                     const int* nbr, int nbr_stride, int num_out, const int* num_out_dev,
+                                     int kernel_volume, int cin, int cout, void* out, int out_stride, const void* bias,
+                                     const float* bn_scale, const float* bn_shift, const void* residual,
+                                     int residual_stride, int relu, int variant, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype == tile::T_F16 || dtype == tile::T_BF16, "spconv_conv_forward_tiled: dtype %d is not 16-bit", dtype);
+  BEVAMD_REQUIRE(kernel_volume > 0 && cin > 0 && cout > 0 && num_out >= 0 && num_in >= 0, "spconv_conv_forward_tiled: bad sizes");
+  if (num_out == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(features && image && nbr && out, "spconv_conv_forward_tiled: null buffer");
+  BEVAMD_REQUIRE(nbr_stride >= num_out, "spconv_conv_forward_tiled: nbr_stride %d < num_out %d", nbr_stride, num_out);
+  const int cinp = tile::pad_cin(cin), nt = tile::pad_nt(cout);
+  BEVAMD_REQUIRE(cinp && nt, "spconv_conv_forward_tiled: channels %d -> %d exceed 128", cin, cout);
+  // rows are read with 16-byte buffer loads of cin_pad channels: the row pitch must cover them
+  BEVAMD_REQUIRE(feat_stride >= cinp && feat_stride % 8 == 0 && ((uintptr_t)features & 15) == 0,
+                 "spconv_conv_forward_tiled: feature pitch %d must be a multiple of 8 and >= %d (zero-padded), 16-byte aligned",
+                 feat_stride, cinp);
+  BEVAMD_REQUIRE((unsigned long long)num_in * feat_stride * 2ull < 0x80000000ull,
+                 "spconv_conv_forward_tiled: feature matrix must be < 2 GiB");
+  BEVAMD_REQUIRE(out_stride >= cout && (!residual || residual_stride >= cout), "spconv_conv_forward_tiled: bad output pitch");
+  BEVAMD_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "spconv_conv_forward_tiled: scale and shift go together");
+  tile::Args a;
+  a.feat = features; a.wimg = image; a.nbr = nbr; a.m_dev = num_out_dev; a.out = out;
+  a.bias = bias; a.scale = bn_scale; a.shift = bn_shift; a.residual = residual;
+  a.feat_stride = feat_stride; a.n_in = num_in; a.nbr_stride = nbr_stride; a.m_cap = num_out; a.K = kernel_volume;
+  a.cout = cout; a.out_stride = out_stride; a.res_stride = residual_stride; a.relu = relu;
+  return dtype == tile::T_F16 ? tile::launch_f16(a, cinp, nt, variant, stream) : tile::launch_bf16(a, cinp, nt, variant, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Per-dtype instantiation of the tiled sparse-convolution kernels (included by spconv_tile_{f16,bf16}.hip).
+#pragma once
+#include "spconv_tile.h"
+
+namespace bevamd {
+namespace tile {
+
+template <int DT, int CINP, int NT, int MT, int NW>
+static int run_resident(const Args& a, hipStream_t stream) {
+  constexpr int CPO = Steps<CINP>::CPO;
+  const size_t lds = (size_t)Steps<CINP>::nsteps(a.K) * CPO * NT * 1024;
+  if (lds > 65536) {
+    set_error("spconv tiled: resident variant needs %zu B of LDS (> 64 KiB)", lds);
+    return BEVAMD_ERR_UNSUPPORTED;
+  }
+  const long long ntiles = ((long long)a.m_cap + 16 * MT - 1) / (16 * MT);
+  long long per_cu = 163840 / (long long)(lds + 512);          // workgroups per CU by LDS
+  const long long by_threads = 2048 / (NW * 64);               // and by wave slots
+  if (per_cu > by_threads) per_cu = by_threads;
+  if (per_cu < 1) per_cu = 1;
+  long long blocks = (ntiles + NW - 1) / NW;
+  if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+  blocks = (blocks + 7) / 8 * 8;
+  spconv_resident_kernel<DT, CINP, NT, MT, NW><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
+  BEVAMD_LAUNCH_CHECK("spconv_resident");
+  return BEVAMD_OK;
+}
+
+template <int DT, int CINP, int NT, int MT, int NW>
+static int run_stream(const Args& a, hipStream_t stream) {
+  constexpr int CPO = Steps<CINP>::CPO;
+  const size_t lds = (size_t)2 * CPO * NT * 1024;
+  constexpr int BM = NW * 16 * MT;
+  const long long nblk = ((long long)a.m_cap + BM - 1) / BM;
+  const long long blocks = (nblk + 7) / 8 * 8;
+  spconv_stream_kernel<DT, CINP, NT, MT, NW><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
+  BEVAMD_LAUNCH_CHECK("spconv_stream");
+  return BEVAMD_OK;
+}
+
+template <int DT, int CINP, int NT>
+static int run_shape(const Args& a, int variant, hipStream_t stream) {
+  constexpr bool RES_OK = CINP <= 32 && NT <= 2;  // shapes whose 27-offset image can fit 64 KiB of LDS
+  if (variant == 0) {
+    const size_t img = image_elems(a.K, CINP, NT) * 2;
+    if (RES_OK && img <= 65536) variant = 122;
+    else variant = NT >= 8 ? 211 : 221;
+  }
+  switch (variant) {
+    case 121: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 2, 4>(a, stream); break;
+    case 122: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 2, 8>(a, stream); break;
+    case 141: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 4, 4>(a, stream); break;
+    case 142: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 4, 8>(a, stream); break;
+    case 211: return run_stream<DT, CINP, NT, 1, 4>(a, stream);
+    case 212: return run_stream<DT, CINP, NT, 1, 8>(a, stream);
+    case 221: return run_stream<DT, CINP, NT, 2, 4>(a, stream);
+    case 222: return run_stream<DT, CINP, NT, 2, 8>(a, stream);
+    default: break;
+  }
+  set_error("spconv tiled: variant %d is not built for cin_pad=%d, cout tiles=%d", variant, CINP, NT);
+  return BEVAMD_ERR_UNSUPPORTED;
+}
+
+template <int DT>
+int launch_impl(const Args& a, int cinp, int nt, int variant, hipStream_t stream) {
+#define BEVAMD_SHAPE(C, N) if (cinp == C && nt == N) return run_shape<DT, C, N>(a, variant, stream)
+  BEVAMD_SHAPE(8, 1);
+  BEVAMD_SHAPE(8, 2);
+  BEVAMD_SHAPE(8, 4);
+  BEVAMD_SHAPE(8, 8);
+  BEVAMD_SHAPE(16, 1);
+  BEVAMD_SHAPE(16, 2);
+  BEVAMD_SHAPE(16, 4);
+  BEVAMD_SHAPE(16, 8);
+  BEVAMD_SHAPE(32, 1);
+  BEVAMD_SHAPE(32, 2);
+  BEVAMD_SHAPE(32, 4);
+  BEVAMD_SHAPE(32, 8);
+  BEVAMD_SHAPE(64, 1);
+  BEVAMD_SHAPE(64, 2);
+  BEVAMD_SHAPE(64, 4);
+  BEVAMD_SHAPE(64, 8);
+  BEVAMD_SHAPE(128, 1);
+  BEVAMD_SHAPE(128, 2);
+  BEVAMD_SHAPE(128, 4);
+  BEVAMD_SHAPE(128, 8);
+#undef BEVAMD_SHAPE
+  set_error("spconv tiled: no kernel for cin_pad=%d, cout tiles=%d", cinp, nt);
+  return BEVAMD_ERR_UNSUPPORTED;
+}
+
+template <int DT>
+int image_impl(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream) {
+  typedef typename Num<DT>::T T;
+  const int rows = transpose_io ? cin : cout, cols = transpose_io ? cout : cin;
+  const int cinp = pad_cin(cols), nt = pad_nt(rows);
+  if (!cinp || !nt) {
+    set_error("spconv filter image: channels %d -> %d exceed 128", cols, rows);
+    return BEVAMD_ERR_UNSUPPORTED;
+  }
+  const size_t total = image_elems(K, cinp, nt);
+  dim3 grid((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), block(256);
+#define BEVAMD_IMG(C) case C: spconv_filter_image_kernel<DT, C><<<grid, block, 0, stream>>>((const T*)w, K, cin, cout, nt, transpose_io, (T*)img); break
+  switch (cinp) {
+    BEVAMD_IMG(8);
+    BEVAMD_IMG(16);
+    BEVAMD_IMG(32);
+    BEVAMD_IMG(64);
+    default: BEVAMD_IMG(128);
+  }
+#undef BEVAMD_IMG
+  BEVAMD_LAUNCH_CHECK("spconv_filter_image");
+  return BEVAMD_OK;
+}
+
+}  // namespace tile
+}  // namespace bevamd

@@ -4,10 +4,13 @@ Same constructor kwargs, module tree and parameter names (`conv_input.0.weight`,
 .conv1.weight`, ..., `conv_out.0.weight`), so reference configs build it unchanged and checkpoints load by key.
 `voxel_features` is cast to half when `fp16_enabled` is set, like mmcv's `@auto_fp16(apply_to=("voxel_features",))`.
 """
+import os
+
 import torch
 from torch import nn
 
 from . import spconv
+from .spconv import fused as _fused
 from .registry import register_everywhere
 from .sparse_block import SparseBasicBlock, make_sparse_convmodule
 
@@ -28,6 +31,9 @@ class SparseEncoder(nn.Module):
         self.encoder_paddings = encoder_paddings
         self.stage_num = len(self.encoder_channels)
         self.fp16_enabled = False
+        # eval-mode 16-bit forward runs on the sync-free fused path (spconv/fused.py); set False (or
+        # BEVAMD_SPCONV_FUSED=0) to force the module-by-module path that mirrors the reference call for call
+        self.fused_inference = os.environ.get("BEVAMD_SPCONV_FUSED", "1") != "0"
 
         assert isinstance(order, (list, tuple)) and len(order) == 3
         assert set(order) == {"conv", "norm", "act"}
@@ -49,6 +55,14 @@ class SparseEncoder(nn.Module):
     def forward(self, voxel_features, coors, batch_size, **kwargs):
         """voxel_features [N, C]; coors [N, 4] int32 (batch_idx, x, y, z) -> [B, C*D, H, W] dense BEV features
         (sparse_encoder.py:100-132)."""
+        if self.fused_inference and _fused.encoder_supported(self, voxel_features):
+            try:
+                return _fused.run_encoder(self, voxel_features, coors, int(batch_size), kwargs.get("num_voxels"))
+            except _fused.Unfusable:
+                self.fused_inference = False  # a module tree / state the fused path does not implement
+        if kwargs.get("num_voxels") is not None:
+            n = int(kwargs["num_voxels"].reshape(-1)[0])  # capacity-padded inputs: the module path needs exact rows
+            voxel_features, coors = voxel_features[:n], coors[:n]
         if self.fp16_enabled and voxel_features.dtype == torch.float32:
             voxel_features = voxel_features.half()
         coors = coors.int()

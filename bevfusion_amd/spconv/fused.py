@@ -1,0 +1,273 @@
+"""Sync-free inference path of the sparse 3D encoder (eval mode, 16-bit features).
+
+What the module-by-module path (conv.py / sparse_block.py, a mirror of the reference's) costs per frame and this
+path removes:
+  * one host sync per strided convolution (row counts needed for tensor shapes)   -> counts stay on the device,
+    buffers and launches are sized by capacity (`min(n_in * prod(ceil(k/s)), grid volume)`);
+  * BatchNorm1d / ReLU / residual add as separate elementwise kernels              -> folded into the convolution
+    epilogue (eval-mode BN = fp32 scale/shift per channel);
+  * a filter re-layout per convolution call                                        -> filter images cached per weight;
+  * hash build per rulebook                                                        -> the (bitmap, prefix) rank index
+    that numbers a strided conv's outputs doubles as the lookup structure of the next layers;
+  * zero-fill + scatter + permute copy of the dense tail                           -> one gather kernel writes
+    [B, C*D, H, W] directly.
+Every kernel is launched on PyTorch's current stream and nothing reads back, so the whole encoder can be captured
+in a HIP graph (`torch.cuda.graph`).
+
+Reference semantics followed: SparseEncoder.forward (models/backbones/sparse_encoder.py:100-132), SparseBasicBlock
+.forward (ops/sparse_block.py:88-107), SparseConvolution.forward (ops/spconv/conv.py:118-223), BatchNorm1d eval.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _capi
+from . import ops
+
+INDEX_HASH, INDEX_RANK = 0, 1
+
+
+class Unfusable(Exception):
+    """The module tree / state does not match what the fused path implements; the caller falls back."""
+
+
+class Level:
+    """An active voxel set at one resolution: coordinates (capacity-sized), live count on the device, and an index
+    that maps a cell to its row (hash for arbitrary row order, rank for ascending order)."""
+
+    def __init__(self, indices, n_cap, n_dev, batch, shape):
+        self.indices = indices
+        self.n_cap = int(n_cap)
+        self.n_dev = n_dev          # int32 device tensor [1] or None (= n_cap rows are all live)
+        self.batch = int(batch)
+        self.shape = [int(s) for s in shape]
+        self.index_kind = None
+        self.index = None
+        self.index_n_cap = 0
+        self._subm = {}
+        self._down = {}
+
+    @property
+    def device(self):
+        return self.indices.device
+
+    def ensure_index(self):
+        if self.index is not None:
+            return
+        lib = _capi.load()
+        dev = self.device
+        with torch.cuda.device(dev):
+            nbytes = lib.bevamd_spconv_hash_index_bytes(self.n_cap)
+            self.index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = lib.bevamd_spconv_hash_index_build(_capi.ptr(self.indices), self.n_cap, _capi.ptr(self.n_dev), self.batch,
+                                                    _capi.ints(self.shape), _capi.ptr(self.index), nbytes,
+                                                    _capi.stream_ptr(dev))
+        _capi.check(rc, "spconv_hash_index_build")
+        self.index_kind, self.index_n_cap = INDEX_HASH, self.n_cap
+
+    def _neighbors(self, out_indices, m_cap, m_dev, out_shape, ksize, stride, padding, subm):
+        lib = _capi.load()
+        self.ensure_index()
+        dev = self.device
+        K = ksize[0] * ksize[1] * ksize[2]
+        nbr = torch.empty((K, max(m_cap, 1)), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.bevamd_spconv_neighbors(_capi.ptr(out_indices), m_cap, _capi.ptr(m_dev), self.batch, _capi.ints(self.shape),
+                                             _capi.ints(out_shape), _capi.ints(ksize), _capi.ints(stride), _capi.ints(padding),
+                                             int(subm), self.index_kind, _capi.ptr(self.index), self.index_n_cap,
+                                             _capi.ptr(nbr), nbr.shape[1], _capi.stream_ptr(dev))
+        _capi.check(rc, "spconv_neighbors")
+        return nbr
+
+    def subm_neighbors(self, ksize):
+        key = tuple(ksize)
+        if key not in self._subm:
+            self._subm[key] = self._neighbors(self.indices, self.n_cap, self.n_dev, self.shape, list(ksize), [1, 1, 1],
+                                              [k // 2 for k in ksize], True)
+        return self._subm[key]
+
+    def downsample(self, ksize, stride, padding):
+        """(output Level with its rank index, nbr [K, cap_out]) of a strided convolution over this set."""
+        key = (tuple(ksize), tuple(stride), tuple(padding))
+        if key in self._down:
+            return self._down[key]
+        lib = _capi.load()
+        dev = self.device
+        out_shape = ops.get_conv_output_size(self.shape, list(ksize), list(stride), list(padding), [1, 1, 1])
+        if min(out_shape) <= 0:
+            raise Unfusable(f"empty output grid {out_shape}")
+        bound = 1
+        for k, s in zip(ksize, stride):
+            bound *= (k + s - 1) // s
+        volume = self.batch * out_shape[0] * out_shape[1] * out_shape[2]
+        cap = max(1, min(self.n_cap * bound, volume))
+        out_indices = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        num_out = torch.empty(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = lib.bevamd_spconv_rank_index_bytes(self.batch, _capi.ints(out_shape))
+            index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = lib.bevamd_spconv_downsample(_capi.ptr(self.indices), self.n_cap, _capi.ptr(self.n_dev), self.batch,
+                                              _capi.ints(self.shape), _capi.ints(out_shape), _capi.ints(ksize),
+                                              _capi.ints(stride), _capi.ints(padding), _capi.ptr(out_indices), cap,
+                                              _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.stream_ptr(dev))
+        _capi.check(rc, "spconv_downsample")
+        out = Level(out_indices, cap, num_out, self.batch, out_shape)
+        out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
+        nbr = self._neighbors(out_indices, cap, num_out, out_shape, list(ksize), list(stride), list(padding), False)
+        self._down[key] = (out, nbr)
+        return out, nbr
+
+
+class FusedTensor:
+    def __init__(self, features, level):
+        self.features = features   # [level.n_cap, C] 16-bit; rows >= the live count are undefined
+        self.level = level
+
+
+# ---- per-module caches ------------------------------------------------------------------------------------
+def _version_key(*tensors):
+    return tuple((t.data_ptr(), t._version, t.dtype, t.device) if t is not None else None for t in tensors)
+
+
+def folded(conv, bn, dtype):
+    """(filter image, bias, bn_scale, bn_shift) of `conv` [+ eval-mode BatchNorm1d], cached on the conv module."""
+    key = (dtype,) + _version_key(conv.weight, conv.bias, *(() if bn is None else (bn.weight, bn.bias, bn.running_mean,
+                                                                                   bn.running_var)))
+    cache = conv.__dict__.get("_bevamd_fused")
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    w = conv.weight.detach()
+    if w.dtype != dtype:
+        w = w.to(dtype)
+    image = ops.make_filter_image(w)
+    bias = None if conv.bias is None else conv.bias.detach().to(dtype).contiguous()
+    scale = shift = None
+    if bn is not None:
+        if bn.running_mean is None or bn.running_var is None:
+            raise Unfusable("BatchNorm without running statistics")
+        inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        g = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(inv)
+        b = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(inv)
+        scale = (g * inv).contiguous()
+        shift = (b - bn.running_mean.detach().float() * scale).contiguous()
+    val = (image, bias, scale, shift)
+    conv.__dict__["_bevamd_fused"] = (key, val)
+    return val
+
+
+# ---- module walkers ---------------------------------------------------------------------------------------
+def _conv(conv, x, bn=None, relu=False, residual=None):
+    from .conv import SparseConvolution
+
+    assert isinstance(conv, SparseConvolution)
+    if conv.conv1x1 or conv.transposed or conv.inverse or any(d != 1 for d in conv.dilation) or conv.ndim != 3:
+        raise Unfusable("convolution flavour not handled by the fused path")
+    if bn is not None and (bn.training or not isinstance(bn, nn.BatchNorm1d)):
+        raise Unfusable("BatchNorm must be BatchNorm1d in eval mode")
+    dtype = x.features.dtype
+    cin, cout = conv.in_channels, conv.out_channels
+    if not ops.tiled_supported(dtype, cin, cout):
+        raise Unfusable(f"no tiled kernel for {cin}->{cout} {dtype}")
+    if x.features.shape[1] < ops.padded_channels(cin):
+        raise Unfusable("feature pitch smaller than the padded channel count")
+    image, bias, scale, shift = folded(conv, bn, dtype)
+    lvl = x.level
+    if conv.subm:
+        nbr, out_lvl = lvl.subm_neighbors(conv.kernel_size), lvl
+    else:
+        out_lvl, nbr = lvl.downsample(conv.kernel_size, conv.stride, conv.padding)
+    K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
+    out = torch.empty((out_lvl.n_cap, cout), dtype=dtype, device=x.features.device)
+    ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
+                          residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out)
+    return FusedTensor(out, out_lvl)
+
+
+def _sequential(seq, x):
+    from ..sparse_block import SparseBasicBlock
+    from .conv import SparseConvolution
+    from .modules import SparseSequential
+
+    mods = list(seq._modules.values())
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, SparseConvolution):
+            bn, relu = None, False
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                bn = mods[i + 1]
+                i += 1
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                relu = True
+                i += 1
+            x = _conv(m, x, bn, relu)
+        elif isinstance(m, SparseBasicBlock):
+            x = _basic_block(m, x)
+        elif isinstance(m, SparseSequential):
+            x = _sequential(m, x)
+        else:
+            raise Unfusable(f"module {type(m).__name__} inside a SparseSequential")
+        i += 1
+    return x
+
+
+def _basic_block(block, x):
+    """sparse_block.py:88-107: conv1-bn1-relu, conv2-bn2, + identity, relu."""
+    if block.downsample is not None:
+        raise Unfusable("SparseBasicBlock with a downsample branch")
+    if not isinstance(block.norm1, nn.BatchNorm1d) or not isinstance(block.norm2, nn.BatchNorm1d):
+        raise Unfusable("SparseBasicBlock norm is not BatchNorm1d")
+    y = _conv(block.conv1, x, block.norm1, relu=True)
+    if y.level is not x.level:
+        raise Unfusable("strided conv inside a residual block")
+    return _conv(block.conv2, y, block.norm2, relu=True, residual=x.features)
+
+
+def dense_bev(x):
+    """[B, C*Z, X, Y] dense tensor of a FusedTensor (sparse_encoder.py:126-131)."""
+    lib = _capi.load()
+    lvl = x.level
+    lvl.ensure_index()
+    C = x.features.shape[1]
+    X, Y, Z = lvl.shape
+    out = torch.empty((lvl.batch, C * Z, X, Y), dtype=x.features.dtype, device=x.features.device)
+    with torch.cuda.device(out.device):
+        rc = lib.bevamd_spconv_dense_bev(_capi.ptr(x.features), x.features.element_size(), x.features.stride(0), C,
+                                         lvl.index_kind, _capi.ptr(lvl.index), lvl.index_n_cap, lvl.batch,
+                                         _capi.ints(lvl.shape), _capi.ptr(out), _capi.stream_ptr(out.device))
+    _capi.check(rc, "spconv_dense_bev")
+    return out
+
+
+def encoder_supported(enc, voxel_features):
+    if enc.training or torch.is_grad_enabled():
+        return False
+    if not voxel_features.is_cuda:
+        return False
+    dtype = enc.conv_input[0].weight.dtype
+    return dtype in (torch.float16, torch.bfloat16)
+
+
+@torch.no_grad()
+def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None):
+    """SparseEncoder.forward on the fused path.  voxel_features [N, C_in] (any float dtype), coors [N, 4] int32
+    (batch, x, y, z); `num_voxels` (optional int32 device tensor [1]): live row count when the inputs are
+    capacity-padded buffers straight from the voxelizer (`voxelize_batch(..., sync=False)`)."""
+    dtype = enc.conv_input[0].weight.dtype
+    n = voxel_features.shape[0]
+    if n == 0:
+        raise Unfusable("empty input")
+    cin = voxel_features.shape[1]
+    pitch = ops.padded_channels(cin)
+    feats = torch.zeros((n, pitch), dtype=dtype, device=voxel_features.device)
+    feats[:, :cin] = voxel_features
+    coors = coors.int().contiguous()
+    if num_voxels is not None:
+        num_voxels = num_voxels.reshape(-1)[:1].int().contiguous()
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape)
+    x = FusedTensor(feats, lvl)
+    x = _sequential(enc.conv_input, x)
+    x = _sequential(enc.encoder_layers, x)
+    x = _sequential(enc.conv_out, x)
+    return dense_bev(x)

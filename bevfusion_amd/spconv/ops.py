@@ -151,7 +151,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
             cap = max(min(cap, vol), 1)
         nbr = torch.empty((K, cap), dtype=torch.int32, device=dev)
         out_indices = indices if subm else torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        wsb = lib.bevamd_spconv_rulebook_workspace_bytes(n, ks, st, int(bool(subm)))
+        wsb = lib.bevamd_spconv_rulebook_workspace_bytes(n, int(batch_size), _capi.ints(out_shape), int(bool(subm)))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         rc = lib.bevamd_spconv_build_rulebook(
             _capi.ptr(indices), n, int(batch_size), _capi.ints(in_shape), _capi.ints(out_shape), ks, st,
@@ -182,6 +182,76 @@ def prepare_filters(filters, transpose_io=False):
     return out
 
 
+def tiled_supported(dtype, cin, cout):
+    """True when the tiled MFMA kernels (csrc/spconv_tile.h) serve this convolution: 16-bit features, <= 128 channels."""
+    if dtype not in (torch.float16, torch.bfloat16):
+        return False
+    return bool(_capi.load().bevamd_spconv_tiled_supported(_DT[dtype], int(cin), int(cout)))
+
+
+def padded_channels(cin):
+    """Row pitch (elements) the tiled kernels read for `cin` input channels."""
+    for c in (8, 16, 32, 64, 128):
+        if cin <= c:
+            return c
+    raise RuntimeError(f"tiled sparse conv supports at most 128 channels, got {cin}")
+
+
+def make_filter_image(filters, transpose_io=False):
+    """Filter [kx,ky,kz,Cin,Cout] (16-bit) -> MFMA-fragment-ordered image for `sparse_conv_tiled`.  Build once per
+    weight (modules cache it against their Parameter)."""
+    lib = _capi.load()
+    f = filters.detach().contiguous()
+    _require_cuda(f, "filters")
+    cin, cout = f.shape[-2], f.shape[-1]
+    K = f.numel() // (cin * cout)
+    dt = _dtype_code(f)
+    with torch.cuda.device(f.device):
+        elems = lib.bevamd_spconv_filter_image_elems(K, cin, cout, int(transpose_io))
+        if elems == 0:
+            raise RuntimeError(f"no tiled kernel for {cin} -> {cout} channels")
+        img = torch.empty(elems, dtype=f.dtype, device=f.device)
+        rc = lib.bevamd_spconv_make_filter_image(_capi.ptr(f), dt, K, cin, cout, int(transpose_io), _capi.ptr(img),
+                                                 _capi.stream_ptr(f.device))
+    _capi.check(rc, "spconv_make_filter_image")
+    return img
+
+
+def sparse_conv_tiled(features, image, nbr, num_out, kernel_volume, cin, cout, bias=None, bn_scale=None, bn_shift=None,
+                      residual=None, relu=False, num_out_dev=None, out=None, variant=0):
+    """One fused launch: out[o] = relu?(bn_scale * (sum_k features[nbr[k, o]] @ W[k] + bias) + bn_shift + residual[o]).
+
+    features [num_in, pitch >= padded_channels(cin)] 16-bit with zero padding channels; `image` from
+    `make_filter_image`; `num_out` bounds the launch, `num_out_dev` (int32 device scalar, optional) is the live row
+    count so that no host sync is needed.  Rows >= the live count of `out` are left untouched."""
+    lib = _capi.load()
+    _require_cuda(features, "features")
+    if features.stride(1) != 1:
+        features = features.contiguous()
+    dt = _dtype_code(features)
+    if out is None:
+        out = torch.empty((num_out, cout), dtype=features.dtype, device=features.device)
+    if num_out == 0:
+        return out
+    if residual is not None and residual.stride(1) != 1:
+        residual = residual.contiguous()
+    with torch.cuda.device(features.device):
+        rc = lib.bevamd_spconv_conv_forward_tiled(
+            _capi.ptr(features), dt, features.stride(0), features.shape[0], _capi.ptr(image), _capi.ptr(nbr),
+            nbr.stride(0), int(num_out), _capi.ptr(num_out_dev), int(kernel_volume), int(cin), int(cout), _capi.ptr(out),
+            out.stride(0), _capi.ptr(bias), _capi.ptr(bn_scale), _capi.ptr(bn_shift), _capi.ptr(residual),
+            residual.stride(0) if residual is not None else 0, int(bool(relu)), int(variant),
+            _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_conv_forward_tiled")
+    return out
+
+
+def _pad_channels(features, pitch):
+    if features.shape[1] == pitch:
+        return features
+    return torch.nn.functional.pad(features, (0, pitch - features.shape[1]))
+
+
 def sparse_conv(features, filters, nbr, num_out, bias=None, bn_scale=None, bn_shift=None, residual=None, relu=False,
                 prepared=None, transpose_io=False):
     """out[o] = epilogue(sum_k features[nbr[k, o]] @ W[k]) — one fused launch.  filters [kx,ky,kz,Cin,Cout]."""
@@ -195,6 +265,16 @@ def sparse_conv(features, filters, nbr, num_out, bias=None, bn_scale=None, bn_sh
     K = nbr.shape[0]
     if features.shape[1] != cin:
         raise RuntimeError(f"features have {features.shape[1]} channels, filters expect {cin}")
+    if prepared is None and tiled_supported(features.dtype, cin, cout):
+        # 16-bit features: tiled MFMA kernels (rows padded to the pitch they read)
+        image = make_filter_image(filters, transpose_io)
+        feats = _pad_channels(features, padded_channels(cin))
+        if bias is not None:
+            bias = bias.to(features.dtype).contiguous()
+        if residual is not None:
+            residual = residual.to(features.dtype)
+        return sparse_conv_tiled(feats, image, nbr, num_out, K, cin, cout, bias=bias, bn_scale=bn_scale,
+                                 bn_shift=bn_shift, residual=residual, relu=relu)
     if prepared is None:
         prepared = prepare_filters(filters, transpose_io)
     out = torch.empty((num_out, cout), dtype=features.dtype, device=features.device)

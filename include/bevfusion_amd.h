@@ -177,13 +177,44 @@ int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* n
  *   out_cap / nbr_stride must be >= bevamd_spconv_max_outputs(...) unless the caller knows better.
  * num_out_dev [1] always receives the row count; num_out_host (optional) makes the call
  * synchronise and return it to the host.  transpose / dilation != 1 are not supported. */
-size_t bevamd_spconv_rulebook_workspace_bytes(int n, const int* ksize, const int* stride, int subm);
+size_t bevamd_spconv_rulebook_workspace_bytes(int n, int batch_size, const int* out_shape, int subm);
 int bevamd_spconv_max_outputs(int n, const int* ksize, const int* stride, int subm);
 int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, const int* in_shape,
                                  const int* out_shape, const int* ksize, const int* stride,
                                  const int* padding, const int* dilation, int subm, int* out_indices,
                                  int out_cap, int* nbr, int nbr_stride, int* num_out_dev,
                                  int* num_out_host, void* ws, size_t ws_bytes, void* stream);
+
+/* Sync-free building blocks of the same rulebook (what the inference path of SparseEncoder chains): every
+ * count may stay on the device — `n_cap` / `m_cap` bound the launches and buffers, `n_dev` / `m_dev`
+ * (optional device ints) hold the live counts.
+ *   hash index  : open-addressing table of a voxel set in ANY row order (bevamd_spconv_hash_index_bytes);
+ *   rank index  : (bitmap, popcount prefix) words of a voxel set whose rows are in ascending linear index
+ *                 — produced by bevamd_spconv_downsample for its outputs (bevamd_spconv_rank_index_bytes);
+ *   downsample  : active outputs of a strided convolution = getIndicePair's non-subm branch
+ *                 (spconv_ops.h:100-139 + torch::_unique), rows ascending, count in num_out_dev (clamped to out_cap);
+ *   neighbors   : nbr[k][o] through an index of the INPUT set (index_kind 0 = hash, 1 = rank;
+ *                 in_index_n_cap = the n_cap the hash index was built with). */
+size_t bevamd_spconv_hash_index_bytes(int n_cap);
+size_t bevamd_spconv_rank_index_bytes(int batch_size, const int* shape);
+int bevamd_spconv_hash_index_build(const int* indices, int n_cap, const int* n_dev, int batch_size,
+                                   const int* shape, void* index, size_t index_bytes, void* stream);
+int bevamd_spconv_downsample(const int* indices, int n_cap, const int* n_dev, int batch_size,
+                             const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
+                             const int* padding, int* out_indices, int out_cap, int* num_out_dev,
+                             void* out_index, size_t out_index_bytes, void* stream);
+int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
+                            const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
+                            const int* padding, int subm, int index_kind, const void* in_index,
+                            int in_index_n_cap, int* nbr, int nbr_stride, void* stream);
+
+/* Dense BEV tail of SparseEncoder.forward (models/backbones/sparse_encoder.py:126-131: SparseConvTensor.dense()
+ * structure.py:49-59 -> permute(0,1,4,2,3) -> view): out [batch, channels*Z, X, Y], same element size as features,
+ * out[b][c*Z+z][x][y] = features[row(b,x,y,z)][c], zeros elsewhere; every element is written once (no pre-zeroing).
+ * Rows are found through an index of the voxel set (kind 0 = hash, 1 = rank). shape: HOST int[3] = (X, Y, Z). */
+int bevamd_spconv_dense_bev(const void* features, int elem_bytes, int pitch, int channels, int index_kind,
+                            const void* index, int index_n_cap, int batch_size, const int* shape, void* out,
+                            void* stream);
 
 /* The reference's rulebook arrays (spconv_ops.h:56-59): indice_pairs [K, 2, pairs_len] int32 (-1
  * padded; [k][0] = input rows, [k][1] = output rows), indice_num [K].  Pairs of one offset are listed
@@ -216,6 +247,28 @@ int bevamd_spconv_conv_forward(const void* features, int dtype, const void* prep
                                int nbr_stride, int num_out, const int* num_out_dev, int kernel_volume,
                                int cin, int cout, void* out, const void* bias, const float* bn_scale,
                                const float* bn_shift, const void* residual, int relu, void* stream);
+
+/* Tiled forward for 16-bit features (dtype 1 = fp16, 2 = bf16; channels <= 128) — the kernel the modules
+ * use at inference.  Same operator as bevamd_spconv_conv_forward (sparse_conv_ext.indice_conv_half /
+ * fused_indice_conv_half, all.cc:28-37 -> spconv_ops.h:260-361), with
+ *   - `image`: the filter in MFMA-fragment order, made once per weight by bevamd_spconv_make_filter_image
+ *     (bevamd_spconv_filter_image_elems elements of the feature dtype);
+ *   - features [num_in, feat_stride]: the pitch must be a multiple of 8 elements and cover cin rounded up to
+ *     8 / 16 / 32 / 64 / 128, the padding channels zero;
+ *   - the epilogue y = relu?( bn_scale * (conv + bias) + bn_shift + residual ), every operand optional
+ *     (eval-mode BatchNorm1d folded to fp32 scale/shift, SparseBasicBlock's identity add, sparse_block.py:88-107);
+ *   - num_out_dev (optional, device int): actual row count, num_out then only bounds the launch;
+ *   - variant 0 = automatic; other values select a kernel for tuning (see spconv_tile_impl.h). */
+int bevamd_spconv_tiled_supported(int dtype, int cin, int cout);
+size_t bevamd_spconv_filter_image_elems(int kernel_volume, int cin, int cout, int transpose_io);
+int bevamd_spconv_make_filter_image(const void* filters, int dtype, int kernel_volume, int cin, int cout,
+                                    int transpose_io, void* image, void* stream);
+int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_stride, int num_in,
+                                     const void* image, const int* nbr, int nbr_stride, int num_out,
+                                     const int* num_out_dev, int kernel_volume, int cin, int cout, void* out,
+                                     int out_stride, const void* bias, const float* bn_scale,
+                                     const float* bn_shift, const void* residual, int residual_stride,
+                                     int relu, int variant, void* stream);
 
 /* Filter-gradient half of sparse_conv_ext.indice_conv_backward_{fp32,half} (spconv_ops.h:363-456):
  *   filter_grad[k] = sum over pairs of features[i]^T @ out_grad[o]   (fp32 accumulation).

@@ -1,0 +1,75 @@
+"""Child process of test_fused_encoder_is_graph_capturable: capture the fused sparse encoder into a HIP graph
+(`torch.cuda.graph`), replay it on new capacity-padded inputs, compare with eager execution.  Prints progress
+markers so that a hang can be located from the parent's captured stdout."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from bevfusion_amd.sparse_encoder import SparseEncoder  # noqa: E402
+
+
+def say(msg):
+    print(msg, flush=True)
+
+
+def coords(rng, B, shape, n):
+    idx = []
+    for b in range(B):
+        lin = rng.choice(int(np.prod(shape)), size=n, replace=False)
+        idx.append(np.concatenate([np.full((len(lin), 1), b), np.stack(np.unravel_index(lin, shape), 1)], 1))
+    ind = np.concatenate(idx).astype(np.int32)
+    rng.shuffle(ind, axis=0)
+    return ind
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B, shape, cap = 1, (40, 40, 41), 4000
+    torch.manual_seed(1)
+    enc = SparseEncoder(5, [40, 40, 41], order=["conv", "norm", "act"], output_channels=32,
+                        encoder_channels=[[16, 16, 32], [32, 32, 64], [64, 64, 64], [64, 64]],
+                        encoder_paddings=[[0, 0, 1], [0, 0, 1], [0, 0, [1, 1, 0]], [0, 0]], block_type="basicblock")
+    enc = enc.to(dev).half().eval()
+    xs = torch.zeros((cap, 5), device=dev)
+    cs = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    ns = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def load(seed, n):
+        rng = np.random.default_rng(seed)
+        cs[:n] = torch.from_numpy(coords(rng, B, shape, n)).to(dev)
+        xs[:n] = torch.from_numpy(rng.standard_normal((n, 5)).astype(np.float32)).to(dev)
+        ns.fill_(n)
+
+    load(1, 3000)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                enc(xs, cs, B, num_voxels=ns)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        say("warmup done")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = enc(xs, cs, B, num_voxels=ns)
+        say("captured")
+        for seed, n in [(2, 2500), (3, 3900), (4, 3000)]:
+            load(seed, n)
+            g.replay()
+            torch.cuda.synchronize()
+            say(f"replayed n={n}")
+            got = out.clone()
+            want = enc(xs[:n].clone(), cs[:n].clone(), B)
+            if not torch.equal(got, want):
+                say(f"MISMATCH n={n} max|d|={float((got.float() - want.float()).abs().max())}")
+                sys.exit(1)
+    say("GRAPH-OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,9 @@ def test_sparse_encoder_vs_oracle_substitution(dev, monkeypatch, dtype, tol):
     with torch.no_grad():
         got = enc(x, c, B)
     assert tuple(got.shape) == (B, 32 * 2, 5, 5)
+    # reference: the module-by-module path with the CPU oracle substituted for the native ops
+    # (`got` above ran the fused inference path for fp16, the module path for fp32)
+    enc.fused_inference = False
     monkeypatch.setattr(sops, "build_rulebook", _oracle_build)
     monkeypatch.setattr(Fsp, "rulebook_conv", _oracle_conv)
     with torch.no_grad():

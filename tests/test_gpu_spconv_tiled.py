@@ -1,0 +1,177 @@
+"""GPU parity of the tiled 16-bit sparse convolution (csrc/spconv_tile.h, through the C ABI) against the CPU oracle
+(oracle.indice_conv, float64 accumulate): every kernel variant, the flattened-reduction shapes (Cin 8/16), the
+epilogue (bias, folded BatchNorm, residual, ReLU), device-side row counts, padded pitches, ragged tile counts.
+
+Bar: |err| <= tol * (1 + max|ref|) with tol = 2e-3 (fp16) / 1.6e-2 (bf16) — one 16-bit rounding of the result;
+bit-reproducible run to run; variants agree bit-for-bit with each other (same summation order)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from bevfusion_amd import spconv
+from bevfusion_amd.spconv import ops as sops
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+RESIDENT = (121, 122, 141, 142)
+STREAM = (211, 212, 221, 222)
+
+
+def _indices(rng, B, shape, n):
+    idx = []
+    for b in range(B):
+        lin = rng.choice(int(np.prod(shape)), size=min(n, int(np.prod(shape))), replace=False)
+        idx.append(np.concatenate([np.full((len(lin), 1), b), np.stack(np.unravel_index(lin, shape), 1)], 1))
+    ind = np.concatenate(idx).astype(np.int32)
+    rng.shuffle(ind, axis=0)
+    return ind
+
+
+def _case(rng, dev, cin, cout, dtype, ks=(3, 3, 3), st=(1, 1, 1), pd=(1, 1, 1), subm=1, B=2, shape=(24, 20, 9), n=1200):
+    indices = _indices(rng, B, shape, n)
+    oi, opairs, onum, _ = oracle.get_indice_pairs(indices, B, shape, ks, st, pd, [1, 1, 1], subm, order="cuda")
+    w = (rng.standard_normal(tuple(ks) + (cin, cout)) / np.sqrt(cin * np.prod(ks) / 4)).astype(np.float32)
+    f = rng.standard_normal((indices.shape[0], cin)).astype(np.float32)
+    f = torch.from_numpy(f).to(dtype)
+    w = torch.from_numpy(w).to(dtype)
+    ref = oracle.indice_conv(f.float().numpy(), w.float().numpy(), opairs, onum, oi.shape[0])
+    rb = spconv.build_rulebook(torch.from_numpy(indices).to(dev), B, list(shape), list(ks), list(st), list(pd), 1, subm)
+    assert rb.num_out == oi.shape[0]
+    return f.to(dev), w.to(dev), rb, ref
+
+
+def _run(f, w, rb, variant=0, pitch=None, **kw):
+    cin, cout = w.shape[-2], w.shape[-1]
+    K = w.numel() // (cin * cout)
+    pitch = pitch or sops.padded_channels(cin)
+    fp = torch.nn.functional.pad(f, (0, pitch - cin))
+    img = sops.make_filter_image(w)
+    return sops.sparse_conv_tiled(fp, img, rb.nbr, rb.num_out, K, cin, cout, variant=variant, **kw)
+
+
+def _assert_close(out, ref, dtype):
+    err = np.max(np.abs(out.float().cpu().numpy().astype(np.float64) - ref))
+    scale = 1.0 + np.max(np.abs(ref))
+    assert err <= TOL[dtype] * scale, (err, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(5, 16), (8, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128),
+                                      (128, 128), (7, 9), (4, 48), (24, 100), (128, 16), (48, 64), (100, 40)])
+def test_auto_variant_vs_oracle(dev, cin, cout, dtype):
+    rng = np.random.default_rng(cin * 977 + cout)
+    for geo in [dict(), dict(ks=(3, 3, 3), st=(2, 2, 2), pd=(1, 1, 1), subm=0),
+                dict(ks=(1, 1, 3), st=(1, 1, 2), pd=(0, 0, 0), subm=0)]:
+        f, w, rb, ref = _case(rng, dev, cin, cout, dtype, **geo)
+        out = _run(f, w, rb)
+        assert out.dtype == dtype and tuple(out.shape) == ref.shape
+        _assert_close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("cin,cout,variants", [
+    (8, 16, RESIDENT + STREAM), (16, 16, RESIDENT + STREAM), (16, 32, RESIDENT + STREAM), (32, 32, RESIDENT + STREAM),
+    (32, 64, STREAM), (64, 64, STREAM), (64, 128, STREAM), (128, 128, STREAM), (128, 64, STREAM), (32, 16, RESIDENT + STREAM)])
+def test_every_variant_agrees_bit_for_bit(dev, cin, cout, variants):
+    rng = np.random.default_rng(cin + 7 * cout)
+    f, w, rb, ref = _case(rng, dev, cin, cout, torch.float16, n=2100)   # 4200 rows: ragged last tile
+    outs = [_run(f, w, rb, variant=v) for v in variants]
+    _assert_close(outs[0], ref, torch.float16)
+    for v, o in zip(variants[1:], outs[1:]):
+        assert torch.equal(o, outs[0]), f"variant {v} differs from {variants[0]}"
+    assert torch.equal(_run(f, w, rb, variant=variants[0]), outs[0])   # run-to-run reproducible
+
+
+def test_resident_variant_rejected_when_image_exceeds_lds(dev):
+    rng = np.random.default_rng(1)
+    f, w, rb, _ = _case(rng, dev, 64, 64, torch.float16, n=100)
+    with pytest.raises(RuntimeError, match="not built|LDS"):
+        _run(f, w, rb, variant=122)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64), (128, 128), (16, 20)])
+def test_epilogue_bias_bn_residual_relu(dev, cin, cout, dtype):
+    rng = np.random.default_rng(cout)
+    f, w, rb, ref = _case(rng, dev, cin, cout, dtype)
+    m = rb.num_out
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dtype)
+    scale = torch.from_numpy((0.5 + rng.random(cout)).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((m, cout)).astype(np.float32)).to(dtype)
+    want = (ref + bias.float().numpy()) * scale.numpy() + shift.numpy() + res.float().numpy()
+    out = _run(f, w, rb, bias=bias.to(dev), bn_scale=scale.to(dev), bn_shift=shift.to(dev), residual=res.to(dev), relu=True)
+    err = np.max(np.abs(out.float().cpu().numpy() - np.maximum(want, 0)))
+    assert err <= 4 * TOL[dtype] * (1 + np.max(np.abs(want))), err          # four rounding points
+    assert float(out.float().min()) >= 0.0
+    # each operand alone
+    out = _run(f, w, rb, bn_scale=scale.to(dev), bn_shift=shift.to(dev))
+    _assert_close(out, ref * scale.numpy() + shift.numpy(), dtype)
+    out = _run(f, w, rb, residual=res.to(dev))
+    _assert_close(out, ref + res.float().numpy(), dtype)
+    out = _run(f, w, rb, relu=True)
+    _assert_close(out, np.maximum(ref, 0), dtype)
+
+
+@pytest.mark.parametrize("variant", [0, 122, 221])
+def test_device_row_count_and_capacity_launch(dev, variant):
+    """Launch sized by a capacity far above the live row count; rows past the live count stay untouched."""
+    rng = np.random.default_rng(5)
+    f, w, rb, ref = _case(rng, dev, 32, 32, torch.float16, n=700)
+    m, cap = rb.num_out, 50000
+    nbr = torch.full((27, cap), 12345678, dtype=torch.int32, device=dev)      # garbage beyond the live rows
+    nbr[:, :m] = rb.nbr[:, :m]
+    out = torch.full((cap, 32), 7.0, dtype=torch.float16, device=dev)
+    m_dev = torch.tensor([m], dtype=torch.int32, device=dev)
+    img = sops.make_filter_image(w)
+    sops.sparse_conv_tiled(f, img, nbr, cap, 27, 32, 32, num_out_dev=m_dev, out=out, variant=variant)
+    _assert_close(out[:m], ref, torch.float16)
+    assert bool((out[m:] == 7.0).all())
+    # a live count above the capacity is clamped to the capacity
+    out2 = torch.full((m, 32), 7.0, dtype=torch.float16, device=dev)
+    big = torch.tensor([10 * cap], dtype=torch.int32, device=dev)
+    sops.sparse_conv_tiled(f, img, rb.nbr, m, 27, 32, 32, num_out_dev=big, out=out2, variant=variant)
+    _assert_close(out2, ref, torch.float16)
+
+
+def test_wide_pitch_and_strided_output(dev):
+    rng = np.random.default_rng(6)
+    f, w, rb, ref = _case(rng, dev, 16, 16, torch.float16)
+    out = _run(f, w, rb, pitch=40)                                   # pitch > padded channels, still zero padded
+    _assert_close(out, ref, torch.float16)
+    wide = torch.zeros((rb.num_out, 48), dtype=torch.float16, device=dev)
+    _run(f, w, rb, out=wide[:, 16:32])                               # write into a column slice (pitch 48)
+    _assert_close(wide[:, 16:32], ref, torch.float16)
+    assert float(wide[:, :16].abs().max()) == 0 and float(wide[:, 32:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 129])
+def test_tiny_row_counts(dev, n):
+    rng = np.random.default_rng(n)
+    for cin, cout in [(16, 16), (64, 64)]:
+        f, w, rb, ref = _case(rng, dev, cin, cout, torch.float16, B=1, shape=(6, 6, 6), n=n)
+        _assert_close(_run(f, w, rb), ref, torch.float16)
+
+
+def test_one_hot_asymmetric_catches_layout_swaps(dev):
+    """One-hot rows x an asymmetric filter: any row/column or offset mix-up in the image or the fragments shows."""
+    rng = np.random.default_rng(3)
+    B, shape, cin, cout = 1, (12, 12, 6), 16, 32
+    indices = _indices(rng, B, shape, 400)
+    rb = spconv.build_rulebook(torch.from_numpy(indices).to(dev), B, list(shape), 3, 1, 1, 1, True)
+    f = torch.zeros(indices.shape[0], cin, device=dev, dtype=torch.float16)
+    f[torch.arange(indices.shape[0]), torch.arange(indices.shape[0]) % cin] = 1.0
+    w = (torch.arange(27 * cin * cout, device=dev, dtype=torch.float32).view(3, 3, 3, cin, cout) % 509 / 64.0).half()
+    out = _run(f, w, rb)
+    _, opairs, onum, _ = oracle.get_indice_pairs(indices, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1)
+    ref = oracle.indice_conv(f.float().cpu().numpy(), w.float().cpu().numpy(), opairs, onum, indices.shape[0])
+    _assert_close(out, ref, torch.float16)
+
+
+def test_rejects_bad_pitch(dev):
+    f = torch.zeros((10, 5), dtype=torch.float16, device=dev)
+    w = torch.zeros((3, 3, 3, 5, 16), dtype=torch.float16, device=dev)
+    img = sops.make_filter_image(w)
+    nbr = torch.full((27, 10), -1, dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="pitch"):
+        sops.sparse_conv_tiled(f, img, nbr, 10, 27, 5, 16)

@@ -1,0 +1,93 @@
+"""Time every tiled sparse-conv variant on the SparseEncoder's layer shapes (synthetic flagship frame).
+    python tools/sweep_spconv.py [--dtype fp16|bf16]   -> table on stdout (copy into profiles/)"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from bevfusion_amd import synth  # noqa: E402
+from bevfusion_amd.spconv import ops as sops  # noqa: E402
+from bevfusion_amd.voxel import voxelize_batch  # noqa: E402
+
+RES = (121, 122, 141, 142)
+STR = (211, 212, 221, 222)
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        e.synchronize()
+        ts.append(s.elapsed_time(e) * 1e3)
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="fp16")
+    args = ap.parse_args()
+    dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    dev = torch.device("cuda", 0)
+    cfg = synth.CL_CONFIG
+    pts = torch.from_numpy(synth.lidar_points(seed=0)).to(dev)
+    vf, vc, _ = voxelize_batch([pts], cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][1])
+    shape = list(cfg["sparse_shape"])
+    ind = vc.int().contiguous()
+    layers = []   # (name, rulebook, n_in, cin, cout)
+    stages = [(16, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (32, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+              (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 0)), (128, 128, (1, 1, 3), (1, 1, 2), (0, 0, 0))]
+    c = 16
+    rb = sops.build_rulebook(ind, 1, shape, 3, 1, 1, 1, True)
+    layers.append(("subm1 5(8)->16", rb, ind.shape[0], 8, 16))
+    for i, (cin, cout, ks, st, pd) in enumerate(stages):
+        layers.append((f"subm{i + 1} {cin}->{cin}", rb, ind.shape[0], cin, cin))
+        rbs = sops.build_rulebook(ind, 1, shape, list(ks), list(st), list(pd), 1, False)
+        layers.append((f"spconv{i + 1} {cin}->{cout} k{ks} s{st}", rbs, ind.shape[0], cin, cout))
+        ind, shape = rbs.out_indices.contiguous(), rbs.out_spatial_shape
+        if i < 3:
+            rb = sops.build_rulebook(ind, 1, shape, 3, 1, 1, 1, True)
+    print(f"# tiled sparse conv sweep, dtype={args.dtype}; time = median us over 20 launches (min in brackets)")
+    for name, rb, n_in, cin, cout in layers:
+        K = rb.nbr.shape[0]
+        f = torch.randn(n_in, cin, device=dev).to(dt)
+        w = (torch.randn(K, cin, cout, device=dev) / (K * cin) ** 0.5).to(dt)
+        img = sops.make_filter_image(w.view(K, 1, 1, cin, cout))
+        pairs = int((rb.nbr[:, :rb.num_out] >= 0).sum())
+        gflop = 2.0 * pairs * cin * cout / 1e9
+        print(f"{name:38s} rows_in={n_in:7d} rows_out={rb.num_out:7d} pairs={pairs:8d} ({gflop:6.2f} GFLOP)")
+        img_bytes = img.numel() * 2
+        for v in (0,) + RES + STR:
+            if v in RES and (img_bytes > 65536 or cin > 32 or cout > 32):
+                continue
+            try:
+                med, mn = timeit(lambda: sops.sparse_conv_tiled(f, img, rb.nbr, rb.num_out, K, cin, cout, variant=v))
+            except RuntimeError as e:
+                print(f"    variant {v:3d}: {str(e)[:80]}")
+                continue
+            print(f"    variant {v:3d}: {med:8.1f} us ({mn:8.1f})  {gflop / med * 1e3:8.1f} TFLOP/s eff")
+        # old kernel for comparison
+        from bevfusion_amd import _capi
+        prep = sops.prepare_filters(w.view(K, 1, 1, cin, cout))
+        lib = _capi.load()
+        out = torch.empty(rb.num_out, cout, dtype=dt, device=dev)
+
+        def old():
+            lib.bevamd_spconv_conv_forward(_capi.ptr(f), 1 if dt == torch.float16 else 2, _capi.ptr(prep), _capi.ptr(rb.nbr),
+                                           rb.nbr.shape[1], rb.num_out, None, K, cin, cout, _capi.ptr(out), None, None, None,
+                                           None, 0, _capi.stream_ptr(dev))
+        med, mn = timeit(old)
+        print(f"    r0 wave-kernel: {med:8.1f} us ({mn:8.1f})")
+
+
+if __name__ == "__main__":
+    main()
