@@ -40,7 +40,7 @@ _SIGNATURES = {
     "bevamd_spconv_hash_index_bytes": (Z, [I]),
     "bevamd_spconv_rank_index_bytes": (Z, [I, P]),
     "bevamd_spconv_hash_index_build": (I, [P, I, P, I, P, P, Z, P]),
-    "bevamd_spconv_downsample": (I, [P, I, P, I, P, P, P, P, P, P, I, P, P, Z, P]),
+    "bevamd_spconv_downsample": (I, [P, I, P, I, P, P, P, P, P, P, I, P, P, Z, P, I, P]),
     "bevamd_spconv_neighbors": (I, [P, I, P, I, P, P, P, P, P, I, I, P, I, P, I, P]),
     "bevamd_spconv_max_outputs": (I, [I, P, P, I]),
     "bevamd_spconv_build_rulebook": (I, [P, I, I, P, P, P, P, P, P, I, P, I, P, I, P, P, P, Z, P]),

@@ -108,59 +108,119 @@ __device__ __forceinline__ int index_lookup(const IndexRef& ix, uint32_t key) {
 }
 
 // nbr[k][o] for o in [0, m): input row at out*stride - pad + k.  `m_dev` (optional) bounds the rows when
-// the count lives on the device.
+// the count lives on the device; the grid is fixed-size and strides over the rows, so a launch sized for a
+// large capacity does not pay for empty workgroups.
 template <int KIND>
 __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out_indices, int m_cap,
                                                      const int* __restrict__ m_dev, ConvGeom g, IndexRef ix,
                                                      int* __restrict__ nbr, int nbr_stride) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
-  if (o >= m) return;
-  const int4 c = ((const int4*)out_indices)[o];
   const int kz = k % g.ksize[2];
   const int ky = (k / g.ksize[2]) % g.ksize[1];
   const int kx = k / (g.ksize[2] * g.ksize[1]);
-  const int ix_ = c.y * g.stride[0] - g.pad[0] + kx;
-  const int iy = c.z * g.stride[1] - g.pad[1] + ky;
-  const int iz = c.w * g.stride[2] - g.pad[2] + kz;
-  int r = -1;
-  if (ix_ >= 0 && ix_ < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && iz >= 0 && iz < g.in_shape[2]) {
-    uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
-    r = index_lookup<KIND>(ix, key);
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) {
+    const int4 c = ((const int4*)out_indices)[o];
+    const int ix_ = c.y * g.stride[0] - g.pad[0] + kx;
+    const int iy = c.z * g.stride[1] - g.pad[1] + ky;
+    const int iz = c.w * g.stride[2] - g.pad[2] + kz;
+    int r = -1;
+    if (ix_ >= 0 && ix_ < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && iz >= 0 && iz < g.in_shape[2]) {
+      uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
+      r = index_lookup<KIND>(ix, key);
+    }
+    nbr[(size_t)k * nbr_stride + o] = r;
   }
-  nbr[(size_t)k * nbr_stride + o] = r;
 }
 
-// strided conv, pass 1: input j sets the bit of every output cell it touches
+// Strided convolution, neighbour table from the INPUT side: each input row knows the <= prod(ceil(k/s))
+// (output cell, offset) pairs it feeds; the output row is the rank of that cell.  ~10x fewer lookups than
+// probing all K offsets of every output row (most of which have no input).  nbr must be pre-filled with -1.
+__global__ __launch_bounds__(256) void sp_nbr_from_inputs_kernel(const int* __restrict__ indices, int n_cap,
+                                                                 const int* __restrict__ n_dev, ConvGeom g,
+                                                                 const uint2* __restrict__ out_words, int m_cap,
+                                                                 int* __restrict__ nbr, int nbr_stride) {
+  int n = n_dev ? *n_dev : n_cap;
+  if (n > n_cap) n = n_cap;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    const int4 c = ((const int4*)indices)[j];
+    for (int kx = 0; kx < g.ksize[0]; ++kx) {
+      int tx = c.y + g.pad[0] - kx;
+      if (tx < 0 || tx % g.stride[0]) continue;
+      int ox = tx / g.stride[0];
+      if (ox >= g.out_shape[0]) continue;
+      for (int ky = 0; ky < g.ksize[1]; ++ky) {
+        int ty = c.z + g.pad[1] - ky;
+        if (ty < 0 || ty % g.stride[1]) continue;
+        int oy = ty / g.stride[1];
+        if (oy >= g.out_shape[1]) continue;
+        for (int kz = 0; kz < g.ksize[2]; ++kz) {
+          int tz = c.w + g.pad[2] - kz;
+          if (tz < 0 || tz % g.stride[2]) continue;
+          int oz = tz / g.stride[2];
+          if (oz >= g.out_shape[2]) continue;
+          uint32_t key = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
+          const int row = rank_lookup(out_words, key);
+          if (row >= 0 && row < m_cap) nbr[(size_t)((kx * g.ksize[1] + ky) * g.ksize[2] + kz) * nbr_stride + row] = j;
+        }
+      }
+    }
+  }
+}
+
+// nbr[k][0..m) = -1 for every offset (rows bounded by the device count)
+__global__ __launch_bounds__(256) void sp_nbr_clear_kernel(int* __restrict__ nbr, int nbr_stride, int m_cap,
+                                                           const int* __restrict__ m_dev) {
+  int m = m_dev ? *m_dev : m_cap;
+  if (m > m_cap) m = m_cap;
+  int* row = nbr + (size_t)blockIdx.y * nbr_stride;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) row[o] = -1;
+}
+
+// strided conv, pass 1: input j sets the bit of every output cell it touches.  Device-scope atomics leave the
+// XCD (L2s are not coherent with each other), so they are the cost here: candidate cells of one (ox, oy) are
+// consecutive in z and are OR-ed into one mask per bitmap word first, and a word that already shows the bits
+// (a plain read, possibly stale -> only ever conservative) is skipped.
+__device__ __forceinline__ void mark_flush(uint2* __restrict__ words, uint32_t w, uint32_t mask) {
+  if (!mask) return;
+  uint32_t* wp = &words[w].x;
+  if ((__builtin_nontemporal_load(wp) & mask) != mask) atomicOr(wp, mask);
+}
+
 __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restrict__ indices, int n_cap,
                                                               const int* __restrict__ n_dev, ConvGeom g,
                                                               uint2* __restrict__ words) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
   int n = n_dev ? *n_dev : n_cap;
   if (n > n_cap) n = n_cap;
-  if (j >= n) return;
-  const int4 c = ((const int4*)indices)[j];
-  for (int kx = 0; kx < g.ksize[0]; ++kx) {
-    int tx = c.y + g.pad[0] - kx;
-    if (tx < 0 || tx % g.stride[0]) continue;
-    int ox = tx / g.stride[0];
-    if (ox >= g.out_shape[0]) continue;
-    for (int ky = 0; ky < g.ksize[1]; ++ky) {
-      int ty = c.z + g.pad[1] - ky;
-      if (ty < 0 || ty % g.stride[1]) continue;
-      int oy = ty / g.stride[1];
-      if (oy >= g.out_shape[1]) continue;
-      for (int kz = 0; kz < g.ksize[2]; ++kz) {
-        int tz = c.w + g.pad[2] - kz;
-        if (tz < 0 || tz % g.stride[2]) continue;
-        int oz = tz / g.stride[2];
-        if (oz >= g.out_shape[2]) continue;
-        uint32_t key = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
-        const uint32_t bit = 1u << (key & 31);
-        uint32_t* wp = &words[key >> 5].x;
-        if (!(__builtin_nontemporal_load(wp) & bit)) atomicOr(wp, bit);   // most cells are hit by several inputs
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    const int4 c = ((const int4*)indices)[j];
+    for (int kx = 0; kx < g.ksize[0]; ++kx) {
+      int tx = c.y + g.pad[0] - kx;
+      if (tx < 0 || tx % g.stride[0]) continue;
+      int ox = tx / g.stride[0];
+      if (ox >= g.out_shape[0]) continue;
+      for (int ky = 0; ky < g.ksize[1]; ++ky) {
+        int ty = c.z + g.pad[1] - ky;
+        if (ty < 0 || ty % g.stride[1]) continue;
+        int oy = ty / g.stride[1];
+        if (oy >= g.out_shape[1]) continue;
+        uint32_t cur_w = 0xFFFFFFFFu, cur_mask = 0u;
+        for (int kz = 0; kz < g.ksize[2]; ++kz) {
+          int tz = c.w + g.pad[2] - kz;
+          if (tz < 0 || tz % g.stride[2]) continue;
+          int oz = tz / g.stride[2];
+          if (oz >= g.out_shape[2]) continue;
+          uint32_t key = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
+          const uint32_t w = key >> 5;
+          if (w != cur_w) {
+            mark_flush(words, cur_w, cur_mask);
+            cur_w = w;
+            cur_mask = 0u;
+          }
+          cur_mask |= 1u << (key & 31);
+        }
+        mark_flush(words, cur_w, cur_mask);
       }
     }
   }
@@ -200,10 +260,10 @@ __global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint2* __r
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
 }
 
-// prefix of every word + the coordinates of every active output, in ascending linear index
-__global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restrict__ words, size_t nwords,
-                                                                 const uint32_t* __restrict__ tile_scan, ConvGeom g,
-                                                                 int* __restrict__ out_indices, int out_cap) {
+// exclusive popcount prefix of every bitmap word; workgroup 0 also clamps the total to the row capacity
+__global__ __launch_bounds__(256) void sp_rank_apply_kernel(uint2* __restrict__ words, size_t nwords,
+                                                            const uint32_t* __restrict__ tile_scan, int* count,
+                                                            int out_cap) {
   __shared__ unsigned lds_wave[4];
   constexpr int PER = RANK_TILE / 256;  // consecutive words per thread
   const size_t w0 = (size_t)blockIdx.x * RANK_TILE + (size_t)threadIdx.x * PER;
@@ -218,14 +278,24 @@ __global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restri
   unsigned run = tile_scan[blockIdx.x] + block_exclusive_scan_256u(s, lds_wave, &tot);
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    if (w0 + i >= nwords) break;
-    words[w0 + i].y = run;
-    uint32_t b = bits[i];
+    if (w0 + i < nwords) words[w0 + i].y = run;
+    run += __popc(bits[i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && *count > out_cap) *count = out_cap;
+}
+
+// coordinates of every active output, in ascending linear index: one thread per bitmap word
+__global__ __launch_bounds__(256) void sp_rank_emit_kernel(const uint2* __restrict__ words, size_t nwords, ConvGeom g,
+                                                           int* __restrict__ out_indices, int out_cap) {
+  for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (size_t)gridDim.x * 256) {
+    const uint2 wd = words[w];
+    uint32_t b = wd.x;
+    unsigned run = wd.y;
     while (b) {
       const int t = __ffs(b) - 1;
       b &= b - 1;
-      if (out_indices && run < (unsigned)out_cap) {
-        uint32_t k = (uint32_t)((w0 + i) * 32 + t);
+      if (run < (unsigned)out_cap) {
+        uint32_t k = (uint32_t)(w * 32 + t);
         int oz = (int)(k % (uint32_t)g.out_shape[2]); k /= (uint32_t)g.out_shape[2];
         int oy = (int)(k % (uint32_t)g.out_shape[1]); k /= (uint32_t)g.out_shape[1];
         int ox = (int)(k % (uint32_t)g.out_shape[0]); k /= (uint32_t)g.out_shape[0];
@@ -234,10 +304,6 @@ __global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restri
       ++run;
     }
   }
-}
-
-__global__ void sp_clamp_count_kernel(int* count, int cap) {
-  if (*count > cap) *count = cap;
 }
 
 // reference-shaped rulebook from nbr: per offset, compact (in,out) pairs ordered by out row
@@ -402,9 +468,15 @@ static IndexRef rank_ref(const void* index) {
   return r;
 }
 
-// active outputs of a strided convolution, ascending linear index, + their rank index
+static unsigned stride_grid(long long n) {  // fixed-size grid for grid-stride kernels
+  long long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+}
+
+// active outputs of a strided convolution, ascending linear index, + their rank index (+ optionally the
+// output-stationary neighbour table, generated from the input side)
 static int downsample(const int* indices, int n_cap, const int* n_dev, const ConvGeom& g, int* out_indices, int out_cap,
-                      int* num_out_dev, void* out_index, size_t bytes, hipStream_t stream) {
+                      int* num_out_dev, void* out_index, size_t bytes, int* nbr, int nbr_stride, hipStream_t stream) {
   const size_t need = rank_index_bytes(g.batch, g.out_shape);
   if (!out_index || bytes < need) {
     set_error("spconv rank index: buffer too small (%zu < %zu)", bytes, need);
@@ -418,24 +490,33 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
   int frc = fill_u32(words, align_up(nw * 8, 16), 0u, stream);  // the Carver keeps 256-byte slack behind `words`
   if (frc) return frc;
   if (n_cap > 0) {
-    sp_mark_outputs_kernel<<<dim3(cdiv(n_cap, 256)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words);
+    sp_mark_outputs_kernel<<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words);
     BEVAMD_LAUNCH_CHECK("sp_mark_outputs");
   }
   sp_rank_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums);
   BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
   int rc = exclusive_scan_u32(tile_sums, tile_sums, nt, (uint32_t*)num_out_dev, sws, bytes - cv.off, stream);
   if (rc) return rc;
-  sp_rank_apply_emit_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, g, out_indices, out_cap);
-  BEVAMD_LAUNCH_CHECK("sp_rank_apply_emit");
-  sp_clamp_count_kernel<<<1, 1, 0, stream>>>(num_out_dev, out_cap);
-  BEVAMD_LAUNCH_CHECK("sp_clamp_count");
+  sp_rank_apply_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, out_cap);
+  BEVAMD_LAUNCH_CHECK("sp_rank_apply");
+  sp_rank_emit_kernel<<<dim3(stride_grid((long long)nw)), dim3(256), 0, stream>>>(words, nw, g, out_indices, out_cap);
+  BEVAMD_LAUNCH_CHECK("sp_rank_emit");
+  if (nbr) {
+    sp_nbr_clear_kernel<<<dim3(stride_grid(out_cap), g.K), dim3(256), 0, stream>>>(nbr, nbr_stride, out_cap, num_out_dev);
+    BEVAMD_LAUNCH_CHECK("sp_nbr_clear");
+    if (n_cap > 0) {
+      sp_nbr_from_inputs_kernel<<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words, out_cap,
+                                                                                   nbr, nbr_stride);
+      BEVAMD_LAUNCH_CHECK("sp_nbr_from_inputs");
+    }
+  }
   return BEVAMD_OK;
 }
 
 static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const ConvGeom& g, int kind, const IndexRef& ix,
                      int* nbr, int nbr_stride, hipStream_t stream) {
   if (m_cap <= 0) return BEVAMD_OK;
-  dim3 grid(cdiv(m_cap, 256), g.K), block(256);
+  dim3 grid(stride_grid(m_cap), g.K), block(256);
   if (kind == INDEX_HASH) sp_nbr_kernel<INDEX_HASH><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
   else sp_nbr_kernel<INDEX_RANK><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
   BEVAMD_LAUNCH_CHECK("sp_nbr");
@@ -470,14 +551,15 @@ int bevamd_spconv_hash_index_build(const int* indices, int n_cap, const int* n_d
 int bevamd_spconv_downsample(const int* indices, int n_cap, const int* n_dev, int batch_size, const int* in_shape,
                              const int* out_shape, const int* ksize, const int* stride, const int* padding,
                              int* out_indices, int out_cap, int* num_out_dev, void* out_index, size_t out_index_bytes,
-                             void* stream_) {
+                             int* nbr, int nbr_stride, void* stream_) {
   ConvGeom g;
   int rc = make_geom(batch_size, in_shape, out_shape, ksize, stride, padding, nullptr, 0, g);
   if (rc) return rc;
   BEVAMD_REQUIRE(n_cap >= 0 && (indices || n_cap == 0), "spconv_downsample: bad input");
   BEVAMD_REQUIRE(num_out_dev && out_indices && out_cap >= 1, "spconv_downsample: null output / out_cap < 1");
-  return downsample(indices, n_cap, n_dev, g, out_indices, out_cap, num_out_dev, out_index, out_index_bytes,
-                    (hipStream_t)stream_);
+  BEVAMD_REQUIRE(!nbr || nbr_stride >= out_cap, "spconv_downsample: nbr_stride %d < out_cap %d", nbr_stride, out_cap);
+  return downsample(indices, n_cap, n_dev, g, out_indices, out_cap, num_out_dev, out_index, out_index_bytes, nbr,
+                    nbr_stride, (hipStream_t)stream_);
 }
 
 int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev, int batch_size, const int* in_shape,
@@ -563,13 +645,12 @@ int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, cons
     return BEVAMD_ERR_WORKSPACE;
   }
   const size_t hbytes = align_up((size_t)hash_capacity((size_t)n) * 8, 256);
-  rc = hash_build(indices, n, nullptr, g, ws, hbytes, stream);
-  if (rc) return rc;
-  const IndexRef ix = hash_ref(ws, n);
 
   if (subm) {
     BEVAMD_REQUIRE(nbr_stride >= n, "spconv_build_rulebook: nbr_stride %d < n %d", nbr_stride, n);
-    rc = neighbors(indices, n, nullptr, g, INDEX_HASH, ix, nbr, nbr_stride, stream);
+    rc = hash_build(indices, n, nullptr, g, ws, hbytes, stream);
+    if (rc) return rc;
+    rc = neighbors(indices, n, nullptr, g, INDEX_HASH, hash_ref(ws, n), nbr, nbr_stride, stream);
     if (rc) return rc;
     if (out_indices && out_indices != indices)
       BEVAMD_HIP_CHECK(hipMemcpyAsync(out_indices, indices, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToDevice, stream));
@@ -580,13 +661,12 @@ int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, cons
   }
 
   BEVAMD_REQUIRE((long long)out_cap >= 1, "spconv_build_rulebook: out_cap must be >= 1");
-  rc = downsample(indices, n, nullptr, g, out_indices, out_cap, num_out_dev, (char*)ws + hbytes, ws_bytes - hbytes, stream);
-  if (rc) return rc;
   // rows are bounded by out_cap on the launch side and by *num_out_dev on the device side
   const long long most = (long long)n * conv_bound(g);
   const int m_cap = out_cap < most ? out_cap : (int)most;
   BEVAMD_REQUIRE(nbr_stride >= m_cap, "spconv_build_rulebook: nbr_stride %d < out_cap %d", nbr_stride, m_cap);
-  rc = neighbors(out_indices, m_cap, num_out_dev, g, INDEX_HASH, ix, nbr, nbr_stride, stream);
+  rc = downsample(indices, n, nullptr, g, out_indices, m_cap, num_out_dev, (char*)ws + hbytes, ws_bytes - hbytes, nbr,
+                  nbr_stride, stream);
   if (rc) return rc;
   if (num_out_host) {
     BEVAMD_HIP_CHECK(hipMemcpyAsync(num_out_host, num_out_dev, sizeof(int), hipMemcpyDeviceToHost, stream));

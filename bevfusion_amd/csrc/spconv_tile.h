@@ -76,26 +76,35 @@ struct Args {
 
 constexpr unsigned OOB = 0x80000000u;  // buffer offset that is always out of range (feature bytes < 2 GiB)
 
-// steps of the reduction: CINP >= 32 -> one kernel offset per step, CINP/32 chunks;
-//                         CINP <  32 -> 32/CINP kernel offsets per step, one chunk.
-template <int CINP> struct Steps {
-  static constexpr int CPO = CINP >= 32 ? CINP / 32 : 1;      // chunks per step
-  static constexpr int OPS = CINP >= 32 ? 1 : 32 / CINP;      // kernel offsets per step
-  __host__ __device__ static int nsteps(int K) { return (K + OPS - 1) / OPS; }
+// The reduction axis is the flattened (kernel offset, input channel) axis in 32-wide CHUNKS (chunk j covers
+// flat elements [32j, 32j+32); lane group g carries 8 of them, all of one offset).  A STEP multiplies CPO
+// consecutive chunks: the unit of software pipelining (and of LDS staging in the stream kernel).  More chunks
+// per step = more gathers in flight per wave and fewer barriers, at the price of registers.
+template <int CINP> struct Chunks {
+  static constexpr int CPB = CINP >= 32 ? CINP / 32 : 1;   // chunks per kernel offset (CINP >= 32)
+  static constexpr int OPC = CINP >= 32 ? 1 : 32 / CINP;   // kernel offsets per chunk (CINP < 32)
+  __host__ __device__ static int count(int K) { return CINP >= 32 ? K * CPB : (K + OPC - 1) / OPC; }
 };
+constexpr int IMAGE_CHUNK_PAD = 24;  // images are zero-padded to a multiple of this many chunks (every CPO divides it)
 
-// kernel offset and byte offset inside the feature row that lane group g reads in step s
-template <int CINP>
-__device__ __forceinline__ void lane_slot(int s, int g, int& k, unsigned& byte_off) {
-  if constexpr (CINP >= 32) {
-    k = s;
-    byte_off = (unsigned)g * 16u;
-  } else {
-    constexpr int OPS = 32 / CINP, GPO = 4 / OPS;  // lane groups per offset
-    k = s * OPS + g / GPO;
-    byte_off = (unsigned)(g % GPO) * 16u;
+// index slots: the distinct kernel offsets a lane touches in one step
+template <int CINP, int CPO> struct StepShape {
+  static_assert(CINP < 32 || CPO % (CINP / 32) == 0, "a step must hold whole kernel offsets");
+  static constexpr int CPB = Chunks<CINP>::CPB;
+  static constexpr int NK = CINP >= 32 ? CPO / CPB : CPO;
+  __host__ __device__ static int nsteps(int K) { return (Chunks<CINP>::count(K) + CPO - 1) / CPO; }
+  // kernel offset of index slot q of step s for lane group g
+  __device__ __forceinline__ static int offset_of(int s, int q, int g) {
+    if constexpr (CINP >= 32) return s * NK + q;
+    else return ((s * CPO + q) * 32 + g * 8) / CINP;
   }
-}
+  // index slot and byte offset inside the feature row of chunk cc of a step for lane group g
+  __device__ __forceinline__ static int slot_of(int cc) { return CINP >= 32 ? cc / CPB : cc; }
+  __device__ __forceinline__ static unsigned byte_of(int cc, int g) {
+    if constexpr (CINP >= 32) return (unsigned)((cc % CPB) * 64 + g * 16);
+    else return (unsigned)(((cc * 32 + g * 8) % CINP) * 2);   // (s*CPO*32) % CINP == 0 whenever it matters: 32 % CINP == 0
+  }
+};
 
 // 4 consecutive output channels [col0, col0+4) of one row.  Rounding points follow the unfused reference
 // pipeline (the conv result, the bias add, BatchNorm and the residual add are each a stored 16-bit tensor).
@@ -148,21 +157,29 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int row, int col0,
 // (A/B): while set A multiplies, the rows of the next step land in set B and the indices of the step after
 // that are being fetched — no register copies, no conditional loads, so hipcc keeps counted vmcnt waits and
 // the prefetches stay in flight across the back-edge.
-template <int DT, int CINP, int NT, int MT>
+template <int DT, int CINP, int NT, int MT, int CPO>
 struct WaveTile {
-  static constexpr int CPO = Steps<CINP>::CPO;
+  typedef StepShape<CINP, CPO> SS;
+  static constexpr int NK = SS::NK;
   f32x4 acc[MT][NT];
-  int row0, m, lane, c, g, nsteps;
+  // Two lane identities.  MFMA operand/result layout: lane = (c = lane & 15: row of the tile, g = lane >> 4: k-group).
+  // LOAD layout: lane = (lr = lane >> 2: row, lg = lane & 3: k-group), i.e. the four 16-byte pieces of one row sit in
+  // four ADJACENT lanes — the texture addresser then sees one contiguous 64-byte segment per lane quad instead of
+  // four unrelated rows (a random dwordx4 gather costs ~1 cycle per distinct segment: 64 -> 16 cycles per wave load).
+  // ds_bpermute moves the data from load layout to MFMA layout (source lane 4c + g) just before the multiply.
+  int row0, m, lane, c, g, lr, lg, perm_addr;
   unsigned row_bytes;
   __amdgpu_buffer_rsrc_t rs;
 
-  __device__ __forceinline__ void init(const Args& a, int row0_, int m_, int nsteps_) {
+  __device__ __forceinline__ void init(const Args& a, int row0_, int m_) {
     row0 = row0_;
     m = m_;
-    nsteps = nsteps_;
     lane = threadIdx.x & 63;
     c = lane & 15;
     g = lane >> 4;
+    lr = lane >> 2;
+    lg = lane & 3;
+    perm_addr = ((lane & 15) * 4 + (lane >> 4)) * 4;
     row_bytes = (unsigned)a.feat_stride * 2u;
     rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat, 0, (unsigned)a.n_in * row_bytes, 0x00020000);
 #pragma unroll
@@ -171,42 +188,57 @@ struct WaveTile {
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // raw neighbour indices of step s (address clamped into the table; validity is decided in gather())
-  __device__ __forceinline__ void load_nb(const Args& a, int s, int (&nb)[MT]) {
-    int k;
-    unsigned bo;
-    lane_slot<CINP>(s, g, k, bo);
-    const int kc = k < a.K ? k : a.K - 1;
+  __device__ __forceinline__ void load_nb(const Args& a, int s, int (&nb)[MT][NK]) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int row = row0 + mt * 16 + c;
-      const int rc = row < m ? row : m - 1;
-      nb[mt] = a.nbr[(size_t)kc * a.nbr_stride + rc];
+    for (int q = 0; q < NK; ++q) {
+      const int k = SS::offset_of(s, q, lg);
+      const int kc = k < a.K ? k : a.K - 1;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = row0 + mt * 16 + lr;
+        const int rc = row < m ? row : m - 1;
+        nb[mt][q] = a.nbr[(size_t)kc * a.nbr_stride + rc];
+      }
     }
   }
-  __device__ __forceinline__ void gather(const Args& a, int s, const int (&nb)[MT], u32x4 (&dst)[MT][CPO]) {
-    int k;
-    unsigned bo;
-    lane_slot<CINP>(s, g, k, bo);
-    // callers pass s < nsteps (clamped); k can still fall off the end inside the last step when CINP < 32
-    const bool ok = CINP >= 32 || k < a.K;
+  // callers pass a step that exists (clamped); offsets past K inside the last step gather zeros
+  __device__ __forceinline__ void gather(const Args& a, int s, const int (&nb)[MT][NK], u32x4 (&dst)[MT][CPO]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const bool valid = ok && nb[mt] >= 0 && row0 + mt * 16 + c < m;
-      const unsigned voff = valid ? (unsigned)nb[mt] * row_bytes + bo : OOB;
+      const bool live = row0 + mt * 16 + lr < m;
+      unsigned base[NK];
 #pragma unroll
-      for (int cc = 0; cc < CPO; ++cc) dst[mt][cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)cc * 64u, 0, 0);
+      for (int q = 0; q < NK; ++q) {
+        const bool valid = live && nb[mt][q] >= 0 && SS::offset_of(s, q, lg) < a.K;
+        base[q] = valid ? (unsigned)nb[mt][q] * row_bytes : OOB;
+      }
+#pragma unroll
+      for (int cc = 0; cc < CPO; ++cc)
+        dst[mt][cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, base[SS::slot_of(cc)] + SS::byte_of(cc, lg), 0, 0);
     }
   }
-  // multiply gathered rows by the step's filter fragments at `wl` (LDS)
+  __device__ __forceinline__ u32x4 to_mfma_layout(const u32x4& v) const {
+    u32x4 r;
+    r.x = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)v.x);
+    r.y = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)v.y);
+    r.z = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)v.z);
+    r.w = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)v.w);
+    return r;
+  }
+  // multiply gathered rows (load layout) by the step's filter fragments at `wl` (LDS)
   __device__ __forceinline__ void multiply(const u32x4* __restrict__ wl, const u32x4 (&x)[MT][CPO]) {
 #pragma unroll
-    for (int cc = 0; cc < CPO; ++cc)
+    for (int cc = 0; cc < CPO; ++cc) {
+      u32x4 xm[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xm[mt] = to_mfma_layout(x[mt][cc]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const u32x4 b = wl[(cc * NT + nt) * 64 + lane];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma<DT>(b, x[mt][cc], acc[mt][nt]);
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma<DT>(b, xm[mt], acc[mt][nt]);
       }
+    }
   }
   __device__ __forceinline__ void store(const Args& a) {
 #pragma unroll
@@ -220,13 +252,14 @@ struct WaveTile {
 };
 
 // ---- RESIDENT: whole filter image in LDS, persistent over row tiles -----------------------------------
-template <int DT, int CINP, int NT, int MT, int NW>
+template <int DT, int CINP, int NT, int MT, int NW, int CPO>
 __global__ __launch_bounds__(NW * 64) void spconv_resident_kernel(Args a) {
   extern __shared__ u32x4 lds[];
-  constexpr int CPO = Steps<CINP>::CPO;
+  typedef WaveTile<DT, CINP, NT, MT, CPO> WT;
+  constexpr int NK = WT::NK;
   constexpr int STEP = CPO * NT * 64;
-  const int nsteps = Steps<CINP>::nsteps(a.K);
-  const int total = nsteps * STEP;
+  const int nsteps = StepShape<CINP, CPO>::nsteps(a.K);
+  const int total = nsteps * STEP;  // <= the zero-padded image
   for (int i = threadIdx.x; i < total; i += NW * 64) lds[i] = ((const u32x4*)a.wimg)[i];
   __syncthreads();
   const int m = a.m_dev ? (*a.m_dev < a.m_cap ? *a.m_dev : a.m_cap) : a.m_cap;
@@ -238,9 +271,9 @@ __global__ __launch_bounds__(NW * 64) void spconv_resident_kernel(Args a) {
   const int tend = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
   const int w = threadIdx.x >> 6;
   for (int t = xcd * per + bix * NW + w; t < tend; t += nxb * NW) {
-    WaveTile<DT, CINP, NT, MT> wt;
-    wt.init(a, t * ROWS, m, nsteps);
-    int nbA[MT], nbB[MT];
+    WT wt;
+    wt.init(a, t * ROWS, m);
+    int nbA[MT][NK], nbB[MT][NK];
     u32x4 xA[MT][CPO], xB[MT][CPO];
     const int last = nsteps - 1;
     auto cl = [&](int st) { return st < last ? st : last; };  // clamped prefetches past the end are never multiplied
@@ -262,14 +295,15 @@ __global__ __launch_bounds__(NW * 64) void spconv_resident_kernel(Args a) {
 }
 
 // ---- STREAM: one step's filter fragments double-buffered in LDS ----------------------------------------
-template <int DT, int CINP, int NT, int MT, int NW>
+template <int DT, int CINP, int NT, int MT, int NW, int CPO>
 __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
   extern __shared__ u32x4 lds[];
-  constexpr int CPO = Steps<CINP>::CPO;
+  typedef WaveTile<DT, CINP, NT, MT, CPO> WT;
+  constexpr int NK = WT::NK;
   constexpr int STEP = CPO * NT * 64;                    // u32x4 per step
   constexpr int WPT = (STEP + NW * 64 - 1) / (NW * 64);  // staged u32x4 per thread
   constexpr bool EXACT = STEP % (NW * 64) == 0;
-  const int nsteps = Steps<CINP>::nsteps(a.K);
+  const int nsteps = StepShape<CINP, CPO>::nsteps(a.K);
   const int m = a.m_dev ? (*a.m_dev < a.m_cap ? *a.m_dev : a.m_cap) : a.m_cap;
   constexpr int BM = NW * 16 * MT;
   const int nblk = (m + BM - 1) / BM;
@@ -279,10 +313,10 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
   if (bix >= per || tb >= nblk) return;  // whole workgroup leaves together: no barrier is skipped
   const int w = threadIdx.x >> 6;
   const u32x4* wg = (const u32x4*)a.wimg;
-  WaveTile<DT, CINP, NT, MT> wt;
-  wt.init(a, tb * BM + w * 16 * MT, m, nsteps);
+  WT wt;
+  wt.init(a, tb * BM + w * 16 * MT, m);
   u32x4 wreg[WPT];
-  // filter fragments of step `st` (clamped) -> registers / registers -> LDS buffer `buf`
+  // filter fragments of step `sc` -> registers / registers -> LDS buffer `buf`
   auto fetch_w = [&](int sc) {
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
@@ -297,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
       if (EXACT || e < STEP) lds[buf * STEP + e] = wreg[i];
     }
   };
-  int nbA[MT], nbB[MT];
+  int nbA[MT][NK], nbB[MT][NK];
   u32x4 xA[MT][CPO], xB[MT][CPO];
   const int last = nsteps - 1;
   auto cl = [&](int st) { return st < last ? st : last; };
@@ -327,16 +361,16 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
 }
 
 // ---- filter image ---------------------------------------------------------------------------------------
-// filters [K][cin][cout] (reference layout [kx,ky,kz,cin,cout], conv.py:100) -> image [step][cc][nt][lane][8]:
-// element e of lane (c = lane&15, g = lane>>4) is W[k][ci + e][nt*16 + c] with (k, ci) the slot of lane group
-// g in (step, cc); zero outside K / cin / cout.  transpose_io swaps the roles of cin and cout (input gradient).
+// filters [K][cin][cout] (reference layout [kx,ky,kz,cin,cout], conv.py:100) -> image [chunk][nt][lane][8]:
+// element e of lane (c = lane&15, g = lane>>4) of chunk j is W[k][ci][nt*16 + c] with flat = 32j + 8g + e,
+// k = flat / CINP, ci = flat % CINP; zero outside K / cin / cout and in the padding chunks.
+// transpose_io swaps the roles of cin and cout (input gradient).
 template <int DT, int CINP>
 __global__ __launch_bounds__(256) void spconv_filter_image_kernel(const typename Num<DT>::T* __restrict__ w, int K,
-                                                                  int cin, int cout, int nt_count, int transpose_io,
+                                                                  int cin, int cout, int nt_count, int nchunks_padded,
+                                                                  int transpose_io,
                                                                   typename Num<DT>::T* __restrict__ img) {
-  constexpr int CPO = Steps<CINP>::CPO;
-  const int nsteps = Steps<CINP>::nsteps(K);
-  const size_t total = (size_t)nsteps * CPO * nt_count * 64 * 8;
+  const size_t total = (size_t)nchunks_padded * nt_count * 64 * 8;
   const int rows = transpose_io ? cin : cout;   // output channels of this pass
   const int cols = transpose_io ? cout : cin;   // reduction channels of this pass
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -344,19 +378,10 @@ __global__ __launch_bounds__(256) void spconv_filter_image_kernel(const typename
     const int lane = (int)((i >> 3) & 63);
     size_t t = i >> 9;
     const int nt = (int)(t % nt_count);
-    t /= nt_count;
-    const int cc = (int)(t % CPO);
-    const int s = (int)(t / CPO);
+    const long long j = (long long)(t / nt_count);
     const int c = lane & 15, g = lane >> 4;
-    int k, ci;
-    if (CINP >= 32) {
-      k = s;
-      ci = cc * 32 + g * 8 + e;
-    } else {
-      constexpr int OPS = 32 / (CINP >= 32 ? 32 : CINP), GPO = 4 / OPS;
-      k = s * OPS + g / GPO;
-      ci = (g % GPO) * 8 + e;
-    }
+    const long long flat = j * 32 + g * 8 + e;
+    const int k = (int)(flat / CINP), ci = (int)(flat % CINP);
     const int co = nt * 16 + c;
     typename Num<DT>::T v = Num<DT>::from_f32(0.f);
     if (k < K && ci < cols && co < rows) {
@@ -373,10 +398,11 @@ static inline int pad_nt(int cout) {
   int nt = (cout + 15) / 16;
   return nt <= 1 ? 1 : nt <= 2 ? 2 : nt <= 4 ? 4 : nt <= 8 ? 8 : 0;
 }
-static inline size_t image_elems(int K, int cinp, int nt) {
-  const int cpo = cinp >= 32 ? cinp / 32 : 1, ops = cinp >= 32 ? 1 : 32 / cinp;
-  return (size_t)((K + ops - 1) / ops) * cpo * nt * 64 * 8;
+static inline int image_chunks(int K, int cinp) {  // padded chunk count
+  const int n = cinp >= 32 ? K * (cinp / 32) : (K + 32 / cinp - 1) / (32 / cinp);
+  return (n + IMAGE_CHUNK_PAD - 1) / IMAGE_CHUNK_PAD * IMAGE_CHUNK_PAD;
 }
+static inline size_t image_elems(int K, int cinp, int nt) { return (size_t)image_chunks(K, cinp) * nt * 64 * 8; }
 
 // implemented once per dtype (spconv_tile_f16.hip / spconv_tile_bf16.hip)
 int launch_f16(const Args& a, int cinp, int nt, int variant, hipStream_t stream);
@@ -384,7 +410,8 @@ int launch_bf16(const Args& a, int cinp, int nt, int variant, hipStream_t stream
 int image_f16(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream);
 int image_bf16(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream);
 
-// variant encoding: 0 = auto; otherwise kind*100 + MT*10 + log2(NW)   (kind 1 = resident, 2 = stream)
+// variant encoding: 0 = auto; otherwise kind*1000 + MT*100 + (NW/4)*10 + SPS  (kind 1 = resident, 2 = stream;
+// SPS = kernel offsets per step for Cin >= 32, chunks per step below)
 template <int DT>
 int launch_impl(const Args& a, int cinp, int nt, int variant, hipStream_t stream);
 

@@ -5,10 +5,10 @@
 namespace bevamd {
 namespace tile {
 
-template <int DT, int CINP, int NT, int MT, int NW>
+template <int DT, int CINP, int NT, int MT, int NW, int SPS>
 static int run_resident(const Args& a, hipStream_t stream) {
-  constexpr int CPO = Steps<CINP>::CPO;
-  const size_t lds = (size_t)Steps<CINP>::nsteps(a.K) * CPO * NT * 1024;
+  constexpr int CPO = SPS * Chunks<CINP>::CPB;
+  const size_t lds = (size_t)StepShape<CINP, CPO>::nsteps(a.K) * CPO * NT * 1024;
   if (lds > 65536) {
     set_error("spconv tiled: resident variant needs %zu B of LDS (> 64 KiB)", lds);
     return BEVAMD_ERR_UNSUPPORTED;
@@ -21,42 +21,63 @@ static int run_resident(const Args& a, hipStream_t stream) {
   long long blocks = (ntiles + NW - 1) / NW;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
   blocks = (blocks + 7) / 8 * 8;
-  spconv_resident_kernel<DT, CINP, NT, MT, NW><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
+  spconv_resident_kernel<DT, CINP, NT, MT, NW, CPO><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
   BEVAMD_LAUNCH_CHECK("spconv_resident");
   return BEVAMD_OK;
 }
 
-template <int DT, int CINP, int NT, int MT, int NW>
+template <int DT, int CINP, int NT, int MT, int NW, int SPS>
 static int run_stream(const Args& a, hipStream_t stream) {
-  constexpr int CPO = Steps<CINP>::CPO;
+  constexpr int CPO = SPS * Chunks<CINP>::CPB;
   const size_t lds = (size_t)2 * CPO * NT * 1024;
   constexpr int BM = NW * 16 * MT;
   const long long nblk = ((long long)a.m_cap + BM - 1) / BM;
   const long long blocks = (nblk + 7) / 8 * 8;
-  spconv_stream_kernel<DT, CINP, NT, MT, NW><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
+  spconv_stream_kernel<DT, CINP, NT, MT, NW, CPO><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
   BEVAMD_LAUNCH_CHECK("spconv_stream");
   return BEVAMD_OK;
 }
 
+// which (MT, NW, SPS) combinations are built for a shape: bounded by registers (gathered sets 2*MT*CPO*4 VGPRs,
+// staged filter CPO*NT/NW*4, accumulators MT*NT*4) and by 64 KiB of LDS for the stream ring (2*CPO*NT KiB)
+template <int CINP, int NT, int MT, int NW, int SPS>
+constexpr bool stream_built() {
+  constexpr int CPO = SPS * Chunks<CINP>::CPB;
+  return 2 * CPO * NT <= 64 && 2 * MT * CPO * 4 + (CPO * NT + NW - 1) / NW * 4 + MT * NT * 4 <= 200;
+}
+template <int CINP, int NT, int MT, int SPS>
+constexpr bool resident_built() {
+  constexpr int CPO = SPS * Chunks<CINP>::CPB;
+  return CINP <= 32 && NT <= 2 && 2 * MT * CPO * 4 + MT * NT * 4 <= 160;
+}
+
 template <int DT, int CINP, int NT>
 static int run_shape(const Args& a, int variant, hipStream_t stream) {
-  constexpr bool RES_OK = CINP <= 32 && NT <= 2;  // shapes whose 27-offset image can fit 64 KiB of LDS
   if (variant == 0) {
-    const size_t img = image_elems(a.K, CINP, NT) * 2;
-    if (RES_OK && img <= 65536) variant = 122;
-    else variant = NT >= 8 ? 211 : 221;
+    const size_t img = (size_t)StepShape<CINP, Chunks<CINP>::CPB>::nsteps(a.K) * Chunks<CINP>::CPB * NT * 1024;  // unpadded image
+    if (resident_built<CINP, NT, 2, 1>() && img <= 65536) variant = 1221;
+    else variant = NT >= 8 ? 2121 : 2211;
   }
+#define BEVAMD_RES(MT, NW, SPS)                                                                       \
+  case 1000 + MT * 100 + (NW / 4) * 10 + SPS:                                                          \
+    if constexpr (resident_built<CINP, NT, MT, SPS>()) return run_resident<DT, CINP, NT, MT, NW, SPS>(a, stream); \
+    break
+#define BEVAMD_STR(MT, NW, SPS)                                                                       \
+  case 2000 + MT * 100 + (NW / 4) * 10 + SPS:                                                          \
+    if constexpr (stream_built<CINP, NT, MT, NW, SPS>()) return run_stream<DT, CINP, NT, MT, NW, SPS>(a, stream); \
+    break
   switch (variant) {
-    case 121: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 2, 4>(a, stream); break;
-    case 122: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 2, 8>(a, stream); break;
-    case 141: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 4, 4>(a, stream); break;
-    case 142: if constexpr (RES_OK) return run_resident<DT, CINP, NT, 4, 8>(a, stream); break;
-    case 211: return run_stream<DT, CINP, NT, 1, 4>(a, stream);
-    case 212: return run_stream<DT, CINP, NT, 1, 8>(a, stream);
-    case 221: return run_stream<DT, CINP, NT, 2, 4>(a, stream);
-    case 222: return run_stream<DT, CINP, NT, 2, 8>(a, stream);
+    BEVAMD_RES(2, 8, 1); BEVAMD_RES(2, 8, 2); BEVAMD_RES(2, 8, 3);
+    BEVAMD_RES(4, 8, 1); BEVAMD_RES(4, 8, 2);
+    BEVAMD_RES(2, 4, 1);
+    BEVAMD_STR(1, 4, 1); BEVAMD_STR(1, 4, 2); BEVAMD_STR(1, 4, 3);
+    BEVAMD_STR(1, 8, 1); BEVAMD_STR(1, 8, 2); BEVAMD_STR(1, 8, 3);
+    BEVAMD_STR(2, 4, 1); BEVAMD_STR(2, 4, 2); BEVAMD_STR(2, 4, 3);
+    BEVAMD_STR(2, 8, 1); BEVAMD_STR(2, 8, 2);
     default: break;
   }
+#undef BEVAMD_RES
+#undef BEVAMD_STR
   set_error("spconv tiled: variant %d is not built for cin_pad=%d, cout tiles=%d", variant, CINP, NT);
   return BEVAMD_ERR_UNSUPPORTED;
 }
@@ -99,8 +120,9 @@ int image_impl(const void* w, int K, int cin, int cout, int transpose_io, void* 
     return BEVAMD_ERR_UNSUPPORTED;
   }
   const size_t total = image_elems(K, cinp, nt);
+  const int nchunks = image_chunks(K, cinp);
   dim3 grid((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), block(256);
-#define BEVAMD_IMG(C) case C: spconv_filter_image_kernel<DT, C><<<grid, block, 0, stream>>>((const T*)w, K, cin, cout, nt, transpose_io, (T*)img); break
+#define BEVAMD_IMG(C) case C: spconv_filter_image_kernel<DT, C><<<grid, block, 0, stream>>>((const T*)w, K, cin, cout, nt, nchunks, transpose_io, (T*)img); break
   switch (cinp) {
     BEVAMD_IMG(8);
     BEVAMD_IMG(16);

@@ -104,17 +104,19 @@ class Level:
         cap = max(1, min(self.n_cap * bound, volume))
         out_indices = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         num_out = torch.empty(1, dtype=torch.int32, device=dev)
+        K = ksize[0] * ksize[1] * ksize[2]
+        nbr = torch.empty((K, cap), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             nbytes = lib.bevamd_spconv_rank_index_bytes(self.batch, _capi.ints(out_shape))
             index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             rc = lib.bevamd_spconv_downsample(_capi.ptr(self.indices), self.n_cap, _capi.ptr(self.n_dev), self.batch,
                                               _capi.ints(self.shape), _capi.ints(out_shape), _capi.ints(ksize),
                                               _capi.ints(stride), _capi.ints(padding), _capi.ptr(out_indices), cap,
-                                              _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.stream_ptr(dev))
+                                              _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.ptr(nbr), cap,
+                                              _capi.stream_ptr(dev))
         _capi.check(rc, "spconv_downsample")
         out = Level(out_indices, cap, num_out, self.batch, out_shape)
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
-        nbr = self._neighbors(out_indices, cap, num_out, out_shape, list(ksize), list(stride), list(padding), False)
         self._down[key] = (out, nbr)
         return out, nbr
 

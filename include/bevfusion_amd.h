@@ -193,6 +193,8 @@ int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, cons
  *                 — produced by bevamd_spconv_downsample for its outputs (bevamd_spconv_rank_index_bytes);
  *   downsample  : active outputs of a strided convolution = getIndicePair's non-subm branch
  *                 (spconv_ops.h:100-139 + torch::_unique), rows ascending, count in num_out_dev (clamped to out_cap);
+ *                 with nbr != NULL it also writes the convolution's neighbour table nbr[K][nbr_stride], generated
+ *                 from the input side (each input row scatters into the <= prod(ceil(k/s)) outputs it feeds);
  *   neighbors   : nbr[k][o] through an index of the INPUT set (index_kind 0 = hash, 1 = rank;
  *                 in_index_n_cap = the n_cap the hash index was built with). */
 size_t bevamd_spconv_hash_index_bytes(int n_cap);
@@ -202,7 +204,7 @@ int bevamd_spconv_hash_index_build(const int* indices, int n_cap, const int* n_d
 int bevamd_spconv_downsample(const int* indices, int n_cap, const int* n_dev, int batch_size,
                              const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
                              const int* padding, int* out_indices, int out_cap, int* num_out_dev,
-                             void* out_index, size_t out_index_bytes, void* stream);
+                             void* out_index, size_t out_index_bytes, int* nbr, int nbr_stride, void* stream);
 int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
                             const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
                             const int* padding, int subm, int index_kind, const void* in_index,

@@ -14,8 +14,8 @@ from bevfusion_amd.spconv import ops as sops
 
 pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
-RESIDENT = (121, 122, 141, 142)
-STREAM = (211, 212, 221, 222)
+RESIDENT = (1221, 1222, 1223, 1421, 1422, 1211)      # kind 1, MT, NW/4, offsets (chunks) per step
+STREAM = (2111, 2112, 2113, 2121, 2122, 2123, 2211, 2212, 2213, 2221, 2222)
 
 
 def _indices(rng, B, shape, n):
@@ -75,18 +75,25 @@ def test_auto_variant_vs_oracle(dev, cin, cout, dtype):
 def test_every_variant_agrees_bit_for_bit(dev, cin, cout, variants):
     rng = np.random.default_rng(cin + 7 * cout)
     f, w, rb, ref = _case(rng, dev, cin, cout, torch.float16, n=2100)   # 4200 rows: ragged last tile
-    outs = [_run(f, w, rb, variant=v) for v in variants]
-    _assert_close(outs[0], ref, torch.float16)
-    for v, o in zip(variants[1:], outs[1:]):
-        assert torch.equal(o, outs[0]), f"variant {v} differs from {variants[0]}"
-    assert torch.equal(_run(f, w, rb, variant=variants[0]), outs[0])   # run-to-run reproducible
+    outs = {}
+    for v in variants:
+        try:
+            outs[v] = _run(f, w, rb, variant=v)
+        except RuntimeError as e:                       # register/LDS budget: not every combination is built per shape
+            assert "not built" in str(e) or "LDS" in str(e), e
+    assert len(outs) >= 3, sorted(outs)
+    first = next(iter(outs))
+    _assert_close(outs[first], ref, torch.float16)
+    for v, o in outs.items():
+        assert torch.equal(o, outs[first]), f"variant {v} differs from {first}"
+    assert torch.equal(_run(f, w, rb, variant=first), outs[first])   # run-to-run reproducible
 
 
 def test_resident_variant_rejected_when_image_exceeds_lds(dev):
     rng = np.random.default_rng(1)
     f, w, rb, _ = _case(rng, dev, 64, 64, torch.float16, n=100)
     with pytest.raises(RuntimeError, match="not built|LDS"):
-        _run(f, w, rb, variant=122)
+        _run(f, w, rb, variant=1221)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -113,7 +120,7 @@ def test_epilogue_bias_bn_residual_relu(dev, cin, cout, dtype):
     _assert_close(out, np.maximum(ref, 0), dtype)
 
 
-@pytest.mark.parametrize("variant", [0, 122, 221])
+@pytest.mark.parametrize("variant", [0, 1221, 1422, 2211, 2123])
 def test_device_row_count_and_capacity_launch(dev, variant):
     """Launch sized by a capacity far above the live row count; rows past the live count stay untouched."""
     rng = np.random.default_rng(5)
