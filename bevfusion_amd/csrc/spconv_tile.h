@@ -168,12 +168,14 @@ struct WaveTile {
   // four unrelated rows (a random dwordx4 gather costs ~1 cycle per distinct segment: 64 -> 16 cycles per wave load).
   // ds_bpermute moves the data from load layout to MFMA layout (source lane 4c + g) just before the multiply.
   int row0, m, lane, c, g, lr, lg, perm_addr;
+  int* nbl;  // wave-private LDS copy of the tile's neighbour table: [K][16*MT]
   unsigned row_bytes;
   __amdgpu_buffer_rsrc_t rs;
 
-  __device__ __forceinline__ void init(const Args& a, int row0_, int m_) {
+  __device__ __forceinline__ void init(const Args& a, int row0_, int m_, int* nbl_) {
     row0 = row0_;
     m = m_;
+    nbl = nbl_;
     lane = threadIdx.x & 63;
     c = lane & 15;
     g = lane >> 4;
@@ -187,18 +189,38 @@ struct WaveTile {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // raw neighbour indices of step s (address clamped into the table; validity is decided in gather())
+  // The tile's whole neighbour table -> LDS in one burst.  The table is streamed exactly once (every access is a cold
+  // miss served by HBM / Infinity Cache, ~2-4k cycles), so fetching it step by step put one such latency on every
+  // step of every wave — the time of all layers was set by that chain, whatever the tiling.  Here all K*16*MT
+  // loads of a tile are independent and in flight together: one latency per tile.
+  __device__ __forceinline__ void preload_nb(const Args& a) {
+    constexpr int R = 16 * MT, UNR = 8;
+    const int total = a.K * R;
+    for (int base = 0; base < total; base += 64 * UNR) {
+      int v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        int idx = base + u * 64 + lane;
+        idx = idx < total ? idx : total - 1;
+        const int k = idx / R, r = idx - k * R;
+        const int row = row0 + r;
+        v[u] = a.nbr[(size_t)k * a.nbr_stride + (row < m ? row : m - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int idx = base + u * 64 + lane;
+        if (idx < total) nbl[idx] = v[u];
+      }
+    }
+  }
+  // neighbour indices of step s for this lane's load slot (validity is decided in gather())
   __device__ __forceinline__ void load_nb(const Args& a, int s, int (&nb)[MT][NK]) {
 #pragma unroll
     for (int q = 0; q < NK; ++q) {
       const int k = SS::offset_of(s, q, lg);
       const int kc = k < a.K ? k : a.K - 1;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int row = row0 + mt * 16 + lr;
-        const int rc = row < m ? row : m - 1;
-        nb[mt][q] = a.nbr[(size_t)kc * a.nbr_stride + rc];
-      }
+      for (int mt = 0; mt < MT; ++mt) nb[mt][q] = nbl[kc * (16 * MT) + mt * 16 + lr];
     }
   }
   // callers pass a step that exists (clamped); offsets past K inside the last step gather zeros
@@ -225,18 +247,38 @@ struct WaveTile {
     r.w = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)v.w);
     return r;
   }
-  // multiply gathered rows (load layout) by the step's filter fragments at `wl` (LDS)
+  // multiply gathered rows (load layout) by the step's filter fragments at `wl` (LDS).
+  // LDS latency (~100+ cycles per ds_read_b128 / ds_bpermute) is the hazard here: with one fragment read in
+  // flight per MFMA the wave idles on lgkmcnt for most of a step (measured: MFMA busy 19 %, 58 % of wave cycles in
+  // s_waitcnt).  So the NT filter fragments and the MT permuted row fragments of chunk cc+1 are all issued
+  // BEFORE the MT*NT MFMAs of chunk cc (two register sets), and sched_barrier keeps hipcc from re-serialising.
+  __device__ __forceinline__ void fetch_chunk(const u32x4* __restrict__ wl, const u32x4 (&x)[MT][CPO], int cc,
+                                              u32x4 (&b)[NT], u32x4 (&xm)[MT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = wl[(cc * NT + nt) * 64 + lane];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xm[mt] = to_mfma_layout(x[mt][cc]);
+  }
+  __device__ __forceinline__ void mma_chunk(const u32x4 (&b)[NT], const u32x4 (&xm)[MT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma<DT>(b[nt], xm[mt], acc[mt][nt]);
+  }
   __device__ __forceinline__ void multiply(const u32x4* __restrict__ wl, const u32x4 (&x)[MT][CPO]) {
+    u32x4 b0[NT], b1[NT], x0[MT], x1[MT];
+    fetch_chunk(wl, x, 0, b0, x0);
 #pragma unroll
-    for (int cc = 0; cc < CPO; ++cc) {
-      u32x4 xm[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) xm[mt] = to_mfma_layout(x[mt][cc]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const u32x4 b = wl[(cc * NT + nt) * 64 + lane];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma<DT>(b, xm[mt], acc[mt][nt]);
+    for (int cc = 0; cc < CPO; cc += 2) {
+      if (cc + 1 < CPO) fetch_chunk(wl, x, cc + 1, b1, x1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_chunk(b0, x0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (cc + 1 < CPO) {
+        if (cc + 2 < CPO) fetch_chunk(wl, x, cc + 2, b0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk(b1, x1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -270,9 +312,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_resident_kernel(Args a) {
   const int per = (ntiles + 7) >> 3;
   const int tend = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
   const int w = threadIdx.x >> 6;
+  int* nbl = (int*)(lds + total) + w * a.K * ROWS;
   for (int t = xcd * per + bix * NW + w; t < tend; t += nxb * NW) {
     WT wt;
-    wt.init(a, t * ROWS, m);
+    wt.init(a, t * ROWS, m, nbl);
+    wt.preload_nb(a);
     int nbA[MT][NK], nbB[MT][NK];
     u32x4 xA[MT][CPO], xB[MT][CPO];
     const int last = nsteps - 1;
@@ -314,7 +358,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
   const int w = threadIdx.x >> 6;
   const u32x4* wg = (const u32x4*)a.wimg;
   WT wt;
-  wt.init(a, tb * BM + w * 16 * MT, m);
+  wt.init(a, tb * BM + w * 16 * MT, m, (int*)(lds + 2 * STEP) + w * a.K * 16 * MT);
+  wt.preload_nb(a);
   u32x4 wreg[WPT];
   // filter fragments of step `sc` -> registers / registers -> LDS buffer `buf`
   auto fetch_w = [&](int sc) {

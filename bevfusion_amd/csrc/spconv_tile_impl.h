@@ -8,7 +8,7 @@ namespace tile {
 template <int DT, int CINP, int NT, int MT, int NW, int SPS>
 static int run_resident(const Args& a, hipStream_t stream) {
   constexpr int CPO = SPS * Chunks<CINP>::CPB;
-  const size_t lds = (size_t)StepShape<CINP, CPO>::nsteps(a.K) * CPO * NT * 1024;
+  const size_t lds = (size_t)StepShape<CINP, CPO>::nsteps(a.K) * CPO * NT * 1024 + (size_t)NW * a.K * 16 * MT * 4;
   if (lds > 65536) {
     set_error("spconv tiled: resident variant needs %zu B of LDS (> 64 KiB)", lds);
     return BEVAMD_ERR_UNSUPPORTED;
@@ -29,7 +29,20 @@ static int run_resident(const Args& a, hipStream_t stream) {
 template <int DT, int CINP, int NT, int MT, int NW, int SPS>
 static int run_stream(const Args& a, hipStream_t stream) {
   constexpr int CPO = SPS * Chunks<CINP>::CPB;
-  const size_t lds = (size_t)2 * CPO * NT * 1024;
+  const size_t lds = (size_t)2 * CPO * NT * 1024 + (size_t)NW * a.K * 16 * MT * 4;  // filter ring + neighbour tables
+  if (lds > 160 * 1024) {
+    set_error("spconv tiled: stream variant needs %zu B of LDS (> 160 KiB)", lds);
+    return BEVAMD_ERR_UNSUPPORTED;
+  }
+  if (lds > 65536) {  // gfx950 has 160 KiB per CU; above 64 KiB the launch needs the opt-in
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void*)&spconv_stream_kernel<DT, CINP, NT, MT, NW, CPO>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+      raised = true;
+    }
+  }
   constexpr int BM = NW * 16 * MT;
   const long long nblk = ((long long)a.m_cap + BM - 1) / BM;
   const long long blocks = (nblk + 7) / 8 * 8;
@@ -54,9 +67,13 @@ constexpr bool resident_built() {
 template <int DT, int CINP, int NT>
 static int run_shape(const Args& a, int variant, hipStream_t stream) {
   if (variant == 0) {
+    // measured on MI355X over the SparseEncoder layer shapes (tools/sweep_spconv.py, profiles/r01_spconv_sweep.txt)
     const size_t img = (size_t)StepShape<CINP, Chunks<CINP>::CPB>::nsteps(a.K) * Chunks<CINP>::CPB * NT * 1024;  // unpadded image
-    if (resident_built<CINP, NT, 2, 1>() && img <= 65536) variant = 1221;
-    else variant = NT >= 8 ? 2121 : 2211;
+    if (NT >= 8) variant = 2121;
+    else if (CINP >= 64) variant = 2211;
+    else if (CINP == 32) variant = 2212;
+    else if (resident_built<CINP, NT, 2, 1>() && img + (size_t)8 * a.K * 32 * 4 <= 65536) variant = 1221;
+    else variant = 2212;
   }
 #define BEVAMD_RES(MT, NW, SPS)                                                                       \
   case 1000 + MT * 100 + (NW / 4) * 10 + SPS:                                                          \

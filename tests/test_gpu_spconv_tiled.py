@@ -120,7 +120,7 @@ def test_epilogue_bias_bn_residual_relu(dev, cin, cout, dtype):
     _assert_close(out, np.maximum(ref, 0), dtype)
 
 
-@pytest.mark.parametrize("variant", [0, 1221, 1422, 2211, 2123])
+@pytest.mark.parametrize("variant", [0, 2121, 2211, 2123])
 def test_device_row_count_and_capacity_launch(dev, variant):
     """Launch sized by a capacity far above the live row count; rows past the live count stay untouched."""
     rng = np.random.default_rng(5)

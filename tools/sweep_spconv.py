@@ -17,19 +17,27 @@ RES = (1221, 1222, 1223, 1421, 1422, 1211)
 STR = (2111, 2112, 2113, 2121, 2122, 2123, 2211, 2212, 2213, 2221, 2222)
 
 
+_BUSY = None
+
+
 def timeit(fn, iters=20):
-    for _ in range(3):
+    """us per launch with the host taken out of the picture: a ~5 ms matmul keeps the GPU busy while the host
+    enqueues all `iters` launches, the events then bracket back-to-back kernel execution."""
+    global _BUSY
+    if _BUSY is None:
+        _BUSY = torch.randn(8192, 8192, device="cuda")
+    for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    ts = []
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _BUSY @ _BUSY
+    s.record()
     for _ in range(iters):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
         fn()
-        e.record()
-        e.synchronize()
-        ts.append(s.elapsed_time(e) * 1e3)
-    return float(np.median(ts)), float(np.min(ts))
+    e.record()
+    e.synchronize()
+    t = s.elapsed_time(e) * 1e3 / iters
+    return t, t
 
 
 def main():
@@ -56,7 +64,7 @@ def main():
         ind, shape = rbs.out_indices.contiguous(), rbs.out_spatial_shape
         if i < 3:
             rb = sops.build_rulebook(ind, 1, shape, 3, 1, 1, 1, True)
-    print(f"# tiled sparse conv sweep, dtype={args.dtype}; time = median us over 20 launches (min in brackets)")
+    print(f"# tiled sparse conv sweep, dtype={args.dtype}; time = us per launch, 20 back-to-back launches behind a busy GPU (host overhead excluded)")
     for name, rb, n_in, cin, cout in layers:
         K = rb.nbr.shape[0]
         f = torch.randn(n_in, cin, device=dev).to(dt)
