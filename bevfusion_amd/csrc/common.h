@@ -106,6 +106,15 @@ int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_ou
                          uint32_t* vals_out, size_t n, int nbits, void* ws, size_t ws_bytes,
                          hipStream_t stream);
 
+// Same sort without the final placement guarantee: the result lands in (*result_keys, *result_vals), which is
+// one of the two buffer pairs (no copy for an even number of passes).
+int radix_sort_pairs_u32_ex(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n,
+                            int nbits, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t** result_keys,
+                            uint32_t** result_vals);
+// fill / copy of 32-bit words as ordinary kernels (captured as kernel nodes in HIP graphs)
+int device_fill_u32(uint32_t* p, size_t n, uint32_t v, hipStream_t stream);
+int device_copy_u32(uint32_t* d, const uint32_t* s, size_t n, hipStream_t stream);
+
 static inline int bits_for(uint64_t max_value_exclusive) {
   int b = 1;
   while (b < 32 && (1ull << b) < max_value_exclusive) ++b;

@@ -132,7 +132,7 @@ size_t scan_workspace_bytes(size_t n) {
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* ws,
                        size_t ws_bytes, hipStream_t stream) {
   if (n == 0) {
-    if (total) BEVAMD_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint32_t), stream));
+    if (total) return device_fill_u32(total, 1, 0u, stream);
     return BEVAMD_OK;
   }
   if (n <= SCAN_SINGLE_BLOCK_MAX) {
@@ -166,7 +166,7 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ROUNDS = 16;
 constexpr int RS_WAVE_CHUNK = 64 * RS_ROUNDS;     // 1024
 constexpr int RS_TILE = 4 * RS_WAVE_CHUNK;        // 4096
-constexpr int RS_MAX_BITS = 8;
+constexpr int RS_MAX_BITS = 9;   // 27-bit voxel keys in 3 passes; 512 digit counters per wave (8 KiB of LDS)
 constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
 
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
@@ -256,8 +256,37 @@ size_t radix_sort_workspace_bytes(size_t n) {
   return hist + scan_workspace_bytes(nblocks * RS_MAX_BINS);
 }
 
-int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                         size_t n, int nbits, void* ws, size_t ws_bytes, hipStream_t stream) {
+// ---- small utility kernels (kernel nodes in HIP graphs; no hipMemset/hipMemcpy on the hot path) ------------
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ p, size_t n, uint32_t v) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+__global__ __launch_bounds__(256) void copy_u32_kernel(uint32_t* __restrict__ d, const uint32_t* __restrict__ s, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+static unsigned util_grid(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);
+}
+int device_fill_u32(uint32_t* p, size_t n, uint32_t v, hipStream_t stream) {
+  if (n == 0) return BEVAMD_OK;
+  fill_u32_kernel<<<util_grid(n), 256, 0, stream>>>(p, n, v);
+  BEVAMD_LAUNCH_CHECK("fill_u32");
+  return BEVAMD_OK;
+}
+int device_copy_u32(uint32_t* d, const uint32_t* s, size_t n, hipStream_t stream) {
+  if (n == 0 || d == s) return BEVAMD_OK;
+  copy_u32_kernel<<<util_grid(n), 256, 0, stream>>>(d, s, n);
+  BEVAMD_LAUNCH_CHECK("copy_u32");
+  return BEVAMD_OK;
+}
+
+// The sorted pairs end in (*result_keys, *result_vals): the *_b buffers after an odd number of passes, the
+// *_a buffers after an even number.  Both buffer pairs are clobbered.
+int radix_sort_pairs_u32_ex(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int nbits,
+                            void* ws, size_t ws_bytes, hipStream_t stream, uint32_t** result_keys,
+                            uint32_t** result_vals) {
+  *result_keys = keys_a;
+  *result_vals = vals_a;
   if (n == 0) return BEVAMD_OK;
   if (n >= (1ull << 32)) {
     set_error("radix_sort_pairs_u32: n too large");
@@ -275,17 +304,9 @@ int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_ou
   void* scan_ws = (char*)ws + hist_bytes;
   size_t scan_ws_bytes = ws_bytes - hist_bytes;
 
-  int npass = (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
-  // an odd number of passes would leave the result in the wrong buffer; the data
-  // must end in *_out, so start from the buffer that makes the last pass land there.
-  int bits_per_pass = (nbits + npass - 1) / npass;
-  uint32_t *ki = keys_in, *vi = vals_in, *ko = keys_out, *vo = vals_out;
-  if ((npass & 1) == 0) {
-    // even: in -> out -> in ... ends in `in`; copy first so that we end in out.
-    BEVAMD_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-    BEVAMD_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
-    ki = keys_out; vi = vals_out; ko = keys_in; vo = vals_in;
-  }
+  const int npass = (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  const int bits_per_pass = (nbits + npass - 1) / npass;
+  uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
   int shift = 0;
   for (int p = 0; p < npass; ++p) {
     int bits = bits_per_pass;
@@ -303,7 +324,22 @@ int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_ou
     t = vi; vi = vo; vo = t;
     shift += bits;
   }
+  *result_keys = ki;
+  *result_vals = vi;
   return BEVAMD_OK;
+}
+
+int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                         size_t n, int nbits, void* ws, size_t ws_bytes, hipStream_t stream) {
+  uint32_t *rk, *rv;
+  int rc = radix_sort_pairs_u32_ex(keys_in, vals_in, keys_out, vals_out, n, nbits, ws, ws_bytes, stream, &rk, &rv);
+  if (rc) return rc;
+  if (rk != keys_out) {  // even number of passes: the result sits in the input buffers
+    rc = device_copy_u32(keys_out, rk, n, stream);
+    if (rc) return rc;
+    rc = device_copy_u32(vals_out, rv, n, stream);
+  }
+  return rc;
 }
 
 }  // namespace bevamd

@@ -233,10 +233,12 @@ static int voxel_segments(const float* points, int n, int nfeat, const VoxGrid& 
   dim3 grid(cdiv(n, 256)), block(256);
   vox_key_kernel<<<grid, block, 0, stream>>>(points, n, nfeat, g, ncells, vb.keys_a, vb.vals_a);
   BEVAMD_LAUNCH_CHECK("vox_key");
-  int rc = radix_sort_pairs_u32(vb.keys_a, vb.vals_a, vb.keys_s, vb.idx_s, (size_t)n, bits_for((uint64_t)ncells + 1),
-                                vb.sws, vb.sws_bytes, stream);
+  // the sorted pairs stay wherever the last pass left them (no placement copy)
+  int rc = radix_sort_pairs_u32_ex(vb.keys_a, vb.vals_a, vb.keys_s, vb.idx_s, (size_t)n, bits_for((uint64_t)ncells + 1),
+                                   vb.sws, vb.sws_bytes, stream, &vb.keys_s, &vb.idx_s);
   if (rc) return rc;
-  BEVAMD_HIP_CHECK(hipMemsetAsync(vb.first, 0, (size_t)n * sizeof(uint32_t), stream));
+  rc = device_fill_u32(vb.first, (size_t)n, 0u, stream);
+  if (rc) return rc;
   vox_heads_kernel<<<grid, block, 0, stream>>>(vb.keys_s, vb.idx_s, n, ncells, vb.head_flag, vb.first);
   BEVAMD_LAUNCH_CHECK("vox_heads");
   rc = exclusive_scan_u32(vb.head_flag, vb.head_scan, (size_t)n, vb.nseg, vb.sws, vb.sws_bytes, stream);
@@ -273,7 +275,8 @@ int bevamd_hard_voxelize(const float* points, float* voxels, int* coors, int* nu
   int rc = make_grid(voxel_size, coors_range, g);
   if (rc) return rc;
   if (num_points == 0) {
-    BEVAMD_HIP_CHECK(hipMemsetAsync(voxel_num_dev, 0, sizeof(int), stream));
+    int frc = device_fill_u32((uint32_t*)voxel_num_dev, 1, 0u, stream);
+    if (frc) return frc;
     if (voxel_num_host) { BEVAMD_HIP_CHECK(hipStreamSynchronize(stream)); *voxel_num_host = 0; }
     return BEVAMD_OK;
   }
@@ -323,8 +326,7 @@ int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* n
   int rc = make_grid(voxel_size, coors_range, g);
   if (rc) return rc;
   if (num_points == 0) {
-    BEVAMD_HIP_CHECK(hipMemsetAsync(voxel_num_dev, 0, sizeof(int), stream));
-    return BEVAMD_OK;
+    return device_fill_u32((uint32_t*)voxel_num_dev, 1, 0u, stream);
   }
   BEVAMD_REQUIRE(points && feats && coords4, "voxelize_mean: null buffer");
   const uint32_t ncells = (uint32_t)((unsigned long long)g.gx * g.gy * g.gz);

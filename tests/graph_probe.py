@@ -68,6 +68,52 @@ def main():
             if not torch.equal(got, want):
                 say(f"MISMATCH n={n} max|d|={float((got.float() - want.float()).abs().max())}")
                 sys.exit(1)
+    say("ENCODER-GRAPH-OK")
+
+    # ---- voxelizer + encoder in one graph (what bench.py replays): points -> [B, C*D, H, W] ---------------
+    from bevfusion_amd.voxel import voxelize_batch
+
+    vsize, prange = [1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 40.0, 40.0, 41.0]
+    npts = 30000
+    pts = torch.zeros((npts, 5), device=dev)
+
+    def load_points(seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        p = torch.rand((npts, 5), generator=g)
+        p[:, 0] *= 44.0
+        p[:, 1] *= 40.0
+        p[:, 2] *= 41.0
+        p[:, :2] -= 2.0      # some points fall outside the range
+        pts.copy_(p)
+
+    def pipeline():
+        vf, vc, _, cnt = voxelize_batch([pts], vsize, prange, 10, cap, sync=False)
+        return enc(vf[0], vc[0], 1, num_voxels=cnt), cnt
+
+    load_points(1)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                pipeline()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            out2, cnt2 = pipeline()
+        say("pipeline captured")
+        for seed in (2, 3):
+            load_points(seed)
+            g2.replay()
+            torch.cuda.synchronize()
+            got = out2.clone()
+            want, cw = pipeline()
+            torch.cuda.synchronize()
+            if int(cnt2) != int(cw) or not torch.equal(got, want):
+                say(f"PIPELINE MISMATCH seed={seed}")
+                sys.exit(1)
+            say(f"pipeline replayed seed={seed} voxels={int(cw)}")
     say("GRAPH-OK")
 
 
