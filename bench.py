@@ -242,6 +242,25 @@ def main():
         with torch.cuda.graph(graph):
             state["lidar_bev"], state["n_voxels_dev"], _ = lidar_branch()
 
+    # side figure (NOT part of `value`): the fused depth (x) context -> BEV op on the same plan, i.e. the
+    # camera branch without the 638 MB feature volume.  Different byte denominator than bev_pool: reported on its own.
+    fh, fw = cfg["feature_size"]
+    dbins = geom.shape[0] // (B * cfg["num_cameras"] * fh * fw)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    depth_prob = torch.softmax(torch.randn((B * cfg["num_cameras"], dbins, fh, fw), generator=g), 1).to(dev)
+    ctx_cl = torch.randn((B * cfg["num_cameras"] * fh * fw, C), generator=g).to(dev)
+    fused_out = torch.empty_like(bev)
+    for _ in range(3):
+        plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
+    fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    fe[0].record()
+    for _ in range(10):
+        plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
+    fe[1].record()
+    fe[1].synchronize()
+    fused_ms = fe[0].elapsed_time(fe[1]) / 10
+    fused_bytes = n_kept * 4 + ctx_cl.numel() * 4 + B * D * H * W * C * 4
+
     NSTAGE = 2
 
     def step(ev=None):
@@ -314,6 +333,10 @@ def main():
                 "stage_ms": dict(zip(["bev_pool", "lidar_branch"], stage_ms)),
                 "lidar_branch_eager_ms": {"voxelize": eager_vox_ms, "sparse_encoder": eager_enc_ms},
                 "hip_graph": graph is not None,
+                "fused_depth_context_bev": {"ms": fused_ms, "algorithmic_bytes": fused_bytes,
+                                            "note": "side figure, not in `value`: out[cell] = sum depth*ctx straight from depth "
+                                                    "[6,118,32,88] + context [6*32*88,80] (the [N',80] volume never exists); "
+                                                    "L2-bound, own byte denominator (SURVEY.md 8d/8f)"},
                 "bev_pool_precompute_ms_uncached": precompute_ms,
                 "bev_pool_precompute_first_call_ms": t_first * 1e3,
             },

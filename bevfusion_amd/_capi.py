@@ -29,6 +29,7 @@ _SIGNATURES = {
     "bevamd_bev_pool_prepare_from_geom": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_forward_cells": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_forward_cells_tuned": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_fused_forward": (I, [P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     # voxelization
     "bevamd_hard_voxelize_workspace_bytes": (Z, [I]),

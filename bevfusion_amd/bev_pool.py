@@ -205,6 +205,35 @@ class BevPoolPlan:
         _capi.check(rc, "bev_pool_forward_cells")
         return out
 
+    def launch_fused(self, depth, ctx, depth_bins, fh, fw, out=None):
+        """Fused depth (x) context -> BEV (csrc/bev_pool_fused.hip): out[cell] = sum_p depth[p] * ctx[pixel(p)] without the
+        [N', C] volume.  depth: fp32, `self.n` elements in frustum-point order ([cams, D, fH, fW] flattened);
+        ctx [cams*fH*fW, C] channels-last fp32 / bf16.  Forward only."""
+        lib = _capi.load()
+        depth = depth.contiguous()
+        ctx = ctx.contiguous()
+        if depth.dtype != torch.float32 or depth.numel() != self.n:
+            raise RuntimeError(f"depth must be fp32 with {self.n} elements, got {depth.dtype} x {depth.numel()}")
+        if ctx.dtype == torch.float32:
+            is_bf16 = 0
+        elif ctx.dtype == torch.bfloat16:
+            is_bf16 = 1
+        else:
+            raise RuntimeError(f"bev_pool fused: unsupported context dtype {ctx.dtype}")
+        if not depth.is_cuda or not ctx.is_cuda:
+            raise RuntimeError("bev_pool fused: inputs must be GPU tensors (the HIP extension has no CPU path)")
+        c = ctx.shape[-1]
+        if ctx.numel() // c * depth_bins != self.n:
+            raise RuntimeError("ctx rows x depth_bins must equal the number of frustum points of the plan")
+        if out is None:
+            out = torch.empty((self.B, self.D, self.H, self.W, c), dtype=torch.float32, device=ctx.device)
+        with torch.cuda.device(ctx.device):
+            rc = lib.bevamd_bev_pool_fused_forward(
+                _capi.ptr(depth), _capi.ptr(ctx), is_bf16, _capi.ptr(self.order), _capi.ptr(self.cell_start), _capi.ptr(out),
+                self.n, c, int(depth_bins), int(fh), int(fw), self.B, self.D, self.H, self.W, _capi.stream_ptr(ctx.device))
+        _capi.check(rc, "bev_pool_fused_forward")
+        return out
+
     def launch_backward(self, out_grad, c):
         lib = _capi.load()
         out_grad = out_grad.contiguous().float()

@@ -1,0 +1,148 @@
+// Fused depth (x) context -> BEV for gfx950.
+//
+// The reference materialises the camera feature volume before pooling it:
+//   models/vtransforms/depth_lss.py:92-97   x = depth.unsqueeze(1) * ctx.unsqueeze(2)   -> [BN, C, D, fH, fW] (638 MB fp32)
+//                                           .view().permute(0,1,3,4,5,2)                 -> a strided view
+//   models/vtransforms/base.py:141-176      reshape (copy), mask gather, sort gather, interval sum
+// i.e. ~5 GB of HBM traffic per frame around an op whose inputs are 13 MB.  Here
+//   out[cell, c] = sum over the frustum points p of the cell of  depth[p] * ctx[pixel(p), c]
+// is evaluated directly from depth [B*N, D, fH, fW] (softmax output, fp32) and the channels-last context
+// [B*N*fH*fW, C] (fp32 or bf16): the volume never exists.  The pooling plan (order / cell_start: stable sort of the
+// points by BEV cell, bev_pool.hip) is the same one the unfused op uses, so the summation order per cell — and with it
+// the rounding — is the reference's (row order inside an interval = point order).
+//
+// Not the same byte denominator as bev_pool: algorithmic bytes = N_kept*4 (depth) + n_pixels*C*s
+// (context, read once) + B*D*H*W*C*4 (output) = 54 MB at the flagship frame; the context rows are re-read ~107x
+// each from L2, so this kernel is L2-bandwidth-bound, not HBM-bound.
+//
+// One 64-lane wave per BEV cell; a context row (C channels) is covered by C/VEC lanes holding 16 bytes each, so
+// floor(64 / lanes-per-row) points are processed per wave instruction; the point's depth is a same-address (broadcast)
+// load for the lanes of its row slot; U independent (index -> depth, context) load pairs in flight per lane; row slots
+// are folded with __shfl; every cell (empty ones as zeros) is stored exactly once.
+#include "common.h"
+
+namespace bevamd {
+
+struct alignas(16) FU4 { uint32_t x, y, z, w; };
+struct FusedDims { int B, D, H, W, C; };
+
+template <int VEC> struct FAcc { float v[VEC]; };
+
+__device__ __forceinline__ void fma_row(FAcc<4>& a, float d, const float4& f) {
+  a.v[0] = fmaf(d, f.x, a.v[0]); a.v[1] = fmaf(d, f.y, a.v[1]); a.v[2] = fmaf(d, f.z, a.v[2]); a.v[3] = fmaf(d, f.w, a.v[3]);
+}
+__device__ __forceinline__ void fma_row(FAcc<8>& a, float d, const FU4& u) {
+  a.v[0] = fmaf(d, __uint_as_float(u.x << 16), a.v[0]); a.v[1] = fmaf(d, __uint_as_float(u.x & 0xFFFF0000u), a.v[1]);
+  a.v[2] = fmaf(d, __uint_as_float(u.y << 16), a.v[2]); a.v[3] = fmaf(d, __uint_as_float(u.y & 0xFFFF0000u), a.v[3]);
+  a.v[4] = fmaf(d, __uint_as_float(u.z << 16), a.v[4]); a.v[5] = fmaf(d, __uint_as_float(u.z & 0xFFFF0000u), a.v[5]);
+  a.v[6] = fmaf(d, __uint_as_float(u.w << 16), a.v[6]); a.v[7] = fmaf(d, __uint_as_float(u.w & 0xFFFF0000u), a.v[7]);
+}
+
+// frustum point p = ((cam * D + d) * fH + h) * fW + w  ->  context row  cam * fH*fW + h*fW + w
+__device__ __forceinline__ uint32_t pixel_of(uint32_t p, uint32_t dfhw, uint32_t fhw) {
+  const uint32_t cam = p / dfhw;
+  const uint32_t rem = p - cam * dfhw;
+  return cam * fhw + rem % fhw;
+}
+
+template <typename VecT, int VEC, int U>
+__global__ __launch_bounds__(256) void bev_pool_fused_cells_kernel(
+    const float* __restrict__ depth, const VecT* __restrict__ ctx, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ cell_start, uint32_t ncells, float* __restrict__ out, int lpr, int rpi, uint32_t dfhw,
+    uint32_t fhw, FusedDims s) {
+  const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (cell >= ncells) return;
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+  const uint32_t start = cell_start[cell];
+  const int len = (int)(cell_start[cell + 1] - start);
+  FAcc<VEC> acc;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
+  if (len > 0) {  // wave-uniform
+    if (slot < rpi) {
+      const uint32_t* ord = order + start;
+      int r = slot;
+      for (; r + (U - 1) * rpi < len; r += U * rpi) {
+        uint32_t p[U];
+        float d[U];
+        VecT a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = ord[r + u * rpi];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          d[u] = depth[p[u]];
+          a[u] = ctx[(size_t)pixel_of(p[u], dfhw, fhw) * lpr + cv];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) fma_row(acc, d[u], a[u]);
+      }
+      for (; r < len; r += rpi) {
+        const uint32_t p = ord[r];
+        const float d = depth[p];
+        const VecT a = ctx[(size_t)pixel_of(p, dfhw, fhw) * lpr + cv];
+        fma_row(acc, d, a);
+      }
+    }
+    // fold the row slots into slot 0 (wave-uniform trip count)
+    FAcc<VEC> tot = acc;
+    for (int sl = 1; sl < rpi; ++sl) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) tot.v[j] += __shfl(acc.v[j], lane + sl * lpr, 64);
+    }
+    acc = tot;
+  }
+  if (slot == 0) {
+    // rank = x*(W*D*B) + y*(D*B) + z*B + b (bev_pool.py:86-91) -> out[b, z, x, y, :] (bev_pool_cuda.cu:33-35)
+    uint32_t r = cell;
+    const int gb = r % s.B; r /= s.B;
+    const int gz = r % s.D; r /= s.D;
+    const int gy = r % s.W; r /= s.W;
+    const int gx = (int)r;
+    float4* o = (float4*)(out + ((((size_t)gb * s.D + gz) * s.H + gx) * s.W + gy) * (size_t)s.C + (size_t)cv * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC / 4; ++j) o[j] = make_float4(acc.v[4 * j], acc.v[4 * j + 1], acc.v[4 * j + 2], acc.v[4 * j + 3]);
+  }
+}
+
+}  // namespace bevamd
+
+using namespace bevamd;
+
+extern "C" {
+
+/* out [b, d, h, w, c] fp32 (every cell written once, no pre-zeroing) from
+ *   depth [n] fp32 (n = cams * depth_bins * fh * fw frustum points in the order of the geometry the plan was built from),
+ *   ctx   [cams * fh * fw, c] channels-last, fp32 (ctx_is_bf16 = 0) or bf16 bits (1),
+ *   order / cell_start: the pooling plan of bevamd_bev_pool_prepare[_from_geom]. */
+int bevamd_bev_pool_fused_forward(const float* depth, const void* ctx, int ctx_is_bf16, const uint32_t* order,
+                                  const uint32_t* cell_start, float* out, int n, int c, int depth_bins, int fh, int fw,
+                                  int b, int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(n >= 0 && c > 0 && depth_bins > 0 && fh > 0 && fw > 0 && b > 0 && d > 0 && h > 0 && w > 0,
+                 "bev_pool_fused_forward: bad sizes");
+  const long long per_cam = (long long)depth_bins * fh * fw;
+  BEVAMD_REQUIRE(n % per_cam == 0, "bev_pool_fused_forward: n=%d is not a multiple of depth_bins*fh*fw=%lld", n, per_cam);
+  const unsigned long long ncells64 = (unsigned long long)b * d * h * w;
+  BEVAMD_REQUIRE(ncells64 < 0xFFFFFFF0ull, "bev_pool_fused_forward: b*d*h*w must be < 2^32 - 16");
+  BEVAMD_REQUIRE(out && cell_start && (n == 0 || (depth && ctx && order)), "bev_pool_fused_forward: null buffer");
+  const int vec = ctx_is_bf16 ? 8 : 4;
+  BEVAMD_REQUIRE(c % vec == 0 && c / vec <= 64 && ((uintptr_t)ctx & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                 "bev_pool_fused_forward: c=%d must be a multiple of %d with at most 64 lanes per row, 16-byte aligned buffers",
+                 c, vec);
+  const uint32_t ncells = (uint32_t)ncells64;
+  const int lpr = c / vec, rpi = 64 / lpr;
+  FusedDims s{b, d, h, w, c};
+  dim3 grid(cdiv(ncells, 4)), block(256);
+  if (ctx_is_bf16)
+    bev_pool_fused_cells_kernel<FU4, 8, 4><<<grid, block, 0, stream>>>(depth, (const FU4*)ctx, order, cell_start, ncells, out,
+                                                                       lpr, rpi, (uint32_t)per_cam, (uint32_t)(fh * fw), s);
+  else
+    bev_pool_fused_cells_kernel<float4, 4, 4><<<grid, block, 0, stream>>>(depth, (const float4*)ctx, order, cell_start, ncells,
+                                                                          out, lpr, rpi, (uint32_t)per_cam, (uint32_t)(fh * fw), s);
+  BEVAMD_LAUNCH_CHECK("bev_pool_fused_cells");
+  return BEVAMD_OK;
+}
+
+}  // extern "C"

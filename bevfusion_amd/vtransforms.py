@@ -33,6 +33,19 @@ def gen_dx_bx(xbound, ybound, zbound):
     return dx, bx, nx
 
 
+class FactoredCamFeats:
+    """`get_cam_feats` result kept factored: depth [B, N, D, fH, fW] (softmax) and context [B, N, C, fH, fW].  Equivalent
+    to the reference's [B, N, D, fH, fW, C] outer product (depth_lss.py:92-97), which `bev_pool` then never builds."""
+
+    def __init__(self, depth, ctx):
+        self.depth, self.ctx = depth, ctx
+
+    def materialize(self):
+        B, N, D, fH, fW = self.depth.shape
+        x = self.depth.unsqueeze(2) * self.ctx.unsqueeze(3)          # [B, N, C, D, fH, fW]
+        return x.permute(0, 1, 3, 4, 5, 2)
+
+
 def _fp32(*tensors):
     """mmcv's @force_fp32: half/bf16 tensor arguments are cast to float."""
     return [t.float() if torch.is_tensor(t) and t.is_floating_point() and t.dtype != torch.float32 else t for t in tensors]
@@ -67,9 +80,11 @@ class BaseTransform(nn.Module):
         self.frustum = self.create_frustum()
         self.D = self.frustum.shape[0]
         self.fp16_enabled = False
-        # MI355X-native knobs (not in the reference): reuse the bev_pool precompute across frames
+        # MI355X-native knobs (not in the reference): reuse the bev_pool precompute across frames; at inference keep
+        # depth and context factored and fold their outer product into the pooling kernel
         self.cache_geometry = False
         self._plan = None
+        self.fused_cam_feats = True
 
     def create_frustum(self):
         """base.py:66-89."""
@@ -115,17 +130,26 @@ class BaseTransform(nn.Module):
 
     def bev_pool(self, geom_feats, x):
         """base.py:141-176: [B,N,D,H,W,3] geometry + [B,N,D,H,W,C] features -> [B, C*nz, nx, ny]."""
-        geom_feats, x = _fp32(geom_feats, x)
-        B, N, D, H, W, C = x.shape
+        factored = x if isinstance(x, FactoredCamFeats) else None
+        if factored is not None:
+            (geom_feats,) = _fp32(geom_feats)
+            B, N, D, H, W = factored.depth.shape
+            C = factored.ctx.shape[2]
+        else:
+            geom_feats, x = _fp32(geom_feats, x)
+            B, N, D, H, W, C = x.shape
         Nprime = B * N * D * H * W
-        x = x.reshape(Nprime, C)
         plan = self._plan if (self.cache_geometry and self._plan is not None and self._plan.n == Nprime
                               and self._plan.B == B) else None
         if plan is None:
             plan = self.make_plan(geom_feats, B)
             if self.cache_geometry:
                 self._plan = plan
-        out = plan.forward(x)                       # [B, nz, nx, ny, C] fp32
+        if factored is not None:
+            ctx_cl = factored.ctx.float().permute(0, 1, 3, 4, 2).contiguous()     # [B, N, fH, fW, C] (5 MB)
+            out = plan.launch_fused(factored.depth.float().contiguous(), ctx_cl.view(-1, C), D, H, W)
+        else:
+            out = plan.forward(x.reshape(Nprime, C))   # [B, nz, nx, ny, C] fp32
         out = out.permute(0, 4, 1, 2, 3)            # [B, C, nz, nx, ny] view
         # collapse Z (reference: torch.cat(x.unbind(dim=2), 1))
         if out.shape[2] == 1:
@@ -253,6 +277,8 @@ class LSSTransform(BaseTransform):
         x = x.view(B * N, C, fH, fW)
         x = self.depthnet(x)
         depth = x[:, : self.D].softmax(dim=1)
+        if self.fused_cam_feats and not torch.is_grad_enabled():
+            return FactoredCamFeats(depth.view(B, N, self.D, fH, fW), x[:, self.D: (self.D + self.C)].view(B, N, self.C, fH, fW))
         x = depth.unsqueeze(1) * x[:, self.D: (self.D + self.C)].unsqueeze(2)
         x = x.view(B, N, self.C, self.D, fH, fW)
         x = x.permute(0, 1, 3, 4, 5, 2)
@@ -291,6 +317,8 @@ class DepthLSSTransform(BaseDepthTransform):
         x = torch.cat([d, x], dim=1)
         x = self.depthnet(x)
         depth = x[:, : self.D].softmax(dim=1)
+        if self.fused_cam_feats and not torch.is_grad_enabled():
+            return FactoredCamFeats(depth.view(B, N, self.D, fH, fW), x[:, self.D: (self.D + self.C)].view(B, N, self.C, fH, fW))
         x = depth.unsqueeze(1) * x[:, self.D: (self.D + self.C)].unsqueeze(2)
         x = x.view(B, N, self.C, self.D, fH, fW)
         x = x.permute(0, 1, 3, 4, 5, 2)

@@ -105,6 +105,17 @@ int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* 
                                   const uint32_t* cell_start, float* out, int n, int c, int b, int d,
                                   int h, int w, void* stream);
 
+/* Fused depth (x) context -> BEV: DepthLSSTransform.get_cam_feats' outer product
+ * (models/vtransforms/depth_lss.py:92-97) folded into the pooling (base.py:141-176), so the [N', C] camera feature
+ * volume (638 MB fp32 per frame) is never materialised:
+ *   out[cell, :] = sum over the frustum points p of the cell of  depth[p] * ctx[pixel(p), :]
+ * depth [n] fp32 = softmax output flattened as [cams, depth_bins, fh, fw] (the point order of the geometry the plan was
+ * built from); ctx [cams*fh*fw, c] channels-last, fp32 (ctx_is_bf16 = 0) or bf16 bits (1); order / cell_start from
+ * bevamd_bev_pool_prepare[_from_geom]; out [b, d, h, w, c] fp32, every cell written once. Forward only (inference). */
+int bevamd_bev_pool_fused_forward(const float* depth, const void* ctx, int ctx_is_bf16, const uint32_t* order,
+                                  const uint32_t* cell_start, float* out, int n, int c, int depth_bins, int fh,
+                                  int fw, int b, int d, int h, int w, void* stream);
+
 /* Tuning hook of the same kernel family (bench sweeps only): variant 0 = shipped default,
  * 1/2 = one wave per cell (4/8 loads in flight), 3..7 = workgroup-cooperative flavours. */
 int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint32_t* order,

@@ -10,7 +10,7 @@ from bevfusion_amd import spconv, synth
 from bevfusion_amd.sparse_encoder import SparseEncoder
 from bevfusion_amd.spconv import functional as Fsp
 from bevfusion_amd.spconv import ops as sops
-from bevfusion_amd.vtransforms import DepthLSSTransform, LSSTransform
+from bevfusion_amd.vtransforms import FactoredCamFeats, DepthLSSTransform, LSSTransform
 
 pytestmark = pytest.mark.gpu
 
@@ -71,9 +71,12 @@ def test_lss_transform_forward_config1(dev):
                                mats["camera_intrinsics"][..., :3, :3], mats["img_aug_matrix"][..., :3, :3],
                                mats["img_aug_matrix"][..., :3, 3], extra_rots=mats["lidar_aug_matrix"][..., :3, :3],
                                extra_trans=mats["lidar_aug_matrix"][..., :3, 3])
+        vt.fused_cam_feats = False                       # the reference's materialised [B,N,D,fH,fW,C] volume
         feats = vt.get_cam_feats(img)
         ref = _reference_bev_pool_torch(vt, geom, feats)
-    assert float((out.double() - ref).abs().max()) <= 1e-4
+        out_unfused = vt(img, None, None, **mats)
+    assert float((out.double() - ref).abs().max()) <= 1e-4          # `out` ran the fused depth (x) context kernel
+    assert float((out_unfused.double() - ref).abs().max()) <= 1e-4
 
 
 def test_depth_lss_transform_forward_flagship_shapes(dev):
@@ -97,12 +100,25 @@ def test_depth_lss_transform_forward_flagship_shapes(dev):
                                mats["cam_intrinsic"][..., :3, :3], mats["img_aug_matrix"][..., :3, :3],
                                mats["img_aug_matrix"][..., :3, 3], extra_rots=mats["lidar_aug_matrix"][..., :3, :3],
                                extra_trans=mats["lidar_aug_matrix"][..., :3, 3])
+        fz = vt.get_cam_feats(img, depth)                # inference default: depth / context kept factored
+        assert isinstance(fz, FactoredCamFeats) and tuple(fz.depth.shape) == (B, 6, 118, 32, 88)
+        vt.fused_cam_feats = False
         feats = vt.get_cam_feats(img, depth)
         assert tuple(feats.shape) == (B, 6, 118, 32, 88, 80)
+        assert torch.allclose(fz.materialize(), feats, rtol=1e-4, atol=1e-6)   # two passes through the conv stack (MIOpen)
         pooled = vt.bev_pool(geom, feats)
         ref = _reference_bev_pool_torch(vt, geom, feats)
         assert tuple(pooled.shape) == (B, 80, 360, 360)
         assert float((pooled.double() - ref).abs().max()) <= 1e-4
+        # fused depth (x) context -> BEV: same sums without the 638 MB volume (fp32 and bf16 context)
+        pooled_f = vt.bev_pool(geom, fz)
+        assert tuple(pooled_f.shape) == (B, 80, 360, 360)
+        assert float((pooled_f.double() - ref).abs().max()) <= 1e-4
+        plan = vt.make_plan(geom, B)
+        ctx16 = fz.ctx.permute(0, 1, 3, 4, 2).contiguous().bfloat16()
+        ref16 = _reference_bev_pool_torch(vt, geom, FactoredCamFeats(fz.depth, ctx16.float().permute(0, 1, 4, 2, 3)).materialize())
+        got16 = plan.launch_fused(fz.depth.contiguous(), ctx16.view(-1, 80), 118, 32, 88).permute(0, 4, 1, 2, 3)[:, :, 0]
+        assert float((got16.double() - ref16).abs().max()) <= 1e-4
         # static calibration: the precompute is built once and reused; same bits as a fresh plan
         vt.cache_geometry = True
         a = vt.bev_pool(geom, feats)
