@@ -31,6 +31,10 @@ _SIGNATURES = {
     "bevamd_bev_pool_forward_cells_tuned": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_fused_forward": (I, [P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    # view-transform glue
+    "bevamd_depth_raster_workspace_bytes": (Z, [I, I, I]),
+    "bevamd_depth_raster": (I, [P, I, I, P, P, P, P, I, I, I, P, P, Z, P]),
+    "bevamd_lss_geometry": (I, [P, I, P, P, P, P, P, P, I, I, P, P]),
     # voxelization
     "bevamd_hard_voxelize_workspace_bytes": (Z, [I]),
     "bevamd_hard_voxelize": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, Z, P]),

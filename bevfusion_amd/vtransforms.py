@@ -19,6 +19,7 @@ from typing import Tuple
 import torch
 from torch import nn
 
+from . import _capi
 from .bev_pool import BevPoolPlan
 from .registry import register_everywhere
 
@@ -102,6 +103,9 @@ class BaseTransform(nn.Module):
         camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans = _fp32(
             camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans)
         B, N, _ = camera2lidar_trans.shape
+        if camera2lidar_trans.is_cuda and not torch.is_grad_enabled():
+            return self._get_geometry_native(camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs)
+        # host tensors / autograd: the reference's own broadcasting formulation
         # undo post-transformation
         points = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
         points = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(points.unsqueeze(-1))
@@ -117,6 +121,27 @@ class BaseTransform(nn.Module):
             extra_trans = _fp32(kwargs["extra_trans"])[0]
             points += extra_trans.view(B, 1, 1, 1, 1, 3).repeat(1, N, 1, 1, 1, 1)
         return points
+
+    def _get_geometry_native(self, c2l_rots, c2l_trans, intrins, post_rots, post_trans, **kwargs):
+        """Same result from one kernel (csrc/vtransform.hip::lss_geometry_kernel): the 3x3 inverses / products of the
+        per-camera matrices stay in torch (B*N tiny matrices), the [B,N,D,fH,fW,3] point cloud is one launch."""
+        lib = _capi.load()
+        B, N, _ = c2l_trans.shape
+        dev = c2l_trans.device
+        post_rot_inv = torch.inverse(post_rots).reshape(B * N, 3, 3).contiguous()
+        combine = c2l_rots.matmul(torch.inverse(intrins)).reshape(B * N, 3, 3).contiguous()
+        extra_rots = _fp32(kwargs["extra_rots"])[0].reshape(B, 3, 3).contiguous() if "extra_rots" in kwargs else None
+        extra_trans = _fp32(kwargs["extra_trans"])[0].reshape(B, 3).contiguous() if "extra_trans" in kwargs else None
+        frustum = self.frustum.detach().to(dev).float().contiguous()
+        D, fH, fW, _ = frustum.shape
+        geom = torch.empty((B, N, D, fH, fW, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.bevamd_lss_geometry(_capi.ptr(frustum), D * fH * fW, _capi.ptr(post_rot_inv),
+                                         _capi.ptr(post_trans.reshape(B * N, 3).contiguous()), _capi.ptr(combine),
+                                         _capi.ptr(c2l_trans.reshape(B * N, 3).contiguous()), _capi.ptr(extra_rots),
+                                         _capi.ptr(extra_trans), B, N, _capi.ptr(geom), _capi.stream_ptr(dev))
+        _capi.check(rc, "lss_geometry")
+        return geom
 
     def get_cam_feats(self, x, *args):
         raise NotImplementedError
@@ -195,6 +220,8 @@ class BaseDepthTransform(BaseTransform):
         batch_size = len(points)
         n_cam = img.shape[1]
         iH, iW = self.image_size
+        if points[0].is_cuda:
+            return self._depth_raster_native(points, n_cam, lidar2image, img_aug_matrix, lidar_aug_matrix)
         depth = torch.zeros(batch_size, n_cam, 1, iH, iW, device=points[0].device)
         for b in range(batch_size):
             cur_coords = points[b][:, :3].float()
@@ -222,6 +249,32 @@ class BaseDepthTransform(BaseTransform):
             cam = torch.arange(n_cam, device=pix.device).view(-1, 1).expand_as(on_img)
             lin = (cam * iH + pix[..., 0]) * iW + pix[..., 1]
             depth[b].view(-1)[lin[on_img]] = dist[on_img]
+        return depth
+
+    def _depth_raster_native(self, points, n_cam, lidar2image, img_aug_matrix, lidar_aug_matrix):
+        """csrc/vtransform.hip: one (winner, write) kernel pair per sample, all cameras at once, no host sync; a pixel hit
+        by several points keeps the LAST one in input order (the reference's assignment order on CPU; its GPU
+        index_put is unordered)."""
+        lib = _capi.load()
+        iH, iW = self.image_size
+        dev = points[0].device
+        B = len(points)
+        depth = torch.empty((B, n_cam, 1, iH, iW), dtype=torch.float32, device=dev)
+        inv_rot = torch.inverse(lidar_aug_matrix[:, :3, :3].float()).contiguous()
+        trans = lidar_aug_matrix[:, :3, 3].float().contiguous()
+        l2i = lidar2image.float().contiguous()
+        ia = img_aug_matrix.float().contiguous()
+        with torch.cuda.device(dev):
+            wsb = lib.bevamd_depth_raster_workspace_bytes(n_cam, iH, iW)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            for b in range(B):
+                p = points[b]
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    p = p.float().contiguous()
+                rc = lib.bevamd_depth_raster(_capi.ptr(p), p.shape[0], p.shape[1], _capi.ptr(inv_rot[b]), _capi.ptr(trans[b]),
+                                             _capi.ptr(l2i[b]), _capi.ptr(ia[b]), n_cam, iH, iW, _capi.ptr(depth[b]),
+                                             _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+                _capi.check(rc, "depth_raster")
         return depth
 
     def forward(self, img, points, radar, sensor2ego, lidar2ego, lidar2camera, lidar2image, cam_intrinsic,

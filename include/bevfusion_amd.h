@@ -129,6 +129,28 @@ int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order,
                                   int d, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * view-transform glue  (reference: mmdet3d/models/vtransforms/base.py — Python in the reference)
+ * ------------------------------------------------------------------------- */
+
+/* Replaces the per-sample body of BaseDepthTransform.forward (base.py:283-329): LiDAR points -> one depth image per
+ * camera.  points [num_points, num_features] fp32 (xyz first); lidar_aug_inv_rot [3,3] = inverse(lidar_aug_matrix[:3,:3]),
+ * lidar_aug_trans [3] = lidar_aug_matrix[:3,3]; lidar2image, img_aug [ncam,4,4]; all DEVICE fp32.
+ * depth [ncam, 1, ih, iw] fp32 is fully written (zeros where no point lands).  A pixel hit by several points takes the
+ * LAST point in input order (deterministic).  ws: bevamd_depth_raster_workspace_bytes(ncam, ih, iw). */
+size_t bevamd_depth_raster_workspace_bytes(int ncam, int ih, int iw);
+int bevamd_depth_raster(const float* points, int num_points, int num_features, const float* lidar_aug_inv_rot,
+                        const float* lidar_aug_trans, const float* lidar2image, const float* img_aug, int ncam,
+                        int ih, int iw, float* depth, void* ws, size_t ws_bytes, void* stream);
+
+/* Replaces BaseTransform.get_geometry (base.py:92-135): frustum [frustum_points, 3] (u, v, d) -> geom
+ * [batch*cams, frustum_points, 3] in the lidar frame.  post_rot_inv [batch*cams,3,3] = inverse(img_aug[:3,:3]),
+ * post_trans [batch*cams,3], combine [batch*cams,3,3] = camera2lidar_rot @ inverse(intrinsics), camera2lidar_trans
+ * [batch*cams,3], extra_rot [batch,3,3] / extra_trans [batch,3] (LiDAR augmentation, either may be NULL). DEVICE fp32. */
+int bevamd_lss_geometry(const float* frustum, int frustum_points, const float* post_rot_inv, const float* post_trans,
+                        const float* combine, const float* camera2lidar_trans, const float* extra_rot,
+                        const float* extra_trans, int batch_size, int cams_per_sample, float* geom, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * voxelization  (reference: mmdet3d/ops/voxel)
  * ------------------------------------------------------------------------- */
 

@@ -279,3 +279,58 @@ def pairs_as_sets(indice_pairs, indice_num):
         pr = np.stack([indice_pairs[k, 0, :m], indice_pairs[k, 1, :m]], 1)
         out.append(pr[np.lexsort((pr[:, 0], pr[:, 1]))] if m else pr.reshape(0, 2))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# view-transform glue (mmdet3d/models/vtransforms/base.py — Python in the reference; restated in numpy fp32)
+# --------------------------------------------------------------------------------------------
+def lss_geometry(frustum, post_rots, post_trans, camera2lidar_rots, camera2lidar_trans, intrins, extra_rots=None,
+                 extra_trans=None):
+    """BaseTransform.get_geometry (base.py:92-135).  frustum [D,fH,fW,3]; per-camera matrices [B,N,3,3] / [B,N,3];
+    extra_rots [B,3,3], extra_trans [B,3] -> [B, N, D, fH, fW, 3] float32."""
+    f32 = np.float32
+    frustum = np.asarray(frustum, f32)
+    B, N = camera2lidar_trans.shape[:2]
+    pts = frustum[None, None] - np.asarray(post_trans, f32).reshape(B, N, 1, 1, 1, 3)                      # :104
+    inv = np.linalg.inv(np.asarray(post_rots, np.float64)).astype(f32)
+    pts = np.einsum("bnij,bndhwj->bndhwi", inv, pts).astype(f32)                                            # :105-109
+    pts = np.concatenate([pts[..., :2] * pts[..., 2:3], pts[..., 2:3]], -1).astype(f32)                     # :111-117
+    combine = (np.asarray(camera2lidar_rots, np.float64) @ np.linalg.inv(np.asarray(intrins, np.float64))).astype(f32)
+    pts = np.einsum("bnij,bndhwj->bndhwi", combine, pts).astype(f32)                                        # :118-119
+    pts = pts + np.asarray(camera2lidar_trans, f32).reshape(B, N, 1, 1, 1, 3)                              # :120
+    if extra_rots is not None:                                                                               # :122-128
+        pts = np.einsum("bij,bndhwj->bndhwi", np.asarray(extra_rots, f32), pts).astype(f32)
+    if extra_trans is not None:                                                                              # :129-133
+        pts = pts + np.asarray(extra_trans, f32).reshape(B, 1, 1, 1, 1, 3)
+    return pts.astype(f32)
+
+
+def depth_raster(points, lidar2image, img_aug_matrix, lidar_aug_matrix, image_size):
+    """One sample of BaseDepthTransform.forward's raster (base.py:283-329): points [n, >=3], lidar2image / img_aug_matrix
+    [N,4,4], lidar_aug_matrix [4,4] -> (depth [N, 1, iH, iW] float32, winner [N, iH, iW] int32 = index of the point
+    written at each pixel or -1).  Colliding points: the last one in input order wins (sequential assignment)."""
+    f32 = np.float32
+    iH, iW = image_size
+    pts = np.asarray(points, f32)[:, :3]
+    lam = np.asarray(lidar_aug_matrix, f32)
+    l2i = np.asarray(lidar2image, f32)
+    ia = np.asarray(img_aug_matrix, f32)
+    cur = pts - lam[:3, 3]                                                                                   # :291
+    cur = (np.linalg.inv(lam[:3, :3].astype(np.float64)).astype(f32) @ cur.T).astype(f32)                   # :292-294 [3, n]
+    cur = np.einsum("cij,jn->cin", l2i[:, :3, :3], cur).astype(f32) + l2i[:, :3, 3].reshape(-1, 3, 1)       # :296-297
+    cur[:, 2, :] = np.clip(cur[:, 2, :], 1e-5, 1e5)                                                          # :300-301 (dist is a view)
+    dist = cur[:, 2, :].copy()
+    cur[:, :2, :] = cur[:, :2, :] / cur[:, 2:3, :]                                                           # :302
+    cur = np.einsum("cij,cjn->cin", ia[:, :3, :3], cur).astype(f32) + ia[:, :3, 3].reshape(-1, 3, 1)        # :305-306
+    rc = cur[:, :2, :].transpose(0, 2, 1)[..., [1, 0]]                                                       # :307-310 (row, col)
+    on = (rc[..., 0] < iH) & (rc[..., 0] >= 0) & (rc[..., 1] < iW) & (rc[..., 1] >= 0)                       # :312-317
+    n_cam = l2i.shape[0]
+    depth = np.zeros((n_cam, 1, iH, iW), f32)
+    winner = np.full((n_cam, iH, iW), -1, np.int32)
+    for c in range(n_cam):
+        idx = np.nonzero(on[c])[0]
+        pix = rc[c, idx].astype(np.int64)                                                                    # .long(): truncation
+        # sequential assignment: later points overwrite earlier ones
+        depth[c, 0, pix[:, 0], pix[:, 1]] = dist[c, idx]
+        winner[c, pix[:, 0], pix[:, 1]] = idx
+    return depth, winner, rc, on
