@@ -169,28 +169,60 @@ __global__ __launch_bounds__(256) void sp_nbr_from_inputs_kernel(const int* __re
   }
 }
 
-// nbr[k][0..m) = -1 for every offset (rows bounded by the device count)
+// nbr[k][0..m) = -1 for offsets k in [k0, k0 + gridDim.y) (rows bounded by the device count); 16-byte stores
 __global__ __launch_bounds__(256) void sp_nbr_clear_kernel(int* __restrict__ nbr, int nbr_stride, int m_cap,
-                                                           const int* __restrict__ m_dev) {
+                                                           const int* __restrict__ m_dev, int k0) {
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
-  int* row = nbr + (size_t)blockIdx.y * nbr_stride;
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) row[o] = -1;
+  int* row = nbr + (size_t)(k0 + blockIdx.y) * nbr_stride;
+  if ((nbr_stride & 3) == 0 && ((uintptr_t)nbr & 15) == 0) {
+    const int m4 = m >> 2;
+    const int4 neg = make_int4(-1, -1, -1, -1);
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < m4; o += gridDim.x * 256) ((int4*)row)[o] = neg;
+    for (int o = (m4 << 2) + blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) row[o] = -1;
+  } else {
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) row[o] = -1;
+  }
 }
 
-// strided conv, pass 1: input j sets the bit of every output cell it touches.  Device-scope atomics leave the
-// XCD (L2s are not coherent with each other), so they are the cost here: candidate cells of one (ox, oy) are
-// consecutive in z and are OR-ed into one mask per bitmap word first, and a word that already shows the bits
-// (a plain read, possibly stale -> only ever conservative) is skipped.
-__device__ __forceinline__ void mark_flush(uint2* __restrict__ words, uint32_t w, uint32_t mask) {
-  if (!mask) return;
-  uint32_t* wp = &words[w].x;
-  if ((__builtin_nontemporal_load(wp) & mask) != mask) atomicOr(wp, mask);
+// SubM neighbour table with half the lookups: in a submanifold convolution input and output sets coincide, so
+// nbr[k][o] = i  <=>  nbr[K-1-k][i] = o (the mirrored offset).  Offsets k < K/2 are looked up and scattered to their
+// mirror (rows of the upper half are pre-cleared to -1), the centre offset is the identity.  Odd kernel sizes only.
+template <int KIND>
+__global__ __launch_bounds__(256) void sp_nbr_subm_sym_kernel(const int* __restrict__ indices, int m_cap,
+                                                              const int* __restrict__ m_dev, ConvGeom g, IndexRef ix,
+                                                              int* __restrict__ nbr, int nbr_stride) {
+  const int k = blockIdx.y;  // 0 .. K/2 (K/2 = centre)
+  int m = m_dev ? *m_dev : m_cap;
+  if (m > m_cap) m = m_cap;
+  const int kz = k % g.ksize[2];
+  const int ky = (k / g.ksize[2]) % g.ksize[1];
+  const int kx = k / (g.ksize[2] * g.ksize[1]);
+  const bool centre = k == g.K / 2;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) {
+    if (centre) {
+      nbr[(size_t)k * nbr_stride + o] = o;
+      continue;
+    }
+    const int4 c = ((const int4*)indices)[o];
+    const int ix_ = c.y - g.pad[0] + kx, iy = c.z - g.pad[1] + ky, iz = c.w - g.pad[2] + kz;
+    int r = -1;
+    if (ix_ >= 0 && ix_ < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && iz >= 0 && iz < g.in_shape[2]) {
+      uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
+      r = index_lookup<KIND>(ix, key);
+    }
+    nbr[(size_t)k * nbr_stride + o] = r;
+    if (r >= 0 && r < m) nbr[(size_t)(g.K - 1 - k) * nbr_stride + r] = o;
+  }
 }
 
+// strided conv, pass 1: input j flags every output cell it touches in a BYTE map (one byte per cell) with plain
+// stores.  A bitmap would need device-scope atomicOr, and device-scope atomics leave the XCD (the 8 L2s are not coherent
+// with each other): 540 k of them cost 25-50 us per level.  Byte stores of the same value race benignly (L2 lines carry
+// byte-granular dirty masks), are fire-and-forget, and the map is folded into bitmap words by the popcount pass below.
 __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restrict__ indices, int n_cap,
                                                               const int* __restrict__ n_dev, ConvGeom g,
-                                                              uint2* __restrict__ words) {
+                                                              uint8_t* __restrict__ cellmap) {
   int n = n_dev ? *n_dev : n_cap;
   if (n > n_cap) n = n_cap;
   for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
@@ -205,22 +237,13 @@ __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restr
         if (ty < 0 || ty % g.stride[1]) continue;
         int oy = ty / g.stride[1];
         if (oy >= g.out_shape[1]) continue;
-        uint32_t cur_w = 0xFFFFFFFFu, cur_mask = 0u;
         for (int kz = 0; kz < g.ksize[2]; ++kz) {
           int tz = c.w + g.pad[2] - kz;
           if (tz < 0 || tz % g.stride[2]) continue;
           int oz = tz / g.stride[2];
           if (oz >= g.out_shape[2]) continue;
-          uint32_t key = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
-          const uint32_t w = key >> 5;
-          if (w != cur_w) {
-            mark_flush(words, cur_w, cur_mask);
-            cur_w = w;
-            cur_mask = 0u;
-          }
-          cur_mask |= 1u << (key & 31);
+          cellmap[(size_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz)] = 1;
         }
-        mark_flush(words, cur_w, cur_mask);
       }
     }
   }
@@ -245,15 +268,28 @@ __device__ __forceinline__ unsigned block_exclusive_scan_256u(unsigned v, unsign
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint2* __restrict__ words, size_t nwords,
-                                                                uint32_t* __restrict__ tile_sums) {
+// byte map -> bitmap words (+ per-tile popcount sums).  Thread t of a tile folds 32 consecutive cells (two 16-byte
+// loads) into one word; `cellmap` is allocated in whole 32-byte groups (zero filled), so no tail handling.
+__global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint8_t* __restrict__ cellmap, uint2* __restrict__ words,
+                                                                size_t nwords, uint32_t* __restrict__ tile_sums) {
   __shared__ unsigned lds_wave[4];
   const size_t base = (size_t)blockIdx.x * RANK_TILE;
   unsigned s = 0;
 #pragma unroll
   for (int i = 0; i < RANK_TILE / 256; ++i) {
     const size_t w = base + (size_t)i * 256 + threadIdx.x;
-    if (w < nwords) s += __popc(words[w].x);
+    if (w < nwords) {
+      const uint4 lo = ((const uint4*)cellmap)[2 * w], hi = ((const uint4*)cellmap)[2 * w + 1];
+      const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      uint32_t bits = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {  // bytes are 0 or 1: gather bit 0 of each of the 4 bytes of v[q]
+        const uint32_t t = v[q] & 0x01010101u;
+        bits |= (((t * 0x01020408u) >> 24) & 0xFu) << (4 * q);   // byte b (cell 4q + b) -> bit 24 + b of the product
+      }
+      words[w].x = bits;
+      s += __popc(bits);
+    }
   }
   unsigned tot;
   block_exclusive_scan_256u(s, lds_wave, &tot);
@@ -428,7 +464,8 @@ static size_t grid_words(int batch, const int* shape) {
 
 static size_t rank_index_bytes(int batch, const int* shape) {
   const size_t nw = grid_words(batch, shape), nt = (nw + RANK_TILE - 1) / RANK_TILE;
-  return align_up(nw * 8, 256) + align_up((nt + 1) * 4, 256) + align_up(scan_workspace_bytes(nt + 1), 256) + 256;
+  return align_up(nw * 8, 256) + align_up((nt + 1) * 4, 256) + align_up(scan_workspace_bytes(nt + 1), 256) +
+         align_up(nw * 32, 256) /* byte map */ + 256;
 }
 
 static int hash_build(const int* indices, int n_cap, const int* n_dev, const ConvGeom& g, void* index, size_t bytes,
@@ -484,25 +521,27 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
   }
   const size_t nw = grid_words(g.batch, g.out_shape), nt = (nw + RANK_TILE - 1) / RANK_TILE;
   Carver cv(out_index, bytes);
-  uint2* words = cv.take<uint2>(nw);
+  uint2* words = cv.take<uint2>(nw);   // must stay first: the rank index IS this array
   uint32_t* tile_sums = cv.take<uint32_t>(nt + 1);
-  void* sws = cv.base + cv.off;
-  int frc = fill_u32(words, align_up(nw * 8, 16), 0u, stream);  // the Carver keeps 256-byte slack behind `words`
+  void* sws = cv.take<char>(align_up(scan_workspace_bytes(nt + 1), 256));
+  const size_t sws_bytes = align_up(scan_workspace_bytes(nt + 1), 256);
+  uint8_t* cellmap = cv.take<uint8_t>(nw * 32);
+  int frc = fill_u32(cellmap, nw * 32, 0u, stream);
   if (frc) return frc;
   if (n_cap > 0) {
-    sp_mark_outputs_kernel<<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words);
+    sp_mark_outputs_kernel<<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, cellmap);
     BEVAMD_LAUNCH_CHECK("sp_mark_outputs");
   }
-  sp_rank_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums);
+  sp_rank_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(cellmap, words, nw, tile_sums);
   BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
-  int rc = exclusive_scan_u32(tile_sums, tile_sums, nt, (uint32_t*)num_out_dev, sws, bytes - cv.off, stream);
+  int rc = exclusive_scan_u32(tile_sums, tile_sums, nt, (uint32_t*)num_out_dev, sws, sws_bytes, stream);
   if (rc) return rc;
   sp_rank_apply_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, out_cap);
   BEVAMD_LAUNCH_CHECK("sp_rank_apply");
   sp_rank_emit_kernel<<<dim3(stride_grid((long long)nw)), dim3(256), 0, stream>>>(words, nw, g, out_indices, out_cap);
   BEVAMD_LAUNCH_CHECK("sp_rank_emit");
   if (nbr) {
-    sp_nbr_clear_kernel<<<dim3(stride_grid(out_cap), g.K), dim3(256), 0, stream>>>(nbr, nbr_stride, out_cap, num_out_dev);
+    sp_nbr_clear_kernel<<<dim3(stride_grid(((long long)out_cap + 3) / 4), g.K), dim3(256), 0, stream>>>(nbr, nbr_stride, out_cap, num_out_dev, 0);
     BEVAMD_LAUNCH_CHECK("sp_nbr_clear");
     if (n_cap > 0) {
       sp_nbr_from_inputs_kernel<<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words, out_cap,
@@ -514,8 +553,21 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
 }
 
 static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const ConvGeom& g, int kind, const IndexRef& ix,
-                     int* nbr, int nbr_stride, hipStream_t stream) {
+                     int* nbr, int nbr_stride, bool subm, hipStream_t stream) {
   if (m_cap <= 0) return BEVAMD_OK;
+  const bool odd = (g.ksize[0] & 1) && (g.ksize[1] & 1) && (g.ksize[2] & 1);
+  if (subm && odd && g.K > 1) {
+    // mirrored offsets: clear the upper half, look up the lower half + centre
+    const int half = g.K / 2;
+    sp_nbr_clear_kernel<<<dim3(stride_grid(((long long)m_cap + 3) / 4), half), dim3(256), 0, stream>>>(nbr, nbr_stride, m_cap,
+                                                                                                     m_dev, half + 1);
+    BEVAMD_LAUNCH_CHECK("sp_nbr_clear");
+    dim3 grid(stride_grid(m_cap), half + 1), block(256);
+    if (kind == INDEX_HASH) sp_nbr_subm_sym_kernel<INDEX_HASH><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
+    else sp_nbr_subm_sym_kernel<INDEX_RANK><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
+    BEVAMD_LAUNCH_CHECK("sp_nbr_subm_sym");
+    return BEVAMD_OK;
+  }
   dim3 grid(stride_grid(m_cap), g.K), block(256);
   if (kind == INDEX_HASH) sp_nbr_kernel<INDEX_HASH><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
   else sp_nbr_kernel<INDEX_RANK><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
@@ -574,7 +626,7 @@ int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev,
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(out_indices && in_index && nbr, "spconv_neighbors: null buffer");
   const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(in_index, in_index_n_cap) : rank_ref(in_index);
-  return neighbors(out_indices, m_cap, m_dev, g, index_kind, ix, nbr, nbr_stride, (hipStream_t)stream_);
+  return neighbors(out_indices, m_cap, m_dev, g, index_kind, ix, nbr, nbr_stride, subm != 0, (hipStream_t)stream_);
 }
 
 int bevamd_spconv_dense_bev(const void* features, int elem_bytes, int pitch, int channels, int index_kind,
@@ -650,7 +702,7 @@ int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, cons
     BEVAMD_REQUIRE(nbr_stride >= n, "spconv_build_rulebook: nbr_stride %d < n %d", nbr_stride, n);
     rc = hash_build(indices, n, nullptr, g, ws, hbytes, stream);
     if (rc) return rc;
-    rc = neighbors(indices, n, nullptr, g, INDEX_HASH, hash_ref(ws, n), nbr, nbr_stride, stream);
+    rc = neighbors(indices, n, nullptr, g, INDEX_HASH, hash_ref(ws, n), nbr, nbr_stride, true, stream);
     if (rc) return rc;
     if (out_indices && out_indices != indices)
       BEVAMD_HIP_CHECK(hipMemcpyAsync(out_indices, indices, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToDevice, stream));

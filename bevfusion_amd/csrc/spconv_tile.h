@@ -72,6 +72,7 @@ struct Args {
   const void* residual; // [m, res_stride] 16-bit or null
   // dense tail (optional): out_dense[b][c*dz + z][x][y] = value, rows addressed through out_indices
   int feat_stride, n_in, nbr_stride, m_cap, K, cout, out_stride, res_stride, relu;
+  int row_epilogue;  // 1: cout, pitches and pointers allow the LDS-transposed 16-byte epilogue (set by the host)
 };
 
 constexpr unsigned OOB = 0x80000000u;  // buffer offset that is always out of range (feature bytes < 2 GiB)
@@ -153,11 +154,17 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int row, int col0,
   }
 }
 
+// wave-private LDS scratch of the row-wise epilogue: 16 rows x (NT*32 + 16) bytes, in u32x4 units
+template <int NT> struct EpiScratch { static constexpr int U4 = 16 * (NT * 2 + 1); };
+
 // One wave, one tile of 16*MT output rows.  The reduction runs two steps per loop trip on two register sets
 // (A/B): while set A multiplies, the rows of the next step land in set B and the indices of the step after
 // that are being fetched — no register copies, no conditional loads, so hipcc keeps counted vmcnt waits and
 // the prefetches stay in flight across the back-edge.
-template <int DT, int CINP, int NT, int MT, int CPO>
+// ABL: ablation mask for profiling builds only (tools/sweep_spconv.py --ablate): 1 = no MFMA, 2 = no row gather,
+// 4 = no filter staging, 8 = no ds_bpermute, 16 = no LDS fragment reads, 32 = no neighbour preload.  Results are wrong
+// for ABL != 0; the shipped kernels are ABL = 0.
+template <int DT, int CINP, int NT, int MT, int CPO, int ABL = 0>
 struct WaveTile {
   typedef StepShape<CINP, CPO> SS;
   static constexpr int NK = SS::NK;
@@ -169,13 +176,15 @@ struct WaveTile {
   // ds_bpermute moves the data from load layout to MFMA layout (source lane 4c + g) just before the multiply.
   int row0, m, lane, c, g, lr, lg, perm_addr;
   int* nbl;  // wave-private LDS copy of the tile's neighbour table: [K][16*MT]
+  u32x4* eps;  // wave-private LDS scratch of the row-wise epilogue
   unsigned row_bytes;
   __amdgpu_buffer_rsrc_t rs;
 
-  __device__ __forceinline__ void init(const Args& a, int row0_, int m_, int* nbl_) {
+  __device__ __forceinline__ void init(const Args& a, int row0_, int m_, int* nbl_, u32x4* eps_) {
     row0 = row0_;
     m = m_;
     nbl = nbl_;
+    eps = eps_;
     lane = threadIdx.x & 63;
     c = lane & 15;
     g = lane >> 4;
@@ -194,6 +203,10 @@ struct WaveTile {
   // step of every wave — the time of all layers was set by that chain, whatever the tiling.  Here all K*16*MT
   // loads of a tile are independent and in flight together: one latency per tile.
   __device__ __forceinline__ void preload_nb(const Args& a) {
+    if constexpr (ABL & 32) {
+      for (int i = lane; i < a.K * 16 * MT; i += 64) nbl[i] = (row0 + i) % (m > 0 ? m : 1);
+      return;
+    }
     constexpr int R = 16 * MT, UNR = 8;
     const int total = a.K * R;
     for (int base = 0; base < total; base += 64 * UNR) {
@@ -235,11 +248,14 @@ struct WaveTile {
         base[q] = valid ? (unsigned)nb[mt][q] * row_bytes : OOB;
       }
 #pragma unroll
-      for (int cc = 0; cc < CPO; ++cc)
-        dst[mt][cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, base[SS::slot_of(cc)] + SS::byte_of(cc, lg), 0, 0);
+      for (int cc = 0; cc < CPO; ++cc) {
+        if constexpr (ABL & 2) dst[mt][cc] = u32x4{base[SS::slot_of(cc)], 1u, 2u, 3u};
+        else dst[mt][cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, base[SS::slot_of(cc)] + SS::byte_of(cc, lg), 0, 0);
+      }
     }
   }
   __device__ __forceinline__ u32x4 to_mfma_layout(const u32x4& v) const {
+    if constexpr (ABL & 8) return v;
     u32x4 r;
     r.x = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)v.x);
     r.y = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)v.y);
@@ -255,7 +271,10 @@ struct WaveTile {
   __device__ __forceinline__ void fetch_chunk(const u32x4* __restrict__ wl, const u32x4 (&x)[MT][CPO], int cc,
                                               u32x4 (&b)[NT], u32x4 (&xm)[MT]) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = wl[(cc * NT + nt) * 64 + lane];
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (ABL & 16) b[nt] = u32x4{(unsigned)(cc + nt), 0x3C003C00u, 0x3C003C00u, (unsigned)lane};
+      else b[nt] = wl[(cc * NT + nt) * 64 + lane];
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xm[mt] = to_mfma_layout(x[mt][cc]);
   }
@@ -263,7 +282,16 @@ struct WaveTile {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma<DT>(b[nt], xm[mt], acc[mt][nt]);
+      for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (ABL & 1) {
+          acc[mt][nt][0] += __uint_as_float(b[nt].x ^ xm[mt].x);
+          acc[mt][nt][1] += __uint_as_float(b[nt].y ^ xm[mt].y);
+          acc[mt][nt][2] += __uint_as_float(b[nt].z ^ xm[mt].z);
+          acc[mt][nt][3] += __uint_as_float(b[nt].w ^ xm[mt].w);
+        } else {
+          acc[mt][nt] = mfma<DT>(b[nt], xm[mt], acc[mt][nt]);
+        }
+      }
   }
   __device__ __forceinline__ void multiply(const u32x4* __restrict__ wl, const u32x4 (&x)[MT][CPO]) {
     u32x4 b0[NT], b1[NT], x0[MT], x1[MT];
@@ -282,7 +310,77 @@ struct WaveTile {
       }
     }
   }
+  // Row-wise epilogue.  In the MFMA result layout a lane owns 4 channels of a row: 8-byte stores (and residual loads)
+  // 32 bytes per row segment, a quarter of an L2 line each — measured 8 us of a 40 us layer.  The tile is instead
+  // rounded to 16 bits (= the reference's stored conv result), transposed through wave-private LDS, and every lane
+  // finishes 8 consecutive channels of one row: 16-byte bias / residual loads, 16-byte stores, whole rows contiguous.
+  __device__ __forceinline__ void store_rows(const Args& a) {
+    typedef typename Num<DT>::T T;
+    constexpr int RB = NT * 32 + 16;          // padded row pitch in the scratch, bytes
+    constexpr int LPR = NT * 2;               // lanes (16-byte pieces) per row
+    constexpr int RPP = 64 / LPR > 16 ? 16 : 64 / LPR;
+    char* sc = (char*)eps;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        T p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = Num<DT>::from_f32(acc[mt][nt][j]);
+        *(uint2*)(sc + c * RB + nt * 32 + g * 8) = *(const uint2*)p;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 16 / RPP; ++pass) {
+        const int r = pass * RPP + lane / LPR, j = lane % LPR;
+        const int row = row0 + mt * 16 + r, col0 = j * 8;
+        if (lane / LPR < RPP && row < m && col0 < a.cout) {
+          const u32x4 raw = *(const u32x4*)(sc + r * RB + j * 16);
+          const T* v = (const T*)&raw;
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(v[e]);
+          if (a.bias) {
+            const u32x4 br = *(const u32x4*)((const T*)a.bias + col0);
+            const T* b = (const T*)&br;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] + Num<DT>::to_f32(b[e])));
+          }
+          if (a.scale) {
+            const float4 s0 = *(const float4*)(a.scale + col0), s1 = *(const float4*)(a.scale + col0 + 4);
+            const float4 h0 = *(const float4*)(a.shift + col0), h1 = *(const float4*)(a.shift + col0 + 4);
+            const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] * sv[e] + hv[e]));
+          }
+          if (a.residual) {
+            const u32x4 rr = *(const u32x4*)((const T*)a.residual + (size_t)row * a.res_stride + col0);
+            const T* rv = (const T*)&rr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] + Num<DT>::to_f32(rv[e])));
+          }
+          T o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = Num<DT>::from_f32(a.relu && x[e] < 0.f ? 0.f : x[e]);
+          *(u32x4*)((T*)a.out + (size_t)row * a.out_stride + col0) = *(const u32x4*)o;
+        }
+      }
+    }
+  }
   __device__ __forceinline__ void store(const Args& a) {
+    if constexpr (ABL & 64) {  // profiling: keep the accumulators alive with one store per wave
+      float t = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) t += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+      if (t == 12345.678f) ((float*)a.out)[0] = t;
+      return;
+    }
+    if (a.row_epilogue) {  // wave-uniform
+      store_rows(a);
+      return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row = row0 + mt * 16 + c;
@@ -313,9 +411,10 @@ __global__ __launch_bounds__(NW * 64) void spconv_resident_kernel(Args a) {
   const int tend = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
   const int w = threadIdx.x >> 6;
   int* nbl = (int*)(lds + total) + w * a.K * ROWS;
+  u32x4* eps = lds + total + (NW * a.K * ROWS + 3) / 4 + w * EpiScratch<NT>::U4;
   for (int t = xcd * per + bix * NW + w; t < tend; t += nxb * NW) {
     WT wt;
-    wt.init(a, t * ROWS, m, nbl);
+    wt.init(a, t * ROWS, m, nbl, eps);
     wt.preload_nb(a);
     int nbA[MT][NK], nbB[MT][NK];
     u32x4 xA[MT][CPO], xB[MT][CPO];
@@ -339,10 +438,10 @@ __global__ __launch_bounds__(NW * 64) void spconv_resident_kernel(Args a) {
 }
 
 // ---- STREAM: one step's filter fragments double-buffered in LDS ----------------------------------------
-template <int DT, int CINP, int NT, int MT, int NW, int CPO>
+template <int DT, int CINP, int NT, int MT, int NW, int CPO, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
   extern __shared__ u32x4 lds[];
-  typedef WaveTile<DT, CINP, NT, MT, CPO> WT;
+  typedef WaveTile<DT, CINP, NT, MT, CPO, ABL> WT;
   constexpr int NK = WT::NK;
   constexpr int STEP = CPO * NT * 64;                    // u32x4 per step
   constexpr int WPT = (STEP + NW * 64 - 1) / (NW * 64);  // staged u32x4 per thread
@@ -358,11 +457,13 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
   const int w = threadIdx.x >> 6;
   const u32x4* wg = (const u32x4*)a.wimg;
   WT wt;
-  wt.init(a, tb * BM + w * 16 * MT, m, (int*)(lds + 2 * STEP) + w * a.K * 16 * MT);
+  wt.init(a, tb * BM + w * 16 * MT, m, (int*)(lds + 2 * STEP) + w * a.K * 16 * MT,
+          lds + 2 * STEP + (NW * a.K * 16 * MT + 3) / 4 + w * EpiScratch<NT>::U4);
   wt.preload_nb(a);
   u32x4 wreg[WPT];
   // filter fragments of step `sc` -> registers / registers -> LDS buffer `buf`
   auto fetch_w = [&](int sc) {
+    if constexpr (ABL & 4) return;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int e = threadIdx.x + i * NW * 64;
@@ -370,6 +471,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
     }
   };
   auto put_w = [&](int buf) {
+    if constexpr (ABL & 4) return;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int e = threadIdx.x + i * NW * 64;
@@ -393,13 +495,13 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
     wt.load_nb(a, cl(s + 3), nbB);
     wt.multiply(lds, xA);  // step s from buffer 0
     put_w(1);
-    __syncthreads();
+    if constexpr (!(ABL & 128)) __syncthreads();
     fetch_w(cl(s + 2));
     wt.gather(a, cl(s + 2), nbA, xA);
     wt.load_nb(a, cl(s + 4), nbA);
     wt.multiply(lds + STEP, xB);  // step s+1 from buffer 1
     put_w(0);
-    __syncthreads();
+    if constexpr (!(ABL & 128)) __syncthreads();
   }
   if (nsteps & 1) wt.multiply(lds, xA);  // odd count: the last step sits in buffer 0
   wt.store(a);

@@ -65,6 +65,10 @@ int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_s
   a.bias = bias; a.scale = bn_scale; a.shift = bn_shift; a.residual = residual;
   a.feat_stride = feat_stride; a.n_in = num_in; a.nbr_stride = nbr_stride; a.m_cap = num_out; a.K = kernel_volume;
   a.cout = cout; a.out_stride = out_stride; a.res_stride = residual_stride; a.relu = relu;
+  // 16-byte row-wise epilogue: 8-channel groups must be whole and 16-byte aligned everywhere they are touched
+  a.row_epilogue = cout % 8 == 0 && out_stride % 8 == 0 && ((uintptr_t)out & 15) == 0 &&
+                   (!residual || (residual_stride % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                   (!bias || ((uintptr_t)bias & 15) == 0) && (!bn_scale || (((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0);
   return dtype == tile::T_F16 ? tile::launch_f16(a, cinp, nt, variant, stream) : tile::launch_bf16(a, cinp, nt, variant, stream);
 }
 

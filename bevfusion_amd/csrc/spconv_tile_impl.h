@@ -8,7 +8,7 @@ namespace tile {
 template <int DT, int CINP, int NT, int MT, int NW, int SPS>
 static int run_resident(const Args& a, hipStream_t stream) {
   constexpr int CPO = SPS * Chunks<CINP>::CPB;
-  const size_t lds = (size_t)StepShape<CINP, CPO>::nsteps(a.K) * CPO * NT * 1024 + (size_t)NW * a.K * 16 * MT * 4;
+  const size_t lds = (size_t)StepShape<CINP, CPO>::nsteps(a.K) * CPO * NT * 1024 + (size_t)(NW * a.K * 16 * MT + 3) / 4 * 16 + (size_t)NW * EpiScratch<NT>::U4 * 16;
   if (lds > 65536) {
     set_error("spconv tiled: resident variant needs %zu B of LDS (> 64 KiB)", lds);
     return BEVAMD_ERR_UNSUPPORTED;
@@ -29,7 +29,7 @@ static int run_resident(const Args& a, hipStream_t stream) {
 template <int DT, int CINP, int NT, int MT, int NW, int SPS>
 static int run_stream(const Args& a, hipStream_t stream) {
   constexpr int CPO = SPS * Chunks<CINP>::CPB;
-  const size_t lds = (size_t)2 * CPO * NT * 1024 + (size_t)NW * a.K * 16 * MT * 4;  // filter ring + neighbour tables
+  const size_t lds = (size_t)2 * CPO * NT * 1024 + (size_t)(NW * a.K * 16 * MT + 3) / 4 * 16 + (size_t)NW * EpiScratch<NT>::U4 * 16;  // filter ring + neighbour tables
   if (lds > 160 * 1024) {
     set_error("spconv tiled: stream variant needs %zu B of LDS (> 160 KiB)", lds);
     return BEVAMD_ERR_UNSUPPORTED;
@@ -64,15 +64,46 @@ constexpr bool resident_built() {
   return CINP <= 32 && NT <= 2 && 2 * MT * CPO * 4 + MT * NT * 4 <= 160;
 }
 
+// profiling only: variant 9000 + mask launches the shipped stream configuration of the 64->64 / 128->128 layers with parts
+// of the kernel compiled out (see WaveTile's ABL) — tools/sweep_spconv.py --ablate
+template <int DT, int CINP, int NT, int MT, int NW, int SPS, int ABL>
+static int run_ablation(const Args& a, hipStream_t stream) {
+  constexpr int CPO = SPS * Chunks<CINP>::CPB;
+  const size_t lds = (size_t)2 * CPO * NT * 1024 + (size_t)(NW * a.K * 16 * MT + 3) / 4 * 16 + (size_t)NW * EpiScratch<NT>::U4 * 16;
+  if (lds > 65536)
+    (void)hipFuncSetAttribute((const void*)&spconv_stream_kernel<DT, CINP, NT, MT, NW, CPO, ABL>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  constexpr int BM = NW * 16 * MT;
+  const long long blocks = ((((long long)a.m_cap + BM - 1) / BM) + 7) / 8 * 8;
+  spconv_stream_kernel<DT, CINP, NT, MT, NW, CPO, ABL><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
+  BEVAMD_LAUNCH_CHECK("spconv_stream(ablation)");
+  return BEVAMD_OK;
+}
+
 template <int DT, int CINP, int NT>
 static int run_shape(const Args& a, int variant, hipStream_t stream) {
+  if (variant >= 9000) {
+    if constexpr (DT == T_F16 && ((CINP == 64 && NT == 4) || (CINP == 128 && NT == 8))) {
+      constexpr int MT = CINP == 64 ? 2 : 1, NW = CINP == 64 ? 4 : 8;
+      switch (variant - 9000) {
+#define BEVAMD_ABL(M) case M: return run_ablation<DT, CINP, NT, MT, NW, 1, M>(a, stream)
+        BEVAMD_ABL(0); BEVAMD_ABL(1); BEVAMD_ABL(2); BEVAMD_ABL(4); BEVAMD_ABL(8); BEVAMD_ABL(16); BEVAMD_ABL(32);
+        BEVAMD_ABL(3); BEVAMD_ABL(6); BEVAMD_ABL(7); BEVAMD_ABL(24); BEVAMD_ABL(31); BEVAMD_ABL(63); BEVAMD_ABL(62);
+        BEVAMD_ABL(64); BEVAMD_ABL(127); BEVAMD_ABL(255); BEVAMD_ABL(191);
+#undef BEVAMD_ABL
+        default: break;
+      }
+    }
+    set_error("spconv tiled: ablation variant %d is not built for this shape", variant);
+    return BEVAMD_ERR_UNSUPPORTED;
+  }
   if (variant == 0) {
     // measured on MI355X over the SparseEncoder layer shapes (tools/sweep_spconv.py, profiles/r01_spconv_sweep.txt)
     const size_t img = (size_t)StepShape<CINP, Chunks<CINP>::CPB>::nsteps(a.K) * Chunks<CINP>::CPB * NT * 1024;  // unpadded image
     if (NT >= 8) variant = 2121;
     else if (CINP >= 64) variant = 2211;
     else if (CINP == 32) variant = 2212;
-    else if (resident_built<CINP, NT, 2, 1>() && img + (size_t)8 * a.K * 32 * 4 <= 65536) variant = 1221;
+    else if (resident_built<CINP, NT, 2, 1>() && img + (size_t)8 * a.K * 32 * 4 + (size_t)8 * EpiScratch<NT>::U4 * 16 <= 65536) variant = 1221;
     else variant = 2212;
   }
 #define BEVAMD_RES(MT, NW, SPS)                                                                       \

@@ -43,6 +43,7 @@ def timeit(fn, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--ablate", action="store_true", help="time the 64->64 / 128->128 SubM layers with parts of the kernel compiled out")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     dev = torch.device("cuda", 0)
@@ -74,6 +75,18 @@ def main():
         gflop = 2.0 * pairs * cin * cout / 1e9
         print(f"{name:38s} rows_in={n_in:7d} rows_out={rb.num_out:7d} pairs={pairs:8d} ({gflop:6.2f} GFLOP)")
         img_bytes = img.numel() * 2
+        if args.ablate:
+            if (cin, cout) not in ((64, 64), (128, 128)) or K != 27:
+                continue
+            names = {0: "full", 1: "no MFMA", 2: "no gather", 4: "no filter staging", 8: "no bpermute", 16: "no LDS fragment reads",
+                     32: "no nbr preload", 3: "no MFMA+gather", 6: "no gather+staging", 7: "no MFMA+gather+staging",
+                     24: "no bpermute+LDS reads", 31: "only nbr preload+epilogue+barriers", 63: "skeleton", 62: "MFMA only",
+                     64: "no epilogue stores", 127: "skeleton, no stores", 255: "skeleton, no stores, no barriers",
+                     191: "skeleton, no barriers"}
+            for mask, nm in names.items():
+                med, _ = timeit(lambda: sops.sparse_conv_tiled(f, img, rb.nbr, rb.num_out, K, cin, cout, variant=9000 + mask))
+                print(f"    ablation {mask:2d} {nm:40s}: {med:8.1f} us")
+            continue
         for v in (0,) + RES + STR:
             try:
                 med, mn = timeit(lambda: sops.sparse_conv_tiled(f, img, rb.nbr, rb.num_out, K, cin, cout, variant=v))
