@@ -40,6 +40,7 @@ _SIGNATURES = {
     "bevamd_hard_voxelize": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, Z, P]),
     "bevamd_dynamic_voxelize": (I, [P, P, P, P, I, I, I, P]),
     "bevamd_voxelize_mean": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, Z, P]),
+    "bevamd_voxel_compact": (I, [P, P, P, P, I, I, I, P, P, P, P, P]),
     # spconv
     "bevamd_spconv_rulebook_workspace_bytes": (Z, [I, I, P, I]),
     "bevamd_spconv_hash_index_bytes": (Z, [I]),

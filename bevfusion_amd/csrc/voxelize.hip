@@ -251,6 +251,26 @@ static int voxel_segments(const float* points, int n, int nfeat, const VoxGrid& 
   return BEVAMD_OK;
 }
 
+// Batch concatenation without a host sync (the `torch.cat` of bevfusion.py:189-191 needs every sample's voxel count on
+// the host): sample b's rows [0, counts[b]) of the padded slabs move to offset sum(counts[:b]) of the packed outputs.
+__global__ __launch_bounds__(256) void vox_compact_kernel(const float* __restrict__ feats, const int* __restrict__ coords,
+                                                          const int* __restrict__ sizes, const int* __restrict__ counts,
+                                                          int batch, int cap, int nfeat, float* __restrict__ out_feats,
+                                                          int* __restrict__ out_coords, int* __restrict__ out_sizes,
+                                                          int* __restrict__ total) {
+  const int b = blockIdx.y;
+  int off = 0;
+  for (int q = 0; q < b; ++q) off += min(counts[q], cap);
+  const int cnt = min(counts[b], cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && b == batch - 1) *total = off + cnt;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < cnt; r += gridDim.x * 256) {
+    const size_t src = (size_t)b * cap + r, dst = (size_t)off + r;
+    for (int f = 0; f < nfeat; ++f) out_feats[dst * nfeat + f] = feats[src * nfeat + f];
+    ((int4*)out_coords)[dst] = ((const int4*)coords)[src];
+    if (sizes && out_sizes) out_sizes[dst] = sizes[src];
+  }
+}
+
 }  // namespace bevamd
 
 using namespace bevamd;
@@ -339,6 +359,20 @@ int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* n
   BEVAMD_LAUNCH_CHECK("vox_mean");
   vox_count_kernel<<<1, 1, 0, stream>>>(vb.nseg, max_voxels, voxel_num_dev);
   BEVAMD_LAUNCH_CHECK("vox_count");
+  return BEVAMD_OK;
+}
+
+int bevamd_voxel_compact(const float* feats, const int* coords4, const int* sizes, const int* counts, int batch_size,
+                         int max_voxels, int num_features, float* out_feats, int* out_coords4, int* out_sizes,
+                         int* total_dev, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(batch_size > 0 && batch_size <= 65535 && max_voxels > 0 && num_features > 0, "voxel_compact: bad sizes");
+  BEVAMD_REQUIRE(feats && coords4 && counts && out_feats && out_coords4 && total_dev, "voxel_compact: null buffer");
+  long long blocks = ((long long)max_voxels + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  vox_compact_kernel<<<dim3((unsigned)blocks, batch_size), dim3(256), 0, stream>>>(
+      feats, coords4, sizes, counts, batch_size, max_voxels, num_features, out_feats, out_coords4, out_sizes, total_dev);
+  BEVAMD_LAUNCH_CHECK("vox_compact");
   return BEVAMD_OK;
 }
 

@@ -166,8 +166,32 @@ def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, m
             _capi.check(rc, "voxelize_mean")
     if not sync:
         return feats, coords, sizes, counts
+
     cnt = counts.tolist()  # the single host sync of the batch
     feats = torch.cat([feats[k, : cnt[k]] for k in range(B)], 0)
     coords = torch.cat([coords[k, : cnt[k]] for k in range(B)], 0)
     sizes = torch.cat([sizes[k, : cnt[k]] for k in range(B)], 0)
     return feats, coords, sizes
+
+
+@torch.no_grad()
+def voxelize_batch_device(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels):
+    """`voxelize_batch` that never touches the host: returns (feats [B*max_voxels, F], coords [B*max_voxels, 4],
+    sizes [B*max_voxels], total [1] int32 on the device) with the batch packed sample after sample in the first `total`
+    rows — what `SparseEncoder(..., num_voxels=total)` consumes on its sync-free path."""
+    lib = _capi.load()
+    feats, coords, sizes, counts = voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
+                                                  sync=False)
+    B, cap, F = feats.shape
+    if B == 1:
+        return feats[0], coords[0], sizes[0], counts
+    dev = feats.device
+    of = torch.empty((B * cap, F), dtype=torch.float32, device=dev)
+    oc = torch.empty((B * cap, 4), dtype=torch.int32, device=dev)
+    osz = torch.empty((B * cap,), dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.bevamd_voxel_compact(_capi.ptr(feats), _capi.ptr(coords), _capi.ptr(sizes), _capi.ptr(counts), B, cap, F,
+                                      _capi.ptr(of), _capi.ptr(oc), _capi.ptr(osz), _capi.ptr(total), _capi.stream_ptr(dev))
+    _capi.check(rc, "voxel_compact")
+    return of, oc, osz, total

@@ -190,6 +190,14 @@ int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* n
                          int max_voxels, int num_points, int num_features, int batch_idx,
                          int* voxel_num_dev, void* ws, size_t ws_bytes, void* stream);
 
+/* Batch concatenation of BEVFusion.voxelize (bevfusion.py:189-191) without a host sync: the padded per-sample slabs
+ * feats [batch, max_voxels, num_features], coords4 [batch, max_voxels, 4], sizes [batch, max_voxels] (optional) with the
+ * device counts [batch] written by bevamd_voxelize_mean are packed sample after sample into out_* (capacity
+ * batch*max_voxels rows); total_dev [1] receives the number of packed rows. */
+int bevamd_voxel_compact(const float* feats, const int* coords4, const int* sizes, const int* counts, int batch_size,
+                         int max_voxels, int num_features, float* out_feats, int* out_coords4, int* out_sizes,
+                         int* total_dev, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * spconv: rulebook + sparse convolution  (reference: mmdet3d/ops/spconv)
  * ------------------------------------------------------------------------- *

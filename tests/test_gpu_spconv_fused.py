@@ -173,3 +173,21 @@ def test_fused_encoder_is_graph_capturable(dev):
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_probe.py")
     r = subprocess.run([sys.executable, probe], capture_output=True, text=True, timeout=170)
     assert r.returncode == 0 and "GRAPH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_points_to_bev_batch_of_three_without_host_sync(dev):
+    """voxelize_batch_device -> fused encoder (device voxel count) == synchronised voxelize_batch -> encoder, B = 3."""
+    from bevfusion_amd.voxel import voxelize_batch, voxelize_batch_device
+
+    vs, pr = [1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 40.0, 40.0, 41.0]
+    pts = []
+    for b in range(3):
+        rng = np.random.default_rng(40 + b)
+        pts.append(torch.from_numpy((rng.random((6000 + 700 * b, 5)) * np.array([40, 40, 41, 1, 1])).astype(np.float32)).to(dev))
+    enc = _small_encoder(dev, torch.float16)
+    with torch.no_grad():
+        f0, c0, _ = voxelize_batch(pts, vs, pr, 10, 8000)
+        want = enc(f0, c0, 3)
+        f1, c1, _, tot = voxelize_batch_device(pts, vs, pr, 10, 8000)
+        got = enc(f1, c1, 3, num_voxels=tot)
+    assert tuple(got.shape) == (3, 64, 5, 5) and torch.equal(got, want)

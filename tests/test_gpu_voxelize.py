@@ -113,3 +113,21 @@ def test_flagship_size_properties(dev):
     # idempotence: voxelizing the first point of every voxel recreates the same voxels in the same order
     v3, c3, n3 = voxelization(v[:, 0, :].contiguous(), *args)
     assert torch.equal(c3, c) and torch.all(n3 == 1)
+
+
+def test_batch_packing_without_host_sync(dev):
+    """voxelize_batch_device == voxelize_batch (host-synchronised concatenation) on the live rows, for B = 1 and B = 3."""
+    from bevfusion_amd.voxel import voxelize_batch, voxelize_batch_device
+
+    vs, pr = [0.5, 0.5, 0.5], [0.0, 0.0, 0.0, 20.0, 20.0, 4.0]
+    for B in (1, 3):
+        pts = []
+        for b in range(B):
+            rng = np.random.default_rng(100 + b)
+            p = rng.random((3000 + 500 * b, 5)).astype(np.float32) * np.array([22, 22, 4.4, 1, 1], np.float32) - 1.0
+            pts.append(torch.from_numpy(p).to(dev))
+        f0, c0, s0 = voxelize_batch(pts, vs, pr, 5, 1500)
+        f1, c1, s1, tot = voxelize_batch_device(pts, vs, pr, 5, 1500)
+        n = int(tot)
+        assert n == f0.shape[0] and f1.shape[0] == B * 1500
+        assert torch.equal(f1[:n], f0) and torch.equal(c1[:n], c0) and torch.equal(s1[:n], s0)
