@@ -103,3 +103,68 @@ def test_product_has_no_oracle_import():
     for f in glob.glob(root + "/**/*.py", recursive=True):
         src = open(f).read()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_oracle_vtransform_restatements_agree_with_module_and_rig():
+    """oracle.lss_geometry (numpy) == the module's broadcasting formulation (torch CPU) == synth.get_geometry; and
+    oracle.depth_raster == the module's torch formulation on inputs without pixel collisions."""
+    import oracle
+
+    cfg = synth.CL_CONFIG
+    vt = DepthLSSTransform(256, 80, cfg["image_size"], cfg["feature_size"], cfg["xbound"], cfg["ybound"], cfg["zbound"],
+                           cfg["dbound"], downsample=2)
+    rig = synth.camera_rig(6)
+    t = lambda a: torch.from_numpy(a)[None]
+    geom = vt.get_geometry(t(rig["camera2lidar_rots"]), t(rig["camera2lidar_trans"]), t(rig["intrins"]),
+                           t(rig["post_rots"]), t(rig["post_trans"]))
+    ref = oracle.lss_geometry(vt.frustum.numpy(), rig["post_rots"][None], rig["post_trans"][None],
+                              rig["camera2lidar_rots"][None], rig["camera2lidar_trans"][None], rig["intrins"][None])
+    assert np.max(np.abs(geom.numpy() - ref)) < 2e-3
+    # depth raster: a sparse, collision-free set of points
+    rng = np.random.default_rng(0)
+    pts = np.concatenate([rng.uniform(-40, 40, (400, 2)), rng.uniform(-2, 1, (400, 1)), rng.random((400, 2))], 1).astype(np.float32)
+    c2l = np.zeros((6, 4, 4), np.float32)
+    c2l[:, :3, :3], c2l[:, :3, 3], c2l[:, 3, 3] = rig["camera2lidar_rots"], rig["camera2lidar_trans"], 1
+    K = np.zeros((6, 4, 4), np.float32)
+    K[:, :3, :3], K[:, 3, 3] = rig["intrins"], 1
+    ia = np.zeros((6, 4, 4), np.float32)
+    ia[:, :3, :3], ia[:, :3, 3], ia[:, 3, 3] = rig["post_rots"], rig["post_trans"], 1
+    l2i = (K.astype(np.float64) @ np.linalg.inv(c2l.astype(np.float64))).astype(np.float32)
+    la = np.eye(4, dtype=np.float32)
+    ref_d, winner, _, _ = oracle.depth_raster(pts, l2i, ia, la, cfg["image_size"])
+    got = vt.depth_raster(torch.zeros(1, 6, 1, 1, 1), [torch.from_numpy(pts)], torch.from_numpy(l2i)[None],
+                          torch.from_numpy(ia)[None], torch.from_numpy(la)[None])
+    assert int((ref_d > 0).sum()) > 20
+    hit = winner >= 0
+    assert np.array_equal(got[0, :, 0].numpy() > 0, hit)
+    assert np.max(np.abs(got[0, :, 0].numpy() - ref_d[:, 0])) < 1e-3
+
+
+def test_factored_cam_feats_is_the_reference_outer_product():
+    """FactoredCamFeats.materialize() == depth_lss.py:92-97 (outer product, view, permute), on CPU."""
+    from bevfusion_amd.vtransforms import FactoredCamFeats
+
+    B, N, D, C, fH, fW = 2, 3, 5, 4, 2, 3
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B * N, D + C, fH, fW, generator=g)
+    depth = x[:, :D].softmax(dim=1)
+    ref = (depth.unsqueeze(1) * x[:, D:D + C].unsqueeze(2)).view(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2)
+    fz = FactoredCamFeats(depth.view(B, N, D, fH, fW), x[:, D:D + C].view(B, N, C, fH, fW))
+    assert torch.equal(fz.materialize(), ref)
+
+
+def test_fused_encoder_path_is_gated_on_cpu_and_keeps_module_semantics():
+    """On CPU tensors / fp32 / grad-enabled the fused path must not engage (the module path then raises loudly because
+    the HIP extension has no CPU path)."""
+    import pytest
+
+    from bevfusion_amd.sparse_encoder import SparseEncoder
+    from bevfusion_amd.spconv import fused
+
+    enc = SparseEncoder(5, [16, 16, 9], order=["conv", "norm", "act"]).eval()
+    x, c = torch.randn(10, 5), torch.zeros(10, 4, dtype=torch.int32)
+    with torch.no_grad():
+        assert not fused.encoder_supported(enc, x)
+        with pytest.raises(RuntimeError, match="GPU tensor"):
+            enc(x, c, 1)
+    assert fused.INDEX_HASH == 0 and fused.INDEX_RANK == 1
