@@ -98,6 +98,12 @@ size_t scan_workspace_bytes(size_t n);
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total,
                        void* ws, size_t ws_bytes, hipStream_t stream);
 
+// Two exclusive scans of equal length n sharing their launches (in == out allowed per array).
+size_t scan_dual_workspace_bytes(size_t n);
+int exclusive_scan_u32_dual(const uint32_t* in_a, uint32_t* out_a, uint32_t* total_a, const uint32_t* in_b,
+                            uint32_t* out_b, uint32_t* total_b, size_t n, void* ws, size_t ws_bytes,
+                            hipStream_t stream);
+
 // Stable LSD radix sort of (key,value) pairs on the low `nbits` bits of the key.
 // Results land in keys_out/vals_out.  keys_in/vals_in are clobbered (used as the
 // ping-pong partner).  ws must hold radix_sort_workspace_bytes(n).

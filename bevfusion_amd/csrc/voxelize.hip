@@ -169,10 +169,28 @@ __global__ __launch_bounds__(256) void vox_mean_kernel(
   int len = (int)(seg_start[seg + 1] - (uint32_t)j);
   int cnt = len < max_points ? len : max_points;
   const float inv_cnt = (float)cnt;
-  for (int f = 0; f < nfeat; ++f) {
-    float s = 0.f;
-    for (int r = 0; r < cnt; ++r) s += points[(size_t)idx[j + r] * nfeat + f];
-    feats[(size_t)vid * nfeat + f] = __fdiv_rn(s, inv_cnt);
+  if (nfeat <= 8) {
+    // point-major walk: one index load per point, all its features accumulated in registers (same per-feature
+    // summation order as the reference's sum over the point slots: r ascending)
+    float acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = 0.f;
+#pragma unroll 2
+    for (int r = 0; r < cnt; ++r) {
+      const float* p = points + (size_t)idx[j + r] * nfeat;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        if (f < nfeat) acc[f] += p[f];
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f < nfeat) feats[(size_t)vid * nfeat + f] = __fdiv_rn(acc[f], inv_cnt);
+  } else {
+    for (int f = 0; f < nfeat; ++f) {
+      float s = 0.f;
+      for (int r = 0; r < cnt; ++r) s += points[(size_t)idx[j + r] * nfeat + f];
+      feats[(size_t)vid * nfeat + f] = __fdiv_rn(s, inv_cnt);
+    }
   }
   if (num_points_per_voxel) num_points_per_voxel[vid] = cnt;
   int cz = (int)(k % (uint32_t)g.gz);
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(256) void vox_mean_kernel(
 static size_t voxelize_ws_bytes(size_t n) {
   size_t a = align_up(n * sizeof(uint32_t), 256);
   size_t a1 = align_up((n + 1) * sizeof(uint32_t), 256);
-  size_t s1 = radix_sort_workspace_bytes(n), s2 = scan_workspace_bytes(n);
+  size_t s1 = radix_sort_workspace_bytes(n), s2 = scan_dual_workspace_bytes(n);
   // keys_a, vals_a, keys_s, idx_s, head_flag, head_scan, is_first(+scan in place), seg_start(+1), seg_vid, nseg
   return 7 * a + 2 * a1 + 256 + align_up(s1 > s2 ? s1 : s2, 256);
 }
@@ -241,9 +259,8 @@ static int voxel_segments(const float* points, int n, int nfeat, const VoxGrid& 
   if (rc) return rc;
   vox_heads_kernel<<<grid, block, 0, stream>>>(vb.keys_s, vb.idx_s, n, ncells, vb.head_flag, vb.first);
   BEVAMD_LAUNCH_CHECK("vox_heads");
-  rc = exclusive_scan_u32(vb.head_flag, vb.head_scan, (size_t)n, vb.nseg, vb.sws, vb.sws_bytes, stream);
-  if (rc) return rc;
-  rc = exclusive_scan_u32(vb.first, vb.first, (size_t)n, nullptr, vb.sws, vb.sws_bytes, stream);
+  rc = exclusive_scan_u32_dual(vb.head_flag, vb.head_scan, vb.nseg, vb.first, vb.first, nullptr, (size_t)n, vb.sws,
+                               vb.sws_bytes, stream);
   if (rc) return rc;
   vox_segments_kernel<<<grid, block, 0, stream>>>(vb.keys_s, vb.idx_s, vb.head_scan, vb.first, n, ncells,
                                                   vb.seg_start, vb.seg_vid);
