@@ -377,7 +377,8 @@ struct WaveTile {
       if (t == 12345.678f) ((float*)a.out)[0] = t;
       return;
     }
-    if (a.row_epilogue) {  // wave-uniform
+    // NT == 1: a row is 32 bytes and the tile's 16 rows are already one contiguous 512-byte store per instruction
+    if (NT >= 2 && a.row_epilogue) {  // wave-uniform
       store_rows(a);
       return;
     }

@@ -103,7 +103,10 @@ static int run_shape(const Args& a, int variant, hipStream_t stream) {
     if (NT >= 8) variant = 2121;
     else if (CINP >= 64) variant = 2211;
     else if (CINP == 32) variant = 2212;
-    else if (resident_built<CINP, NT, 2, 1>() && img + (size_t)8 * a.K * 32 * 4 + (size_t)8 * EpiScratch<NT>::U4 * 16 <= 65536) variant = 1221;
+    else if (resident_built<CINP, NT, 2, 1>() &&
+             img + (size_t)8 * a.K * 32 * 4 + (size_t)8 * EpiScratch<NT>::U4 * 16 <= 65536) variant = 1221;   // 8 waves
+    else if (resident_built<CINP, NT, 2, 1>() &&
+             img + (size_t)4 * a.K * 32 * 4 + (size_t)4 * EpiScratch<NT>::U4 * 16 <= 65536) variant = 1211;   // 4 waves
     else variant = 2212;
   }
 #define BEVAMD_RES(MT, NW, SPS)                                                                       \
