@@ -58,6 +58,8 @@ class SparseEncoder(nn.Module):
         if self.fused_inference and _fused.encoder_supported(self, voxel_features):
             try:
                 return _fused.run_encoder(self, voxel_features, coors, int(batch_size), kwargs.get("num_voxels"))
+            except _fused.NotThisCall:
+                pass                          # e.g. an empty frame: module path for this call only
             except _fused.Unfusable:
                 self.fused_inference = False  # a module tree / state the fused path does not implement
         if kwargs.get("num_voxels") is not None:

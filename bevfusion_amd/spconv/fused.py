@@ -32,6 +32,10 @@ class Unfusable(Exception):
     """The module tree / state does not match what the fused path implements; the caller falls back."""
 
 
+class NotThisCall(Exception):
+    """This particular input is left to the module path (e.g. no voxels at all); the fused path stays enabled."""
+
+
 class Level:
     """An active voxel set at one resolution: coordinates (capacity-sized), live count on the device, and an index
     that maps a cell to its row (hash for arbitrary row order, rank for ascending order)."""
@@ -259,7 +263,7 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None):
     dtype = enc.conv_input[0].weight.dtype
     n = voxel_features.shape[0]
     if n == 0:
-        raise Unfusable("empty input")
+        raise NotThisCall("empty input")
     cin = voxel_features.shape[1]
     pitch = ops.padded_channels(cin)
     feats = torch.zeros((n, pitch), dtype=dtype, device=voxel_features.device)

@@ -191,3 +191,16 @@ def test_points_to_bev_batch_of_three_without_host_sync(dev):
         f1, c1, _, tot = voxelize_batch_device(pts, vs, pr, 10, 8000)
         got = enc(f1, c1, 3, num_voxels=tot)
     assert tuple(got.shape) == (3, 64, 5, 5) and torch.equal(got, want)
+
+
+def test_empty_frame_goes_through_and_keeps_the_fused_path_enabled(dev):
+    enc = _small_encoder(dev, torch.float16)
+    with torch.no_grad():
+        out = enc(torch.zeros((0, 5), device=dev), torch.zeros((0, 4), dtype=torch.int32, device=dev), 2)
+        assert tuple(out.shape) == (2, 64, 5, 5) and float(out.abs().max()) == 0.0
+        assert enc.fused_inference
+        # a device count of zero with capacity-padded buffers: every level is empty, output is all zeros
+        xs = torch.full((100, 5), float("nan"), device=dev)
+        cs = torch.full((100, 4), 7, dtype=torch.int32, device=dev)
+        out = enc(xs, cs, 2, num_voxels=torch.zeros(1, dtype=torch.int32, device=dev))
+        assert tuple(out.shape) == (2, 64, 5, 5) and float(out.abs().max()) == 0.0 and enc.fused_inference
