@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--feat-dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--spconv-dtype", choices=["fp16", "fp32", "bf16"], default="fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU (BASELINE config 4 quotes batch 8 on one GPU)")
     ap.add_argument("--no-graph", action="store_true", help="launch the LiDAR branch kernel by kernel instead of replaying a HIP graph")
     return ap.parse_args()
 
@@ -122,10 +123,10 @@ def cpu_baseline(inp, pts, cfg, B, D, H, W):
 
     # bev_pool: 2 of the 6 cameras (a third of the frame), scaled
     n_cam = cfg["num_cameras"]
-    per_cam = inp["geom"].shape[0] // n_cam
+    per_cam = inp["geom"].shape[0] // (n_cam * B)      # the baseline times ONE frame (the first of the batch)
     sub = 2 * per_cam
     coords, kept = oracle.bev_cell_index(inp["geom"][:sub], 1, inp["origin"], inp["dx"], inp["nx"])
-    t_bev = cpu_bev_pool_quickcumsum(coords[kept], inp["feats"][:sub][kept], B, D, H, W) * (n_cam / 2.0)
+    t_bev = cpu_bev_pool_quickcumsum(coords[kept], inp["feats"][:sub][kept], 1, D, H, W) * (n_cam / 2.0)
     # voxelization + mean: the restated serial algorithm (the reference's own CPU code is memory-unsafe on the
     # non-cubic 1440x1440x40 grid)
     t0 = time.perf_counter()
@@ -165,12 +166,12 @@ def main():
 
     from bevfusion_amd import synth
     from bevfusion_amd.bev_pool import BevPoolPlan
-    from bevfusion_amd.voxel import voxelize_batch
+    from bevfusion_amd.voxel import voxelize_batch_device
 
     cfg = synth.CL_CONFIG
-    B = 1
+    B = max(1, args.batch)
     # ---- synthetic frame (per rank: its own seed -> its own features / point cloud; same calibration) ----
-    inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank)
+    inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank)   # B frames: same calibration, independent features
     H, W, D = (int(v) for v in inp["nx"])
     C = inp["channels"]
     geom = torch.from_numpy(inp["geom"]).to(dev)
@@ -178,8 +179,9 @@ def main():
     if args.feat_dtype == "bf16":
         feats = feats.bfloat16()
     elem = feats.element_size()
-    pts_np = synth.lidar_points(seed=rank)
-    pts = torch.from_numpy(pts_np).to(dev)
+    pts_all = [synth.lidar_points(seed=rank * B + b) for b in range(B)]        # one point cloud per frame
+    pts_np = pts_all[0]
+    pts_list = [torch.from_numpy(p).to(dev) for p in pts_all]
     sp_dtype = {"fp16": torch.float16, "fp32": torch.float32, "bf16": torch.bfloat16}[args.spconv_dtype]
     enc = make_encoder(cfg, dev, sp_dtype)
 
@@ -202,13 +204,13 @@ def main():
     def lidar_branch():
         # voxelize + mean into capacity-sized buffers, voxel count stays on the device (no host sync), then the
         # sparse encoder on its sync-free fused inference path
-        vf, vc, _, cnt = voxelize_batch([pts], cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                        cfg["max_voxels"][1], sync=False)
+        vf, vc, _, cnt = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
+                                               cfg["max_voxels"][1])
         mid = torch.cuda.Event(enable_timing=True) if state.get("probe") else None
         if mid is not None:
             mid.record()
         with torch.no_grad():
-            out = enc(vf[0], vc[0], B, num_voxels=cnt)
+            out = enc(vf, vc, B, num_voxels=cnt)
         return out, cnt, mid
 
     from bevfusion_amd.sharding import barrier, max_over_ranks
@@ -245,7 +247,7 @@ def main():
     # side figure (NOT part of `value`): the fused depth (x) context -> BEV op on the same plan, i.e. the
     # camera branch without the 638 MB feature volume.  Different byte denominator than bev_pool: reported on its own.
     fh, fw = cfg["feature_size"]
-    dbins = geom.shape[0] // (B * cfg["num_cameras"] * fh * fw)
+    dbins = geom.shape[0] // (B * cfg["num_cameras"] * fh * fw)  # noqa
     g = torch.Generator(device="cpu").manual_seed(7)
     depth_prob = torch.softmax(torch.randn((B * cfg["num_cameras"], dbins, fh, fw), generator=g), 1).to(dev)
     ctx_cl = torch.randn((B * cfg["num_cameras"] * fh * fw, C), generator=g).to(dev)
@@ -296,7 +298,7 @@ def main():
     elapsed = max_over_ranks(elapsed, device=dev)  # slowest rank defines the step time
 
     if rank == 0:
-        frames = args.steps * world
+        frames = args.steps * world * B
         # algorithmic bytes of the bev_pool scatter: every kept feature row read once + one
         # (geom, start, length) record per interval + every output cell written once
         alg_bytes = n_kept * C * elem + n_int * 24 + B * D * H * W * C * 4
@@ -317,6 +319,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_frame": elapsed / args.steps * 1e3 / B,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -325,10 +328,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "hot path of configs[1]+[2] (the C+L model's camera view-transform reduction and LiDAR "
-                            f"voxel pipeline), 1 frame/step/GPU: bev_pool N'={geom.shape[0]} frustum points ({n_kept} kept) "
-                            f"x C={C} -> {n_int} non-empty of {B * D * H * W} cells; hard voxelize {pts.shape[0]} points -> "
+                            f"voxel pipeline), {B} frame(s)/step/GPU: bev_pool N'={geom.shape[0]} frustum points ({n_kept} kept) "
+                            f"x C={C} -> {n_int} non-empty of {B * D * H * W} cells; hard voxelize {sum(p.shape[0] for p in pts_all)} points -> "
                             f"{state['n_voxels']} voxels; SparseEncoder 1440x1440x41 (17 SubM + 4 strided convs) -> "
-                            "[1,256,180,180]. bev_pool rank/sort/CSR precompute cached per calibration.",
+                            f"[{B},256,180,180]. bev_pool rank/sort/CSR precompute cached per calibration.",
+                "frames_per_step_per_gpu": B,
                 "stages": ["bev_pool_forward_cells", "voxelize_mean + sparse_encoder"],
                 "stage_ms": dict(zip(["bev_pool", "lidar_branch"], stage_ms)),
                 "lidar_branch_eager_ms": {"voxelize": eager_vox_ms, "sparse_encoder": eager_enc_ms},
