@@ -1,8 +1,13 @@
-"""SparseEncoder — mirror of `mmdet3d/models/backbones/sparse_encoder.py:10-217` (VoxelNet sparse 3D backbone).
+"""SparseEncoder — the VoxelNet sparse 3D backbone with the interface of `mmdet3d/models/backbones/sparse_encoder.py:10-217`.
 
-Same constructor kwargs, module tree and parameter names (`conv_input.0.weight`, `encoder_layers.encoder_layer1.0
-.conv1.weight`, ..., `conv_out.0.weight`), so reference configs build it unchanged and checkpoints load by key.
-`voxel_features` is cast to half when `fp16_enabled` is set, like mmcv's `@auto_fp16(apply_to=("voxel_features",))`.
+Constructor kwargs, attribute names, the module tree and therefore every state-dict key (`conv_input.0.weight`,
+`encoder_layers.encoder_layer1.0.conv1.weight`, ..., `conv_out.0.weight`) are the reference's, so its configs build
+this class unchanged and its checkpoints load by key.  `voxel_features` is cast to half when `fp16_enabled` is set, as
+mmcv's `@auto_fp16(apply_to=("voxel_features",))` does.
+
+Two execution paths: in eval mode with 16-bit weights and gradients off, `spconv/fused.py` runs the whole encoder
+sync-free (folded BatchNorm, device-side row counts, one gather for the dense tail); otherwise the modules run one by
+one, making the same native calls the reference makes.
 """
 import os
 
@@ -10,9 +15,11 @@ import torch
 from torch import nn
 
 from . import spconv
-from .spconv import fused as _fused
 from .registry import register_everywhere
 from .sparse_block import SparseBasicBlock, make_sparse_convmodule
+from .spconv import fused as _fused
+
+_BLOCK_TYPES = ("conv_module", "basicblock")
 
 
 class SparseEncoder(nn.Module):
@@ -21,101 +28,88 @@ class SparseEncoder(nn.Module):
                  encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
                  encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type="conv_module"):
         super().__init__()
-        assert block_type in ["conv_module", "basicblock"]
-        self.sparse_shape = sparse_shape
+        if block_type not in _BLOCK_TYPES:
+            raise AssertionError(f"block_type must be one of {_BLOCK_TYPES}")
+        if not (isinstance(order, (list, tuple)) and sorted(order) == ["act", "conv", "norm"]):
+            raise AssertionError("order must be a permutation of ('conv', 'norm', 'act')")
         self.in_channels = in_channels
+        self.sparse_shape = sparse_shape
         self.order = tuple(order)
         self.base_channels = base_channels
         self.output_channels = output_channels
         self.encoder_channels = encoder_channels
         self.encoder_paddings = encoder_paddings
-        self.stage_num = len(self.encoder_channels)
+        self.stage_num = len(encoder_channels)
         self.fp16_enabled = False
         # eval-mode 16-bit forward runs on the sync-free fused path (spconv/fused.py); set False (or
         # BEVAMD_SPCONV_FUSED=0) to force the module-by-module path that mirrors the reference call for call
         self.fused_inference = os.environ.get("BEVAMD_SPCONV_FUSED", "1") != "0"
 
-        assert isinstance(order, (list, tuple)) and len(order) == 3
-        assert set(order) == {"conv", "norm", "act"}
+        # stem: a pre-activation order keeps only the convolution here (sparse_encoder.py:62-80)
+        stem_order = self.order if self.order[0] == "conv" else ("conv",)
+        self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                 indice_key="subm1", conv_type="SubMConv3d", order=stem_order)
+        stage_out = self.make_encoder_layers(make_sparse_convmodule, norm_cfg, base_channels, block_type=block_type)
+        # head: collapses z with a (1, 1, 3) / stride (1, 1, 2) convolution (sparse_encoder.py:87-97)
+        self.conv_out = make_sparse_convmodule(stage_out, output_channels, kernel_size=(1, 1, 3), stride=(1, 1, 2),
+                                               norm_cfg=norm_cfg, padding=0, indice_key="spconv_down2",
+                                               conv_type="SparseConv3d")
 
-        if self.order[0] != "conv":  # pre activate
-            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
-                                                     indice_key="subm1", conv_type="SubMConv3d", order=("conv",))
-        else:  # post activate
-            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
-                                                     indice_key="subm1", conv_type="SubMConv3d")
-
-        encoder_out_channels = self.make_encoder_layers(make_sparse_convmodule, norm_cfg, self.base_channels,
-                                                        block_type=block_type)
-
-        self.conv_out = make_sparse_convmodule(encoder_out_channels, self.output_channels, kernel_size=(1, 1, 3),
-                                               stride=(1, 1, 2), norm_cfg=norm_cfg, padding=0,
-                                               indice_key="spconv_down2", conv_type="SparseConv3d")
-
+    # ------------------------------------------------------------------------------------------------------
     def forward(self, voxel_features, coors, batch_size, **kwargs):
-        """voxel_features [N, C]; coors [N, 4] int32 (batch_idx, x, y, z) -> [B, C*D, H, W] dense BEV features
-        (sparse_encoder.py:100-132)."""
+        """voxel_features [N, C_in]; coors [N, 4] int32 (batch, x, y, z) -> dense BEV features [B, C*D, H, W]
+        (sparse_encoder.py:100-132).  `num_voxels=` (int32 device tensor) marks capacity-padded inputs."""
+        num_voxels = kwargs.get("num_voxels")
         if self.fused_inference and _fused.encoder_supported(self, voxel_features):
             try:
-                return _fused.run_encoder(self, voxel_features, coors, int(batch_size), kwargs.get("num_voxels"))
+                return _fused.run_encoder(self, voxel_features, coors, int(batch_size), num_voxels)
             except _fused.NotThisCall:
                 pass                          # e.g. an empty frame: module path for this call only
             except _fused.Unfusable:
                 self.fused_inference = False  # a module tree / state the fused path does not implement
-        if kwargs.get("num_voxels") is not None:
-            n = int(kwargs["num_voxels"].reshape(-1)[0])  # capacity-padded inputs: the module path needs exact rows
-            voxel_features, coors = voxel_features[:n], coors[:n]
+        if num_voxels is not None:            # the module path needs exact row counts on the host
+            live = int(num_voxels.reshape(-1)[0])
+            voxel_features, coors = voxel_features[:live], coors[:live]
         if self.fp16_enabled and voxel_features.dtype == torch.float32:
             voxel_features = voxel_features.half()
-        coors = coors.int()
-        input_sp_tensor = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, int(batch_size))
-        x = self.conv_input(input_sp_tensor)
+        x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, int(batch_size))
+        x = self.conv_input(x)
+        for stage in self.encoder_layers:
+            x = stage(x)
+        dense = self.conv_out(x).dense()                       # [B, C, H, W, D]
+        b, c, h, w, d = dense.shape
+        return dense.permute(0, 1, 4, 2, 3).contiguous().view(b, c * d, h, w)
 
-        encode_features = []
-        for encoder_layer in self.encoder_layers:
-            x = encoder_layer(x)
-            encode_features.append(x)
-
-        out = self.conv_out(encode_features[-1])
-        spatial_features = out.dense()
-
-        N, C, H, W, D = spatial_features.shape
-        spatial_features = spatial_features.permute(0, 1, 4, 2, 3).contiguous()
-        spatial_features = spatial_features.view(N, C * D, H, W)
-        return spatial_features
-
+    # ------------------------------------------------------------------------------------------------------
     def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type="conv_module",
                             conv_cfg=dict(type="SubMConv3d")):
-        """sparse_encoder.py:134-217."""
-        assert block_type in ["conv_module", "basicblock"]
+        """Stages `encoder_layer{i}` (sparse_encoder.py:134-217).  conv_module: stage i > 1 OPENS with a strided
+        SparseConv3d; basicblock: every stage but the last CLOSES with one, the other entries are residual blocks."""
+        if block_type not in _BLOCK_TYPES:
+            raise AssertionError(f"block_type must be one of {_BLOCK_TYPES}")
         self.encoder_layers = spconv.SparseSequential()
-
-        for i, blocks in enumerate(self.encoder_channels):
-            blocks_list = []
-            for j, out_channels in enumerate(tuple(blocks)):
-                padding = tuple(self.encoder_paddings[i])[j]
-                if isinstance(padding, list):
-                    padding = tuple(padding)
-                # each stage started with a spconv layer except the first stage
-                if i != 0 and j == 0 and block_type == "conv_module":
-                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
-                                                  padding=padding, indice_key=f"spconv{i + 1}",
-                                                  conv_type="SparseConv3d"))
-                elif block_type == "basicblock":
-                    if j == len(blocks) - 1 and i != len(self.encoder_channels) - 1:
-                        blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
-                                                      padding=padding, indice_key=f"spconv{i + 1}",
-                                                      conv_type="SparseConv3d"))
-                    else:
-                        blocks_list.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg,
-                                                            conv_cfg=conv_cfg))
+        last_stage = len(self.encoder_channels) - 1
+        out_channels = in_channels
+        for i, widths in enumerate(self.encoder_channels):
+            widths = tuple(widths)
+            pads = tuple(self.encoder_paddings[i])
+            blocks = []
+            for j, out_channels in enumerate(widths):
+                pad = tuple(pads[j]) if isinstance(pads[j], list) else pads[j]
+                if block_type == "basicblock":
+                    downsample = j == len(widths) - 1 and i != last_stage
                 else:
-                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, padding=padding,
-                                                  indice_key=f"subm{i + 1}", conv_type="SubMConv3d"))
+                    downsample = j == 0 and i != 0
+                if downsample:
+                    blocks.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2, padding=pad,
+                                             indice_key=f"spconv{i + 1}", conv_type="SparseConv3d"))
+                elif block_type == "basicblock":
+                    blocks.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg, conv_cfg=conv_cfg))
+                else:
+                    blocks.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, padding=pad,
+                                             indice_key=f"subm{i + 1}", conv_type="SubMConv3d"))
                 in_channels = out_channels
-            stage_name = f"encoder_layer{i + 1}"
-            stage_layers = spconv.SparseSequential(*blocks_list)
-            self.encoder_layers.add_module(stage_name, stage_layers)
+            self.encoder_layers.add_module(f"encoder_layer{i + 1}", spconv.SparseSequential(*blocks))
         return out_channels
 
 

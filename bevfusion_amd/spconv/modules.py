@@ -1,16 +1,19 @@
-"""SparseModule / SparseSequential — mirror of `mmdet3d/ops/spconv/modules.py:40-139`."""
-import sys
+"""Module containers of the sparse-conv package — API of `mmdet3d/ops/spconv/modules.py:40-139` (`SparseModule`,
+`SparseSequential`, `ToDense`, `RemoveGrid`): a `SparseSequential` hands the `SparseConvTensor` itself to sparse modules
+and only `.features` to ordinary `nn.Module`s (BatchNorm1d, ReLU, ...)."""
 from collections import OrderedDict
 
-import torch
 from torch import nn
 
 from .structure import SparseConvTensor
 
 
+class SparseModule(nn.Module):
+    """Marker base class: subclasses receive the SparseConvTensor, not its feature matrix."""
+
+
 def is_spconv_module(module):
-    spconv_modules = (SparseModule,)
-    return isinstance(module, spconv_modules)
+    return isinstance(module, SparseModule)
 
 
 def is_sparse_conv(module):
@@ -19,43 +22,27 @@ def is_sparse_conv(module):
     return isinstance(module, SparseConvolution)
 
 
-class SparseModule(nn.Module):
-    """Place holder: modules deriving from it receive the SparseConvTensor itself inside SparseSequential."""
-
-    pass
-
-
 class SparseSequential(SparseModule):
-    """Sequential container: spconv modules get the sparse tensor, ordinary nn.Modules get `.features`."""
-
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *modules, **named):
         super().__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
+        if len(modules) == 1 and isinstance(modules[0], OrderedDict):
+            entries = list(modules[0].items())
         else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if sys.version_info < (3, 6):
-                raise ValueError("kwargs only supported in py36+")
+            entries = [(str(i), m) for i, m in enumerate(modules)]
+        for name, module in entries + list(named.items()):
             if name in self._modules:
                 raise ValueError("name exists.")
             self.add_module(name, module)
         self._sparity_dict = {}
 
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError("index {} is out of range".format(idx))
-        if idx < 0:
-            idx += len(self)
-        it = iter(self._modules.values())
-        for _ in range(idx):
-            next(it)
-        return next(it)
-
     def __len__(self):
         return len(self._modules)
+
+    def __getitem__(self, idx):
+        n = len(self)
+        if not -n <= idx < n:
+            raise IndexError("index {} is out of range".format(idx))
+        return list(self._modules.values())[idx % n]
 
     @property
     def sparity_dict(self):
@@ -69,22 +56,22 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        for name, module in self._modules.items():
+            sparse_in = isinstance(input, SparseConvTensor)
             if is_spconv_module(module):
-                assert isinstance(input, SparseConvTensor)
-                self._sparity_dict[k] = input.sparity
+                assert sparse_in, f"{type(module).__name__} needs a SparseConvTensor"
+                self._sparity_dict[name] = input.sparity
                 input = module(input)
+            elif sparse_in:
+                if input.indices.shape[0] != 0:     # dense modules see the [N, C] feature matrix; empty sets are skipped
+                    input.features = module(input.features)
             else:
-                if isinstance(input, SparseConvTensor):
-                    if input.indices.shape[0] != 0:
-                        input.features = module(input.features)
-                else:
-                    input = module(input)
+                input = module(input)
         return input
 
 
 class ToDense(SparseModule):
-    """SparseConvTensor -> dense NCHW tensor (modules.py ToDense)."""
+    """SparseConvTensor -> dense [B, C, *spatial]."""
 
     def forward(self, x: SparseConvTensor):
         return x.dense()
