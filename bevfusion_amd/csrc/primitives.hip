@@ -40,6 +40,21 @@ __device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigne
   return base + inc - v;
 }
 
+// Sum of sums[0 .. upto) by one 256-thread workgroup (every thread gets it).  With at most a few thousand tiles this is
+// cheaper than a separate single-workgroup scan launch between the reduce and apply passes.
+__device__ __forceinline__ unsigned block_prefix_of_tiles(const uint32_t* __restrict__ sums, unsigned upto,
+                                                          unsigned* lds_wave /*[4]*/) {
+  unsigned part = 0;
+  for (unsigned t = threadIdx.x; t < upto; t += SCAN_THREADS) part += sums[t];
+  part = (unsigned)wave_reduce_add((int)part);
+  if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const unsigned r = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+  __syncthreads();
+  return r;
+}
+constexpr size_t SCAN_INLINE_TILES_MAX = 8192;  // above this the tile sums get their own scan launch
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_reduce_kernel(const uint32_t* __restrict__ in,
                                                                         uint32_t* __restrict__ tile_sums,
                                                                         size_t n) {
@@ -98,11 +113,15 @@ __global__ __launch_bounds__(1024) void scan_single_block_kernel(const uint32_t*
   if (threadIdx.x == 0 && total) *total = carry;
 }
 
+// INLINE: tile_offsets holds the raw tile SUMS; this workgroup adds up the ones before it itself and the last workgroup
+// writes the grand total — no scan launch between the reduce and apply passes.
+template <bool INLINE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_kernel(const uint32_t* __restrict__ in,
                                                                        uint32_t* __restrict__ out,
                                                                        const uint32_t* __restrict__ tile_offsets,
-                                                                       size_t n) {
+                                                                       size_t n, uint32_t* __restrict__ total) {
   __shared__ unsigned lds_wave[4];
+  const unsigned tile_base = INLINE ? block_prefix_of_tiles(tile_offsets, blockIdx.x, lds_wave) : tile_offsets[blockIdx.x];
   // blocked arrangement: thread t owns items [t*ITEMS, t*ITEMS+ITEMS) of the tile
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   unsigned v[SCAN_ITEMS];
@@ -114,12 +133,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_kernel(const uin
   }
   unsigned tot;
   unsigned ex = block_exclusive_scan_256(s, lds_wave, &tot);
-  unsigned run = tile_offsets[blockIdx.x] + ex;
+  unsigned run = tile_base + ex;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     if (base + i < n) out[base + i] = run;
     run += v[i];
   }
+  if (INLINE && total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = tile_base + tot;
 }
 
 constexpr size_t SCAN_SINGLE_BLOCK_MAX = 1u << 14;  // above this one workgroup's serial trips cost more than two extra launches
@@ -148,9 +168,13 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* to
   uint32_t* tile_sums = (uint32_t*)ws;
   scan_tile_reduce_kernel<<<(unsigned)ntiles, SCAN_THREADS, 0, stream>>>(in, tile_sums, n);
   BEVAMD_LAUNCH_CHECK("scan_tile_reduce");
-  scan_single_block_kernel<<<1, 1024, 0, stream>>>(tile_sums, tile_sums, ntiles, total);
-  BEVAMD_LAUNCH_CHECK("scan_single_block");
-  scan_tile_apply_kernel<<<(unsigned)ntiles, SCAN_THREADS, 0, stream>>>(in, out, tile_sums, n);
+  if (ntiles <= SCAN_INLINE_TILES_MAX) {
+    scan_tile_apply_kernel<true><<<(unsigned)ntiles, SCAN_THREADS, 0, stream>>>(in, out, tile_sums, n, total);
+  } else {
+    scan_single_block_kernel<<<1, 1024, 0, stream>>>(tile_sums, tile_sums, ntiles, total);
+    BEVAMD_LAUNCH_CHECK("scan_single_block");
+    scan_tile_apply_kernel<false><<<(unsigned)ntiles, SCAN_THREADS, 0, stream>>>(in, out, tile_sums, n, nullptr);
+  }
   BEVAMD_LAUNCH_CHECK("scan_tile_apply");
   return BEVAMD_OK;
 }
@@ -213,11 +237,14 @@ __global__ __launch_bounds__(1024) void scan_single_block_dual_kernel(uint32_t* 
   if (threadIdx.x == 0 && p.total[blockIdx.x]) *p.total[blockIdx.x] = carry;
 }
 
+template <bool INLINE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_dual_kernel(ScanPair p, const uint32_t* __restrict__ tile_offsets,
                                                                             size_t ntiles, size_t n) {
   __shared__ unsigned lds_wave[4];
   const uint32_t* in = p.in[blockIdx.y];
   uint32_t* out = p.out[blockIdx.y];
+  const uint32_t* my_tiles = tile_offsets + blockIdx.y * ntiles;
+  const unsigned tile_base = INLINE ? block_prefix_of_tiles(my_tiles, blockIdx.x, lds_wave) : my_tiles[blockIdx.x];
   const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
   unsigned v[SCAN_ITEMS];
   unsigned s = 0;
@@ -228,12 +255,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_apply_dual_kernel(Scan
   }
   unsigned tot;
   unsigned ex = block_exclusive_scan_256(s, lds_wave, &tot);
-  unsigned run = tile_offsets[blockIdx.y * ntiles + blockIdx.x] + ex;
+  unsigned run = tile_base + ex;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     if (base + i < n) out[base + i] = run;
     run += v[i];
   }
+  if (INLINE && p.total[blockIdx.y] && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *p.total[blockIdx.y] = tile_base + tot;
 }
 
 size_t scan_dual_workspace_bytes(size_t n) {
@@ -257,9 +285,13 @@ int exclusive_scan_u32_dual(const uint32_t* in_a, uint32_t* out_a, uint32_t* tot
   ScanPair p{{in_a, in_b}, {out_a, out_b}, {total_a, total_b}};
   scan_tile_reduce_dual_kernel<<<dim3((unsigned)ntiles, 2), SCAN_THREADS, 0, stream>>>(p, tile_sums, ntiles, n);
   BEVAMD_LAUNCH_CHECK("scan_tile_reduce_dual");
-  scan_single_block_dual_kernel<<<2, 1024, 0, stream>>>(tile_sums, ntiles, p);
-  BEVAMD_LAUNCH_CHECK("scan_single_block_dual");
-  scan_tile_apply_dual_kernel<<<dim3((unsigned)ntiles, 2), SCAN_THREADS, 0, stream>>>(p, tile_sums, ntiles, n);
+  if (ntiles <= SCAN_INLINE_TILES_MAX) {
+    scan_tile_apply_dual_kernel<true><<<dim3((unsigned)ntiles, 2), SCAN_THREADS, 0, stream>>>(p, tile_sums, ntiles, n);
+  } else {
+    scan_single_block_dual_kernel<<<2, 1024, 0, stream>>>(tile_sums, ntiles, p);
+    BEVAMD_LAUNCH_CHECK("scan_single_block_dual");
+    scan_tile_apply_dual_kernel<false><<<dim3((unsigned)ntiles, 2), SCAN_THREADS, 0, stream>>>(p, tile_sums, ntiles, n);
+  }
   BEVAMD_LAUNCH_CHECK("scan_tile_apply_dual");
   return BEVAMD_OK;
 }

@@ -296,11 +296,20 @@ __global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint8_t* _
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
 }
 
-// exclusive popcount prefix of every bitmap word; workgroup 0 also clamps the total to the row capacity
+// exclusive popcount prefix of every bitmap word.  `tile_sums` are the raw per-tile popcounts: each workgroup adds up the
+// tiles before it itself (a few hundred values) — no scan launch in between — and the last one publishes the row count,
+// clamped to the capacity.
 __global__ __launch_bounds__(256) void sp_rank_apply_kernel(uint2* __restrict__ words, size_t nwords,
-                                                            const uint32_t* __restrict__ tile_scan, int* count,
+                                                            const uint32_t* __restrict__ tile_sums, int* count,
                                                             int out_cap) {
   __shared__ unsigned lds_wave[4];
+  unsigned part = 0;
+  for (unsigned t = threadIdx.x; t < blockIdx.x; t += 256) part += tile_sums[t];
+  part = (unsigned)wave_reduce_add((int)part);
+  if ((threadIdx.x & 63) == 0) lds_wave[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const unsigned tile_base = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
+  __syncthreads();
   constexpr int PER = RANK_TILE / 256;  // consecutive words per thread
   const size_t w0 = (size_t)blockIdx.x * RANK_TILE + (size_t)threadIdx.x * PER;
   uint32_t bits[PER];
@@ -311,13 +320,16 @@ __global__ __launch_bounds__(256) void sp_rank_apply_kernel(uint2* __restrict__ 
     s += __popc(bits[i]);
   }
   unsigned tot;
-  unsigned run = tile_scan[blockIdx.x] + block_exclusive_scan_256u(s, lds_wave, &tot);
+  unsigned run = tile_base + block_exclusive_scan_256u(s, lds_wave, &tot);
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     if (w0 + i < nwords) words[w0 + i].y = run;
     run += __popc(bits[i]);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && *count > out_cap) *count = out_cap;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const unsigned total = tile_base + tot;
+    *count = (int)(total < (unsigned)out_cap ? total : (unsigned)out_cap);
+  }
 }
 
 // coordinates of every active output, in ascending linear index: one thread per bitmap word
@@ -534,8 +546,8 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
   }
   sp_rank_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(cellmap, words, nw, tile_sums);
   BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
-  int rc = exclusive_scan_u32(tile_sums, tile_sums, nt, (uint32_t*)num_out_dev, sws, sws_bytes, stream);
-  if (rc) return rc;
+  (void)sws;
+  (void)sws_bytes;
   sp_rank_apply_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, out_cap);
   BEVAMD_LAUNCH_CHECK("sp_rank_apply");
   sp_rank_emit_kernel<<<dim3(stride_grid((long long)nw)), dim3(256), 0, stream>>>(words, nw, g, out_indices, out_cap);
