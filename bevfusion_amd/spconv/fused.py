@@ -11,13 +11,16 @@ path removes:
     that numbers a strided conv's outputs doubles as the lookup structure of the next layers;
   * zero-fill + scatter + permute copy of the dense tail                           -> one gather kernel writes
     [B, C*D, H, W] directly.
-Every kernel is launched on PyTorch's current stream and nothing reads back, so the whole encoder can be captured
-in a HIP graph (`torch.cuda.graph`).
+Nothing reads back, so the whole encoder can be captured in a HIP graph (`torch.cuda.graph`).  Rulebooks depend only on
+voxel coordinates, never on features: the whole geometry chain (hash index, every level's downsample, every neighbour
+table) is issued up front on a second HIP stream and runs underneath the convolutions of the earlier levels; each
+convolution waits on the event of the table it reads (`BEVAMD_SPCONV_GEOM_STREAM=0` keeps everything on one stream).
 
 Reference semantics followed: SparseEncoder.forward (models/backbones/sparse_encoder.py:100-132), SparseBasicBlock
 .forward (ops/sparse_block.py:88-107), SparseConvolution.forward (ops/spconv/conv.py:118-223), BatchNorm1d eval.
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -36,11 +39,29 @@ class NotThisCall(Exception):
     """This particular input is left to the module path (e.g. no voxels at all); the fused path stays enabled."""
 
 
+_GEOM_STREAMS = {}
+
+
+def geometry_stream(device):
+    """The side stream rulebook construction runs on (one per device, created on first use); None when disabled."""
+    if os.environ.get("BEVAMD_SPCONV_GEOM_STREAM", "1") == "0":
+        return None
+    key = torch.device(device).index
+    if key not in _GEOM_STREAMS:
+        _GEOM_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _GEOM_STREAMS[key]
+
+
 class Level:
     """An active voxel set at one resolution: coordinates (capacity-sized), live count on the device, and an index
-    that maps a cell to its row (hash for arbitrary row order, rank for ascending order)."""
+    that maps a cell to its row (hash for arbitrary row order, rank for ascending order).
 
-    def __init__(self, indices, n_cap, n_dev, batch, shape):
+    `gstream` (optional): the stream every rulebook kernel of this level is launched on.  Products carry the event
+    recorded behind them; `subm_neighbors` / `downsample` make the CURRENT stream wait on it before handing them out.
+    Buffers are allocated by the caller's (current-stream) allocator; `run_encoder` joins the two streams before it
+    returns, so their reuse stays ordered."""
+
+    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None):
         self.indices = indices
         self.n_cap = int(n_cap)
         self.n_dev = n_dev          # int32 device tensor [1] or None (= n_cap rows are all live)
@@ -49,12 +70,32 @@ class Level:
         self.index_kind = None
         self.index = None
         self.index_n_cap = 0
+        self.gstream = gstream
+        self.ready = None           # event behind the kernels that produced indices / n_dev / index (None: already ordered)
         self._subm = {}
         self._down = {}
 
     @property
     def device(self):
         return self.indices.device
+
+    def _stream_ptr(self):
+        if self.gstream is not None:
+            return ctypes.c_void_p(self.gstream.cuda_stream)
+        return _capi.stream_ptr(self.device)
+
+    def _mark(self):
+        """Event behind everything launched so far on the geometry stream (None on the single-stream path)."""
+        if self.gstream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.gstream)
+        return ev
+
+    @staticmethod
+    def _await(ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def ensure_index(self):
         if self.index is not None:
@@ -66,9 +107,10 @@ class Level:
             self.index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             rc = lib.bevamd_spconv_hash_index_build(_capi.ptr(self.indices), self.n_cap, _capi.ptr(self.n_dev), self.batch,
                                                     _capi.ints(self.shape), _capi.ptr(self.index), nbytes,
-                                                    _capi.stream_ptr(dev))
+                                                    self._stream_ptr())
         _capi.check(rc, "spconv_hash_index_build")
         self.index_kind, self.index_n_cap = INDEX_HASH, self.n_cap
+        self.ready = self._mark()
 
     def _neighbors(self, out_indices, m_cap, m_dev, out_shape, ksize, stride, padding, subm):
         lib = _capi.load()
@@ -80,22 +122,30 @@ class Level:
             rc = lib.bevamd_spconv_neighbors(_capi.ptr(out_indices), m_cap, _capi.ptr(m_dev), self.batch, _capi.ints(self.shape),
                                              _capi.ints(out_shape), _capi.ints(ksize), _capi.ints(stride), _capi.ints(padding),
                                              int(subm), self.index_kind, _capi.ptr(self.index), self.index_n_cap,
-                                             _capi.ptr(nbr), nbr.shape[1], _capi.stream_ptr(dev))
+                                             _capi.ptr(nbr), nbr.shape[1], self._stream_ptr())
         _capi.check(rc, "spconv_neighbors")
         return nbr
 
-    def subm_neighbors(self, ksize):
+    def subm_neighbors(self, ksize, wait=True):
+        """nbr [K, n_cap] of a submanifold convolution over this set (built once per kernel size)."""
         key = tuple(ksize)
         if key not in self._subm:
-            self._subm[key] = self._neighbors(self.indices, self.n_cap, self.n_dev, self.shape, list(ksize), [1, 1, 1],
-                                              [k // 2 for k in ksize], True)
-        return self._subm[key]
+            nbr = self._neighbors(self.indices, self.n_cap, self.n_dev, self.shape, list(ksize), [1, 1, 1],
+                                  [k // 2 for k in ksize], True)
+            self._subm[key] = (nbr, self._mark())
+        nbr, ev = self._subm[key]
+        if wait:
+            self._await(ev)
+        return nbr
 
-    def downsample(self, ksize, stride, padding):
+    def downsample(self, ksize, stride, padding, wait=True):
         """(output Level with its rank index, nbr [K, cap_out]) of a strided convolution over this set."""
         key = (tuple(ksize), tuple(stride), tuple(padding))
         if key in self._down:
-            return self._down[key]
+            out, nbr = self._down[key]
+            if wait:
+                self._await(out.ready)
+            return out, nbr
         lib = _capi.load()
         dev = self.device
         out_shape = ops.get_conv_output_size(self.shape, list(ksize), list(stride), list(padding), [1, 1, 1])
@@ -117,11 +167,14 @@ class Level:
                                               _capi.ints(self.shape), _capi.ints(out_shape), _capi.ints(ksize),
                                               _capi.ints(stride), _capi.ints(padding), _capi.ptr(out_indices), cap,
                                               _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.ptr(nbr), cap,
-                                              _capi.stream_ptr(dev))
+                                              self._stream_ptr())
         _capi.check(rc, "spconv_downsample")
-        out = Level(out_indices, cap, num_out, self.batch, out_shape)
+        out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream)
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
+        out.ready = self._mark()    # behind the downsample: indices, count, rank index and this conv's nbr are final
         self._down[key] = (out, nbr)
+        if wait:
+            self._await(out.ready)
         return out, nbr
 
 
@@ -235,6 +288,7 @@ def dense_bev(x):
     lib = _capi.load()
     lvl = x.level
     lvl.ensure_index()
+    Level._await(lvl.ready)
     C = x.features.shape[1]
     X, Y, Z = lvl.shape
     out = torch.empty((lvl.batch, C * Z, X, Y), dtype=x.features.dtype, device=x.features.device)
@@ -271,9 +325,39 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None):
     coors = coors.int().contiguous()
     if num_voxels is not None:
         num_voxels = num_voxels.reshape(-1)[:1].int().contiguous()
-    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape)
-    x = FusedTensor(feats, lvl)
-    x = _sequential(enc.conv_input, x)
-    x = _sequential(enc.encoder_layers, x)
-    x = _sequential(enc.conv_out, x)
-    return dense_bev(x)
+    dev = voxel_features.device
+    g = geometry_stream(dev)
+    main = torch.cuda.current_stream(dev)
+    if g is not None:
+        g.wait_stream(main)       # fork: coordinates / count are final, recycled buffers are quiescent
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g)
+    try:
+        if g is not None:
+            prefetch_geometry(enc, lvl)
+        x = FusedTensor(feats, lvl)
+        x = _sequential(enc.conv_input, x)
+        x = _sequential(enc.encoder_layers, x)
+        x = _sequential(enc.conv_out, x)
+        return dense_bev(x)
+    finally:
+        if g is not None:
+            main.wait_stream(g)   # join: whatever follows on this stream is ordered behind the geometry kernels
+
+
+def prefetch_geometry(enc, lvl):
+    """Issue the whole rulebook chain on the geometry stream, in module (= execution) order, without waiting for any of
+    it: hash index, SubM neighbour tables and downsamples of every level.  The feature pass then finds each product in
+    its Level's cache and waits on its event only.  A tree whose module order differs from its execution order merely
+    builds some tables later, on demand."""
+    from .conv import SparseConvolution
+
+    cur = lvl
+    for m in enc.modules():
+        if not isinstance(m, SparseConvolution) or m.conv1x1 or m.transposed or m.inverse or m.ndim != 3:
+            continue
+        if any(d != 1 for d in m.dilation):
+            continue
+        if m.subm:
+            cur.subm_neighbors(m.kernel_size, wait=False)
+        else:
+            cur, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False)
