@@ -64,6 +64,11 @@ _SIGNATURES = {
     "bevamd_spconv_conv_forward_tiled": (I, [P, I, I, I, P, P, I, I, P, I, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_wgrad_workspace_bytes": (Z, [I, I, I]),
     "bevamd_spconv_conv_wgrad": (I, [P, P, I, P, I, I, I, I, I, P, P, Z, P]),
+    # iou3d
+    "bevamd_iou3d_boxes_overlap_bev": (I, [P, I, P, I, P, P]),
+    "bevamd_iou3d_boxes_iou_bev": (I, [P, I, P, I, P, P]),
+    "bevamd_iou3d_nms_workspace_bytes": (Z, [I]),
+    "bevamd_iou3d_nms": (I, [P, I, c_float, I, P, P, P, P, Z, P]),
     # primitives
     "bevamd_scan_workspace_bytes": (Z, [Z]),
     "bevamd_exclusive_scan_u32": (I, [P, P, Z, P, P, Z, P]),

@@ -35,6 +35,26 @@ extern "C" {
 const char* bevamd_last_error(void);
 
 /* ------------------------------------------------------------------------- *
+ * iou3d  (reference: mmdet3d/ops/iou3d) — rotated boxes in the BEV plane, [x1, y1, x2, y2, angle] fp32
+ * ------------------------------------------------------------------------- */
+
+/* Replace iou3d_cuda.boxes_overlap_bev_gpu / boxes_iou_bev_gpu (iou3d.cpp:57-94 -> iou3d_kernel.cu:231-262):
+ * ans [num_a, num_b] fp32 = overlap area / IoU of every pair.  Every element is written. */
+int bevamd_iou3d_boxes_overlap_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b,
+                                   float* ans_overlap, void* stream);
+int bevamd_iou3d_boxes_iou_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou,
+                               void* stream);
+
+/* Replace iou3d_cuda.nms_gpu (normal = 0, rotated IoU) and nms_normal_gpu (normal = 1, axis-aligned IoU)
+ * (iou3d.cpp:96-180): boxes [num_boxes, 5] sorted by descending score; keep [num_boxes] int64 receives the indices
+ * of the kept boxes in order, num_out_dev [1] their number.  The suppression mask and the greedy sweep stay on the
+ * device (the reference copies the mask to the host and sweeps there); num_out_host (optional) adds the one
+ * synchronisation the reference API implies. */
+size_t bevamd_iou3d_nms_workspace_bytes(int num_boxes);
+int bevamd_iou3d_nms(const float* boxes, int num_boxes, float thresh, int normal, long long* keep, int* num_out_dev,
+                     int* num_out_host, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * bev_pool  (reference: mmdet3d/ops/bev_pool)
  * ------------------------------------------------------------------------- */
 

@@ -334,3 +334,64 @@ def depth_raster(points, lidar2image, img_aug_matrix, lidar_aug_matrix, image_si
         depth[c, 0, pix[:, 0], pix[:, 1]] = dist[c, idx]
         winner[c, pix[:, 0], pix[:, 1]] = idx
     return depth, winner, rc, on
+
+
+# --------------------------------------------------------------------------------------------
+# iou3d (mmdet3d/ops/iou3d): rotated BEV overlap / IoU / NMS
+# --------------------------------------------------------------------------------------------
+def iou3d_pairwise(boxes_a, boxes_b, mode):
+    """mode 'overlap' | 'iou' | 'iou_normal' -> [M, N] float32 (iou3d_kernel.cu:126-229, 291-299)."""
+    a = np.ascontiguousarray(boxes_a, dtype=np.float32).reshape(-1, 5)
+    b = np.ascontiguousarray(boxes_b, dtype=np.float32).reshape(-1, 5)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    lib().iou3d_pairwise(_p(a), _i64(a.shape[0]), _p(b), _i64(b.shape[0]),
+                         ctypes.c_int({"overlap": 0, "iou": 1, "iou_normal": 2}[mode]), _p(out))
+    return out
+
+
+def iou3d_nms(boxes_sorted, thresh, normal=False):
+    """Greedy NMS over boxes sorted by descending score (iou3d.cpp:96-180) -> kept indices int64."""
+    b = np.ascontiguousarray(boxes_sorted, dtype=np.float32).reshape(-1, 5)
+    keep = np.zeros(max(b.shape[0], 1), np.int64)
+    fn = lib().iou3d_nms
+    fn.restype = ctypes.c_int64
+    k = fn(_p(b), _i64(b.shape[0]), ctypes.c_float(thresh), ctypes.c_int(int(normal)), _p(keep))
+    return keep[: int(k)].copy()
+
+
+def rotated_overlap_float64(box_a, box_b):
+    """Independent check of the overlap area: Sutherland-Hodgman clipping of the two rotated rectangles in float64
+    (not the reference's algorithm; agrees with it away from degenerate contacts)."""
+    def corners(bx):
+        x1, y1, x2, y2, ang = [float(v) for v in bx]
+        cx, cy = (x1 + x2) / 2, (y1 + y2) / 2
+        c, s = np.cos(ang), np.sin(ang)
+        pts = [(x1, y1), (x2, y1), (x2, y2), (x1, y2)]
+        # rotate_around_center (iou3d_kernel.cu:109-118): x' = dx*c + dy*s, y' = -dx*s + dy*c
+        return [((px - cx) * c + (py - cy) * s + cx, -(px - cx) * s + (py - cy) * c + cy) for px, py in pts]
+
+    def area(poly):
+        return 0.5 * sum(poly[i][0] * poly[(i + 1) % len(poly)][1] - poly[(i + 1) % len(poly)][0] * poly[i][1]
+                         for i in range(len(poly)))
+
+    subj, clip = corners(box_a), corners(box_b)
+    if area(clip) < 0:
+        clip = clip[::-1]
+    for i in range(4):
+        p, q = clip[i], clip[(i + 1) % 4]
+        if not subj:
+            break
+        inside = lambda r: (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0]) >= 0  # noqa: E731
+        out = []
+        for j in range(len(subj)):
+            cur, prev = subj[j], subj[j - 1]
+            if inside(cur) != inside(prev):
+                d1 = (q[0] - p[0], q[1] - p[1])
+                d2 = (cur[0] - prev[0], cur[1] - prev[1])
+                den = d1[0] * d2[1] - d1[1] * d2[0]
+                t = ((prev[0] - p[0]) * d2[1] - (prev[1] - p[1]) * d2[0]) / den
+                out.append((p[0] + t * d1[0], p[1] + t * d1[1]))
+            if inside(cur):
+                out.append(cur)
+        subj = out
+    return abs(area(subj)) if len(subj) >= 3 else 0.0

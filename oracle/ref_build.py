@@ -6,6 +6,7 @@ Builds the REFERENCE's own native extensions for the hot path from the sources w
   voxel_layer      mmdet3d/ops/voxel/src/*        CPU + hipified GPU paths
   sparse_conv_ext  mmdet3d/ops/spconv/{src,include}  CPU functors + hipified GPU functors
   bev_pool_ext     mmdet3d/ops/bev_pool/src/*     hipified GPU kernel only (no CPU path exists)
+  iou3d_cuda       mmdet3d/ops/iou3d/src/*        hipified GPU kernels only (rotated BEV overlap / IoU / NMS)
 
 No reference source is copied into the repository: sources are staged in a temp dir (hipify writes
 `*_hip.*` files next to its inputs and /root/reference is read-only) and only the compiled .so is kept.
@@ -40,6 +41,11 @@ EXTS = {
     "bev_pool_ext": dict(
         dir="mmdet3d/ops/bev_pool",
         sources=["src/bev_pool_cpu.cpp", "src/bev_pool_cuda.cu"],
+        include=None,
+    ),
+    "iou3d_cuda": dict(
+        dir="mmdet3d/ops/iou3d",
+        sources=["src/iou3d.cpp", "src/iou3d_kernel.cu"],
         include=None,
     ),
 }
