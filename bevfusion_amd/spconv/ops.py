@@ -352,6 +352,12 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     return sparse_conv(features, filters, nbr, int(num_activate_out))
 
 
+def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
+    """ops.py:166-182: `indice_conv` with the bias added by the same kernel."""
+    nbr = _nbr_from_pairs(indice_pairs, indice_pair_num, num_activate_out, inverse)
+    return sparse_conv(features, filters, nbr, int(num_activate_out), bias=bias)
+
+
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
     """ops.py:185-211 / spconv_ops.h:363-456 -> [in_grad, filter_grad]."""
     num_out = out_bp.shape[0]
@@ -376,6 +382,17 @@ class _SparseConvExt:
     @staticmethod
     def indice_conv_half(features, filters, indice_pairs, indice_num, num_act_out, inverse, subm):
         return indice_conv(features.half(), filters.half(), indice_pairs, indice_num, num_act_out, bool(inverse), bool(subm))
+
+    @staticmethod
+    def fused_indice_conv_fp32(features, filters, bias, indice_pairs, indice_num, num_act_out, inverse, subm):
+        """all.cc:32-37 / fused_spconv_ops.h: convolution + bias in one call (here: the bias rides in the epilogue)."""
+        return fused_indice_conv(features.float(), filters.float(), bias.float(), indice_pairs, indice_num, num_act_out,
+                                 bool(inverse), bool(subm))
+
+    @staticmethod
+    def fused_indice_conv_half(features, filters, bias, indice_pairs, indice_num, num_act_out, inverse, subm):
+        return fused_indice_conv(features.half(), filters.half(), bias.half(), indice_pairs, indice_num, num_act_out,
+                                 bool(inverse), bool(subm))
 
     @staticmethod
     def indice_conv_backward_fp32(features, filters, out_grad, indice_pairs, indice_num, inverse, subm):

@@ -228,3 +228,21 @@ def test_rulebook_cache_and_indice_key_semantics(dev):
     assert tuple(dense.shape) == (1, 4, 16, 16, 8)
     got = dense[0, :, indices[:, 1], indices[:, 2], indices[:, 3]].t()
     assert torch.equal(got, o3.features)
+
+
+@pytest.mark.parametrize("dtype,fn", [(torch.float32, "fused_indice_conv_fp32"), (torch.float16, "fused_indice_conv_half")])
+def test_drop_in_fused_indice_conv_adds_bias(dev, dtype, fn):
+    """sparse_conv_ext.fused_indice_conv_* (all.cc:32-37) == indice_conv + bias."""
+    rng = np.random.default_rng(17)
+    B, shape, cin, cout = 2, (16, 14, 7), 16, 32
+    indices = _random_indices(rng, B, shape, 600)
+    ti = torch.from_numpy(indices).to(dev)
+    oi, pairs, num = spconv.get_indice_pairs(ti, B, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, 0, True, False)
+    f = torch.from_numpy(rng.standard_normal((indices.shape[0], cin)).astype(np.float32)).to(dev).to(dtype)
+    w = torch.from_numpy((rng.standard_normal((3, 3, 3, cin, cout)) * 0.1).astype(np.float32)).to(dev).to(dtype)
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev).to(dtype)
+    plain = sops.indice_conv(f, w, pairs, num, oi.shape[0], False, True)
+    fused = getattr(sops.sparse_conv_ext, fn)(f, w, b, pairs, num, oi.shape[0], 0, 1)
+    assert fused.dtype == dtype
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((fused.float() - (plain.float() + b.float())).abs().max()) <= tol
