@@ -116,6 +116,7 @@ class BevPoolPlan:
         self.order = torch.empty(n_alloc, dtype=torch.int32, device=device)
         self.cell_start = torch.empty(self.ncells + 2, dtype=torch.int32, device=device)
         self.interval_starts = self.interval_lengths = self.n_intervals_dev = self.geom_sorted = None
+        self._cell_of_point = None   # rank per frustum point in point order (built on first fused backward)
         if want_intervals:
             cap = max(min(self.n, self.ncells), 1)
             self.interval_starts = torch.empty(cap, dtype=torch.int32, device=device)
@@ -234,6 +235,39 @@ class BevPoolPlan:
         _capi.check(rc, "bev_pool_fused_forward")
         return out
 
+    def cell_of_point(self):
+        if self._cell_of_point is None:
+            lib = _capi.load()
+            cop = torch.empty(max(self.n, 1), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = lib.bevamd_bev_pool_cell_of_point(_capi.ptr(self.order), _capi.ptr(self.ranks_sorted), self.n,
+                                                       _capi.ptr(cop), _capi.stream_ptr(self.device))
+            _capi.check(rc, "bev_pool_cell_of_point")
+            self._cell_of_point = cop
+        return self._cell_of_point
+
+    def launch_fused_backward(self, out_grad, depth, ctx, depth_bins, fh, fw):
+        """(d_depth like depth, d_ctx like ctx) of `launch_fused` for fp32 context."""
+        lib = _capi.load()
+        out_grad = out_grad.contiguous().float()
+        depth, ctx = depth.contiguous(), ctx.contiguous()
+        if ctx.dtype != torch.float32:
+            raise RuntimeError("bev_pool fused backward: fp32 context only")
+        c = ctx.shape[-1]
+        d_depth = torch.empty_like(depth)
+        d_ctx = torch.empty_like(ctx)
+        cop = self.cell_of_point()
+        with torch.cuda.device(ctx.device):
+            rc = lib.bevamd_bev_pool_fused_backward(
+                _capi.ptr(out_grad), _capi.ptr(depth), _capi.ptr(ctx), _capi.ptr(cop), _capi.ptr(d_depth), _capi.ptr(d_ctx),
+                self.n, c, int(depth_bins), int(fh), int(fw), self.B, self.D, self.H, self.W, _capi.stream_ptr(ctx.device))
+        _capi.check(rc, "bev_pool_fused_backward")
+        return d_depth, d_ctx
+
+    def fused(self, depth, ctx, depth_bins, fh, fw):
+        """Differentiable fused depth (x) context -> BEV: [B, D, H, W, C] fp32 (autograd through `launch_fused_backward`)."""
+        return _FusedPool.apply(depth, ctx, self, int(depth_bins), int(fh), int(fw))
+
     def launch_backward(self, out_grad, c):
         lib = _capi.load()
         out_grad = out_grad.contiguous().float()
@@ -258,6 +292,21 @@ class _PlannedBevPool(torch.autograd.Function):
     def backward(ctx, out_grad):
         g = ctx.plan.launch_backward(out_grad, ctx.c)
         return g.to(ctx.in_dtype), None
+
+
+class _FusedPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx_, depth, ctx, plan, depth_bins, fh, fw):
+        depth32, ctx32 = depth.float().contiguous(), ctx.contiguous()
+        ctx_.plan, ctx_.dims, ctx_.dtypes = plan, (depth_bins, fh, fw), (depth.dtype, ctx.dtype)
+        ctx_.save_for_backward(depth32, ctx32)
+        return plan.launch_fused(depth32.reshape(-1), ctx32, depth_bins, fh, fw)
+
+    @staticmethod
+    def backward(ctx_, out_grad):
+        depth32, ctx32 = ctx_.saved_tensors
+        d_depth, d_ctx = ctx_.plan.launch_fused_backward(out_grad, depth32, ctx32.float(), *ctx_.dims)
+        return d_depth.to(ctx_.dtypes[0]), d_ctx.to(ctx_.dtypes[1]), None, None, None, None
 
 
 def bev_pool(feats, coords, B, D, H, W, plan=None, channels_last_view=False):

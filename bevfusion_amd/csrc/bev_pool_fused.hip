@@ -106,6 +106,80 @@ __global__ __launch_bounds__(256) void bev_pool_fused_cells_kernel(
   }
 }
 
+// ---- backward (fp32 context) ---------------------------------------------------------------------------------------
+//   d_depth[p]      = sum_c  g[cell(p), c] * ctx[pixel(p), c]           (0 for points the range mask dropped)
+//   d_ctx[pixel, c] = sum over the D frustum points p of the pixel of  depth[p] * g[cell(p), c]
+// `cell_of_point[p]` (rank of the BEV cell, or >= ncells when dropped) is the plan's sort key in point order.
+
+__device__ __forceinline__ size_t grad_cell_offset(uint32_t r, const FusedDims& s) {
+  const int gb = r % s.B; r /= s.B;
+  const int gz = r % s.D; r /= s.D;
+  const int gy = r % s.W; r /= s.W;
+  const int gx = (int)r;
+  return ((((size_t)gb * s.D + gz) * s.H + gx) * s.W + gy) * (size_t)s.C;
+}
+
+// cell_of_point[order[j]] = ranks_sorted[j]
+__global__ __launch_bounds__(256) void bev_cell_of_point_kernel(const uint32_t* __restrict__ order,
+                                                                const uint32_t* __restrict__ ranks_sorted, int n,
+                                                                uint32_t* __restrict__ cell_of_point) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) cell_of_point[order[j]] = ranks_sorted[j];
+}
+
+// one row slot (lpr lanes) per frustum point: dot product of the cell's gradient row with the pixel's context row
+__global__ __launch_bounds__(256) void bev_pool_fused_bwd_depth_kernel(
+    const float* __restrict__ out_grad, const float4* __restrict__ ctx, const uint32_t* __restrict__ cell_of_point,
+    uint32_t ncells, int n, float* __restrict__ d_depth, int lpr, int rpi, uint32_t dfhw, uint32_t fhw, FusedDims s) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t p = wave * rpi + slot;
+  const bool active = slot < rpi && p < (size_t)n;
+  float part = 0.f;
+  if (active) {
+    const uint32_t r = cell_of_point[p];
+    if (r < ncells) {
+      const float4 g = *(const float4*)(out_grad + grad_cell_offset(r, s) + (size_t)cv * 4);
+      const float4 c = ctx[(size_t)pixel_of((uint32_t)p, dfhw, fhw) * lpr + cv];
+      part = g.x * c.x + g.y * c.y + g.z * c.z + g.w * c.w;
+    }
+  }
+  // sum the lpr lanes of the slot: segmented butterfly inside the slot's lane range (every lane shuffles)
+  for (int o = 1; o < lpr; o <<= 1) {
+    const float t = __shfl_down(part, o, 64);
+    if (cv + o < lpr) part += t;
+  }
+  if (active && cv == 0) d_depth[p] = part;
+}
+
+// one row slot per context pixel: walk its D depth bins
+__global__ __launch_bounds__(256) void bev_pool_fused_bwd_ctx_kernel(
+    const float* __restrict__ out_grad, const float* __restrict__ depth, const uint32_t* __restrict__ cell_of_point,
+    uint32_t ncells, int npix, int depth_bins, float4* __restrict__ d_ctx, int lpr, int rpi, uint32_t fhw, FusedDims s) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr;
+  const int cv = lane - slot * lpr;
+  if (slot >= rpi) return;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t pix = wave * rpi + slot;
+  if (pix >= (size_t)npix) return;
+  const uint32_t cam = (uint32_t)(pix / fhw), inner = (uint32_t)(pix - (size_t)cam * fhw);
+  const size_t p0 = (size_t)cam * depth_bins * fhw + inner;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int d = 0; d < depth_bins; ++d) {
+    const size_t p = p0 + (size_t)d * fhw;
+    const uint32_t r = cell_of_point[p];
+    if (r < ncells) {
+      const float w = depth[p];
+      const float4 g = *(const float4*)(out_grad + grad_cell_offset(r, s) + (size_t)cv * 4);
+      acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y); acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
+    }
+  }
+  d_ctx[pix * lpr + cv] = acc;
+}
+
 }  // namespace bevamd
 
 using namespace bevamd;
@@ -142,6 +216,46 @@ int bevamd_bev_pool_fused_forward(const float* depth, const void* ctx, int ctx_i
     bev_pool_fused_cells_kernel<float4, 4, 4><<<grid, block, 0, stream>>>(depth, (const float4*)ctx, order, cell_start, ncells,
                                                                           out, lpr, rpi, (uint32_t)per_cam, (uint32_t)(fh * fw), s);
   BEVAMD_LAUNCH_CHECK("bev_pool_fused_cells");
+  return BEVAMD_OK;
+}
+
+/* cell_of_point [n] u32: the BEV-cell rank of every frustum point in POINT order (>= b*d*h*w for dropped points),
+ * derived from the plan (order, ranks_sorted).  Static per plan; needed by the backward only. */
+int bevamd_bev_pool_cell_of_point(const uint32_t* order, const uint32_t* ranks_sorted, int n, uint32_t* cell_of_point,
+                                  void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(n >= 0, "bev_pool_cell_of_point: n < 0");
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(order && ranks_sorted && cell_of_point, "bev_pool_cell_of_point: null buffer");
+  bev_cell_of_point_kernel<<<dim3(cdiv(n, 256)), dim3(256), 0, stream>>>(order, ranks_sorted, n, cell_of_point);
+  BEVAMD_LAUNCH_CHECK("bev_cell_of_point");
+  return BEVAMD_OK;
+}
+
+/* Backward of bevamd_bev_pool_fused_forward for fp32 context: out_grad [b,d,h,w,c] -> d_depth [n] and d_ctx [cams*fh*fw, c]
+ * (both fully written, no atomics: one row slot per frustum point / per context pixel). */
+int bevamd_bev_pool_fused_backward(const float* out_grad, const float* depth, const float* ctx,
+                                   const uint32_t* cell_of_point, float* d_depth, float* d_ctx, int n, int c,
+                                   int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(n >= 0 && c > 0 && depth_bins > 0 && fh > 0 && fw > 0 && b > 0 && d > 0 && h > 0 && w > 0,
+                 "bev_pool_fused_backward: bad sizes");
+  const long long per_cam = (long long)depth_bins * fh * fw;
+  BEVAMD_REQUIRE(n % per_cam == 0, "bev_pool_fused_backward: n=%d is not a multiple of depth_bins*fh*fw=%lld", n, per_cam);
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(out_grad && depth && ctx && cell_of_point && d_depth && d_ctx, "bev_pool_fused_backward: null buffer");
+  BEVAMD_REQUIRE(c % 4 == 0 && c / 4 <= 64 && (((uintptr_t)ctx | (uintptr_t)out_grad | (uintptr_t)d_ctx) & 15) == 0,
+                 "bev_pool_fused_backward: c=%d must be a multiple of 4 (<= 256), 16-byte aligned buffers", c);
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  const int lpr = c / 4, rpi = 64 / lpr;
+  const int npix = (int)(n / depth_bins);
+  FusedDims s{b, d, h, w, c};
+  bev_pool_fused_bwd_depth_kernel<<<dim3(cdiv(cdiv(n, rpi), 4)), dim3(256), 0, stream>>>(
+      out_grad, (const float4*)ctx, cell_of_point, ncells, n, d_depth, lpr, rpi, (uint32_t)per_cam, (uint32_t)(fh * fw), s);
+  BEVAMD_LAUNCH_CHECK("bev_pool_fused_bwd_depth");
+  bev_pool_fused_bwd_ctx_kernel<<<dim3(cdiv(cdiv(npix, rpi), 4)), dim3(256), 0, stream>>>(
+      out_grad, depth, cell_of_point, ncells, npix, depth_bins, (float4*)d_ctx, lpr, rpi, (uint32_t)(fh * fw), s);
+  BEVAMD_LAUNCH_CHECK("bev_pool_fused_bwd_ctx");
   return BEVAMD_OK;
 }
 

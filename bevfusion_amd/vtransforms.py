@@ -81,8 +81,8 @@ class BaseTransform(nn.Module):
         self.frustum = self.create_frustum()
         self.D = self.frustum.shape[0]
         self.fp16_enabled = False
-        # MI355X-native knobs (not in the reference): reuse the bev_pool precompute across frames; at inference keep
-        # depth and context factored and fold their outer product into the pooling kernel
+        # MI355X-native knobs (not in the reference): reuse the bev_pool precompute across frames; keep depth and
+        # context factored and fold their outer product into the pooling kernel, forward and backward
         self.cache_geometry = False
         self._plan = None
         self.fused_cam_feats = True
@@ -172,7 +172,7 @@ class BaseTransform(nn.Module):
                 self._plan = plan
         if factored is not None:
             ctx_cl = factored.ctx.float().permute(0, 1, 3, 4, 2).contiguous()     # [B, N, fH, fW, C] (5 MB)
-            out = plan.launch_fused(factored.depth.float().contiguous(), ctx_cl.view(-1, C), D, H, W)
+            out = plan.fused(factored.depth.float().contiguous(), ctx_cl.view(-1, C), D, H, W)   # autograd-aware
         else:
             out = plan.forward(x.reshape(Nprime, C))   # [B, nz, nx, ny, C] fp32
         out = out.permute(0, 4, 1, 2, 3)            # [B, C, nz, nx, ny] view
@@ -330,7 +330,7 @@ class LSSTransform(BaseTransform):
         x = x.view(B * N, C, fH, fW)
         x = self.depthnet(x)
         depth = x[:, : self.D].softmax(dim=1)
-        if self.fused_cam_feats and not torch.is_grad_enabled():
+        if self.fused_cam_feats:
             return FactoredCamFeats(depth.view(B, N, self.D, fH, fW), x[:, self.D: (self.D + self.C)].view(B, N, self.C, fH, fW))
         x = depth.unsqueeze(1) * x[:, self.D: (self.D + self.C)].unsqueeze(2)
         x = x.view(B, N, self.C, self.D, fH, fW)
@@ -370,7 +370,7 @@ class DepthLSSTransform(BaseDepthTransform):
         x = torch.cat([d, x], dim=1)
         x = self.depthnet(x)
         depth = x[:, : self.D].softmax(dim=1)
-        if self.fused_cam_feats and not torch.is_grad_enabled():
+        if self.fused_cam_feats:
             return FactoredCamFeats(depth.view(B, N, self.D, fH, fW), x[:, self.D: (self.D + self.C)].view(B, N, self.C, fH, fW))
         x = depth.unsqueeze(1) * x[:, self.D: (self.D + self.C)].unsqueeze(2)
         x = x.view(B, N, self.C, self.D, fH, fW)

@@ -131,10 +131,19 @@ int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* 
  *   out[cell, :] = sum over the frustum points p of the cell of  depth[p] * ctx[pixel(p), :]
  * depth [n] fp32 = softmax output flattened as [cams, depth_bins, fh, fw] (the point order of the geometry the plan was
  * built from); ctx [cams*fh*fw, c] channels-last, fp32 (ctx_is_bf16 = 0) or bf16 bits (1); order / cell_start from
- * bevamd_bev_pool_prepare[_from_geom]; out [b, d, h, w, c] fp32, every cell written once. Forward only (inference). */
+ * bevamd_bev_pool_prepare[_from_geom]; out [b, d, h, w, c] fp32, every cell written once. */
 int bevamd_bev_pool_fused_forward(const float* depth, const void* ctx, int ctx_is_bf16, const uint32_t* order,
                                   const uint32_t* cell_start, float* out, int n, int c, int depth_bins, int fh,
                                   int fw, int b, int d, int h, int w, void* stream);
+
+/* Backward of the fused op (fp32 context): d_depth [n] = sum_c out_grad[cell(p), c] * ctx[pixel(p), c] (0 for dropped
+ * points), d_ctx [cams*fh*fw, c] = sum over the depth bins of a pixel of depth[p] * out_grad[cell(p), :]; both fully
+ * written, no atomics.  cell_of_point [n] (rank per point in POINT order) comes from bevamd_bev_pool_cell_of_point. */
+int bevamd_bev_pool_cell_of_point(const uint32_t* order, const uint32_t* ranks_sorted, int n, uint32_t* cell_of_point,
+                                  void* stream);
+int bevamd_bev_pool_fused_backward(const float* out_grad, const float* depth, const float* ctx,
+                                   const uint32_t* cell_of_point, float* d_depth, float* d_ctx, int n, int c,
+                                   int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream);
 
 /* Tuning hook of the same kernel family (bench sweeps only): variant 0 = shipped default,
  * 1/2 = one wave per cell (4/8 loads in flight), 3..7 = workgroup-cooperative flavours. */

@@ -271,3 +271,39 @@ def test_fused_rejects_bad_inputs(dev):
         plan.launch_fused(torch.zeros(24, device=dev), torch.zeros((5, 8), device=dev), 4, 2, 3)
     with pytest.raises(RuntimeError, match="multiple of"):
         plan.launch_fused(torch.zeros(24, device=dev), torch.zeros((6, 6), device=dev), 4, 2, 3)
+
+
+def test_fused_depth_context_backward_vs_float64_and_unfused_autograd(dev):
+    """d depth / d context of the fused op against float64 formulas and against autograd through the materialised
+    outer product + the unfused native op (same plan)."""
+    rng = np.random.default_rng(9)
+    cams, D, fh, fw, c = 3, 6, 4, 5, 80
+    B, Dz, H, W = 1, 1, 8, 9
+    n = cams * D * fh * fw
+    coords = np.stack([rng.integers(-1, H + 1, n), rng.integers(-1, W + 1, n), np.zeros(n, np.int64), np.zeros(n, np.int64)], 1)
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)
+    depth = torch.from_numpy(rng.random((cams, D, fh, fw)).astype(np.float32)).to(dev).requires_grad_(True)
+    ctx = torch.from_numpy(rng.standard_normal((cams * fh * fw, c)).astype(np.float32)).to(dev).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((B, Dz, H, W, c)).astype(np.float32)).to(dev)
+    out = plan.fused(depth, ctx, D, fh, fw)
+    out.backward(g)
+    # float64 reference
+    p = np.arange(n)
+    pix = (p // (D * fh * fw)) * fh * fw + (p % (D * fh * fw)) % (fh * fw)
+    ok = (coords[:, 0] >= 0) & (coords[:, 0] < H) & (coords[:, 1] >= 0) & (coords[:, 1] < W)
+    gn, cn, dn = g.cpu().numpy().astype(np.float64), ctx.detach().cpu().numpy().astype(np.float64), depth.detach().cpu().numpy().reshape(-1).astype(np.float64)
+    grow = np.zeros((n, c))
+    grow[ok] = gn[0, 0, coords[ok, 0], coords[ok, 1]]
+    want_dd = (grow * cn[pix]).sum(1)
+    want_dc = np.zeros_like(cn)
+    np.add.at(want_dc, pix, dn[:, None] * grow)
+    assert np.max(np.abs(depth.grad.cpu().numpy().reshape(-1) - want_dd)) <= 1e-4
+    assert np.max(np.abs(ctx.grad.cpu().numpy() - want_dc)) <= 1e-4
+    # autograd through the reference formulation: outer product -> unfused op
+    d2 = depth.detach().clone().requires_grad_(True)
+    c2 = ctx.detach().clone().requires_grad_(True)
+    rows = (d2.reshape(cams, D, fh * fw, 1) * c2.reshape(cams, 1, fh * fw, c)).reshape(n, c)
+    out2 = plan.forward(rows)
+    out2.backward(g)
+    assert float((out - out2).detach().abs().max()) <= 1e-4
+    assert float((depth.grad - d2.grad).abs().max()) <= 1e-4 and float((ctx.grad - c2.grad).abs().max()) <= 1e-4
