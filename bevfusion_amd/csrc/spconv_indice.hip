@@ -31,9 +31,32 @@ namespace bevamd {
 constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;
 
 struct ConvGeom {
-  int in_shape[3], out_shape[3], ksize[3], stride[3], pad[3];
+  int in_shape[3], out_shape[3], ksize[3], stride[3], pad[3], dil[3];
   int batch, K;
+  int transpose;  // 1: out = in*stride - pad + k*dil (geometry.h:86-141) instead of in = out*stride - pad + k*dil
 };
+
+// The two coordinate maps of one axis.  `scatter` runs the relation  dst*stride - pad + k*dil == src  backwards (dst from
+// src: the division must be exact), `reach` runs it forwards.  A regular convolution reaches inputs from outputs and
+// scatters inputs to outputs; a transposed one does the opposite.
+__device__ __forceinline__ bool axis_scatter(const ConvGeom& g, int a, int src, int k, int dst_size, int& dst) {
+  const int t = src + g.pad[a] - k * g.dil[a];
+  if (t < 0 || t % g.stride[a]) return false;
+  dst = t / g.stride[a];
+  return dst < dst_size;
+}
+__device__ __forceinline__ bool axis_reach(const ConvGeom& g, int a, int src, int k, int dst_size, int& dst) {
+  dst = src * g.stride[a] - g.pad[a] + k * g.dil[a];
+  return dst >= 0 && dst < dst_size;
+}
+// output cell fed by input coordinate `in` through kernel tap k, on axis a
+__device__ __forceinline__ bool axis_in_to_out(const ConvGeom& g, int a, int in, int k, int& out) {
+  return g.transpose ? axis_reach(g, a, in, k, g.out_shape[a], out) : axis_scatter(g, a, in, k, g.out_shape[a], out);
+}
+// input cell read by output coordinate `out` through kernel tap k, on axis a
+__device__ __forceinline__ bool axis_out_to_in(const ConvGeom& g, int a, int out, int k, int& in) {
+  return g.transpose ? axis_scatter(g, a, out, k, g.in_shape[a], in) : axis_reach(g, a, out, k, g.in_shape[a], in);
+}
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
   k ^= k >> 16; k *= 0x7feb352dU; k ^= k >> 15; k *= 0x846ca68bU; k ^= k >> 16;
@@ -122,11 +145,9 @@ __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out
   const int kx = k / (g.ksize[2] * g.ksize[1]);
   for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) {
     const int4 c = ((const int4*)out_indices)[o];
-    const int ix_ = c.y * g.stride[0] - g.pad[0] + kx;
-    const int iy = c.z * g.stride[1] - g.pad[1] + ky;
-    const int iz = c.w * g.stride[2] - g.pad[2] + kz;
+    int ix_, iy, iz;
     int r = -1;
-    if (ix_ >= 0 && ix_ < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && iz >= 0 && iz < g.in_shape[2]) {
+    if (axis_out_to_in(g, 0, c.y, kx, ix_) && axis_out_to_in(g, 1, c.z, ky, iy) && axis_out_to_in(g, 2, c.w, kz, iz)) {
       uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
       r = index_lookup<KIND>(ix, key);
     }
@@ -146,20 +167,12 @@ __global__ __launch_bounds__(256) void sp_nbr_from_inputs_kernel(const int* __re
   for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
     const int4 c = ((const int4*)indices)[j];
     for (int kx = 0; kx < g.ksize[0]; ++kx) {
-      int tx = c.y + g.pad[0] - kx;
-      if (tx < 0 || tx % g.stride[0]) continue;
-      int ox = tx / g.stride[0];
-      if (ox >= g.out_shape[0]) continue;
+      int ox, oy, oz;
+      if (!axis_in_to_out(g, 0, c.y, kx, ox)) continue;
       for (int ky = 0; ky < g.ksize[1]; ++ky) {
-        int ty = c.z + g.pad[1] - ky;
-        if (ty < 0 || ty % g.stride[1]) continue;
-        int oy = ty / g.stride[1];
-        if (oy >= g.out_shape[1]) continue;
+        if (!axis_in_to_out(g, 1, c.z, ky, oy)) continue;
         for (int kz = 0; kz < g.ksize[2]; ++kz) {
-          int tz = c.w + g.pad[2] - kz;
-          if (tz < 0 || tz % g.stride[2]) continue;
-          int oz = tz / g.stride[2];
-          if (oz >= g.out_shape[2]) continue;
+          if (!axis_in_to_out(g, 2, c.w, kz, oz)) continue;
           uint32_t key = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
           const int row = rank_lookup(out_words, key);
           if (row >= 0 && row < m_cap) nbr[(size_t)((kx * g.ksize[1] + ky) * g.ksize[2] + kz) * nbr_stride + row] = j;
@@ -228,20 +241,12 @@ __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restr
   for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
     const int4 c = ((const int4*)indices)[j];
     for (int kx = 0; kx < g.ksize[0]; ++kx) {
-      int tx = c.y + g.pad[0] - kx;
-      if (tx < 0 || tx % g.stride[0]) continue;
-      int ox = tx / g.stride[0];
-      if (ox >= g.out_shape[0]) continue;
+      int ox, oy, oz;
+      if (!axis_in_to_out(g, 0, c.y, kx, ox)) continue;
       for (int ky = 0; ky < g.ksize[1]; ++ky) {
-        int ty = c.z + g.pad[1] - ky;
-        if (ty < 0 || ty % g.stride[1]) continue;
-        int oy = ty / g.stride[1];
-        if (oy >= g.out_shape[1]) continue;
+        if (!axis_in_to_out(g, 1, c.z, ky, oy)) continue;
         for (int kz = 0; kz < g.ksize[2]; ++kz) {
-          int tz = c.w + g.pad[2] - kz;
-          if (tz < 0 || tz % g.stride[2]) continue;
-          int oz = tz / g.stride[2];
-          if (oz >= g.out_shape[2]) continue;
+          if (!axis_in_to_out(g, 2, c.w, kz, oz)) continue;
           cellmap[(size_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz)] = 1;
         }
       }
@@ -434,12 +439,14 @@ __global__ __launch_bounds__(256) void sp_dense_bev_kernel(const T* __restrict__
 }
 
 static int make_geom(int batch, const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
-                     const int* pad, const int* dil, int subm, ConvGeom& g) {
+                     const int* pad, const int* dil, int subm, ConvGeom& g, int transpose = 0) {
   BEVAMD_REQUIRE(in_shape && out_shape && ksize && stride && pad, "spconv: null geometry (host pointers)");
   g.batch = batch;
   g.K = 1;
+  g.transpose = (transpose && !subm) ? 1 : 0;  // the SubM functors ignore the flag (indice.cu.h:147-203)
   for (int i = 0; i < 3; ++i) {
-    BEVAMD_REQUIRE(!dil || dil[i] == 1, "spconv: dilation != 1 is not supported");
+    g.dil[i] = dil ? dil[i] : 1;
+    BEVAMD_REQUIRE(g.dil[i] > 0, "spconv: dilation must be > 0 on axis %d", i);
     g.in_shape[i] = in_shape[i];
     g.ksize[i] = ksize[i];
     g.stride[i] = subm ? 1 : stride[i];
@@ -463,9 +470,10 @@ static uint32_t hash_capacity(size_t n) {
   return cap;
 }
 
-static int conv_bound(const ConvGeom& g) {
+static int conv_bound(const ConvGeom& g) {  // outputs one input can activate
   int b = 1;
-  for (int i = 0; i < 3; ++i) b *= (g.ksize[i] + g.stride[i] - 1) / g.stride[i];
+  for (int i = 0; i < 3; ++i)
+    b *= (g.transpose || g.dil[i] != 1) ? g.ksize[i] : (g.ksize[i] + g.stride[i] - 1) / g.stride[i];
   return b;
 }
 
@@ -568,7 +576,8 @@ static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const 
                      int* nbr, int nbr_stride, bool subm, hipStream_t stream) {
   if (m_cap <= 0) return BEVAMD_OK;
   const bool odd = (g.ksize[0] & 1) && (g.ksize[1] & 1) && (g.ksize[2] & 1);
-  if (subm && odd && g.K > 1) {
+  const bool undilated = g.dil[0] == 1 && g.dil[1] == 1 && g.dil[2] == 1;  // pad = k/2 centres the window only then
+  if (subm && odd && undilated && g.K > 1) {
     // mirrored offsets: clear the upper half, look up the lower half + centre
     const int half = g.K / 2;
     sp_nbr_clear_kernel<<<dim3(stride_grid(((long long)m_cap + 3) / 4), half), dim3(256), 0, stream>>>(nbr, nbr_stride, m_cap,
@@ -686,14 +695,24 @@ int bevamd_spconv_max_outputs(int n, const int* ksize, const int* stride, int su
   return m > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (int)m;
 }
 
+/* same bound for any dilation / a transposed convolution (one input reaches at most prod(ksize) outputs then) */
+int bevamd_spconv_max_outputs_ex(int n, const int* ksize, const int* stride, const int* dilation, int subm, int transpose) {
+  if (subm) return n;
+  long long bound = 1;
+  for (int i = 0; i < 3; ++i)
+    bound *= (transpose || (dilation && dilation[i] != 1)) ? ksize[i] : (ksize[i] + stride[i] - 1) / stride[i];
+  long long m = (long long)n * bound;
+  return m > 0x7FFFFFF0ll ? 0x7FFFFFF0 : (int)m;
+}
+
 int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, const int* in_shape,
                                  const int* out_shape, const int* ksize, const int* stride, const int* padding,
-                                 const int* dilation, int subm, int* out_indices, int out_cap, int* nbr,
+                                 const int* dilation, int subm, int transpose, int* out_indices, int out_cap, int* nbr,
                                  int nbr_stride, int* num_out_dev, int* num_out_host, void* ws, size_t ws_bytes,
                                  void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ConvGeom g;
-  int rc = make_geom(batch_size, in_shape, out_shape, ksize, stride, padding, dilation, subm, g);
+  int rc = make_geom(batch_size, in_shape, out_shape, ksize, stride, padding, dilation, subm, g, transpose);
   if (rc) return rc;
   BEVAMD_REQUIRE(n >= 0, "spconv_build_rulebook: n < 0");
   BEVAMD_REQUIRE(num_out_dev != nullptr, "spconv_build_rulebook: num_out_dev is null");

@@ -50,6 +50,7 @@ class IndiceData:
         self.rulebook = rulebook
         self.in_indices = in_indices
         self.in_spatial_shape = in_spatial_shape
+        self.inverse = None   # rulebook of the coupled inverse convolution, built on first use
 
     def _tuple(self):
         pairs, num = self.rulebook.indice_pairs()
@@ -118,20 +119,29 @@ class SparseConvolution(SparseModule):
     def _geometry_key(self, input):
         ind = input.indices
         return ("__geom__", ind.data_ptr(), ind.shape[0], tuple(input.spatial_shape), tuple(self.kernel_size),
-                tuple(self.stride), tuple(self.padding), tuple(self.dilation), bool(self.subm))
+                tuple(self.stride), tuple(self.padding), tuple(self.dilation), bool(self.subm), bool(self.transposed),
+                tuple(self.output_padding))
 
     def get_rulebook(self, input):
-        if self.transposed or self.inverse:
-            raise NotImplementedError("transposed / inverse sparse convolutions are not implemented "
-                                      "(no BEVFusion config uses them)")
+        if self.ndim not in (2, 3):
+            raise NotImplementedError(f"{self.ndim}D sparse convolution is not implemented (2D and 3D are)")
         datas = input.find_indice_pair(self.indice_key)
+        if self.inverse:
+            # the coupled convolution's pairs with inputs and outputs swapped (conv.py:153-158)
+            assert datas is not None and self.indice_key is not None
+            rb = datas.rulebook
+            assert rb.kernel_volume == int(np.prod(self.kernel_size)), \
+                "inverse conv must have same kernel size as its couple conv"
+            if datas.inverse is None:
+                datas.inverse = ops.inverse_rulebook(rb, datas.in_indices, datas.in_spatial_shape)
+            return datas.inverse
         if self.indice_key is not None and datas is not None:
             return datas.rulebook
         gkey = self._geometry_key(input)
         datas = input.indice_dict.get(gkey)
         if datas is None:
             rb = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size, self.stride,
-                                    self.padding, self.dilation, self.subm)
+                                    self.padding, self.dilation, self.subm, self.transposed, self.output_padding)
             datas = IndiceData(rb, input.indices, input.spatial_shape)
             input.indice_dict[gkey] = datas
         if self.indice_key is not None:
@@ -150,19 +160,71 @@ class SparseConvolution(SparseModule):
             out_tensor.grid = input.grid
             return out_tensor
         rb = self.get_rulebook(input)
-        out_features = Fsp.rulebook_conv(features, self.weight, rb)
-        if self.bias is not None:
-            out_features = out_features + self.bias.to(out_features.dtype)
+        if self.fused_bn:
+            # conv.py:184-195: bias folded into the convolution call, no autograd (the reference's has none either)
+            assert self.bias is not None
+            out_features = ops.sparse_conv(features, self.weight, rb.conv_tables()[0], rb.num_out, bias=self.bias)
+        else:
+            out_features = Fsp.rulebook_conv(features, self.weight, rb)
+            if self.bias is not None:
+                out_features = out_features + self.bias.to(out_features.dtype)
         out_tensor = SparseConvTensor(out_features, rb.out_indices, rb.out_spatial_shape, input.batch_size)
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid
         return out_tensor
 
 
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
 class SparseConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  indice_key=None):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SparseConv4d(SparseConvolution):
+    """Constructible (configs and checkpoints keep loading); forward raises — there is no 4D rulebook here."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(4, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SparseConvTranspose2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         transposed=True, indice_key=indice_key)
+
+
+class SparseConvTranspose3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         transposed=True, indice_key=indice_key)
+
+
+class SparseInverseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(2, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
                          indice_key=indice_key)
 
 
@@ -173,5 +235,16 @@ class SubMConv3d(SparseConvolution):
                          indice_key=indice_key)
 
 
-register_everywhere("conv", SparseConv3d)
-register_everywhere("conv", SubMConv3d)
+class SubMConv4d(SparseConvolution):
+    """Constructible only, like SparseConv4d."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(4, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+# the reference registers exactly these ten classes in mmcv's CONV_LAYERS (conv.py:226-455)
+for _cls in (SparseConv2d, SparseConv3d, SparseConv4d, SparseConvTranspose2d, SparseConvTranspose3d, SparseInverseConv2d,
+             SparseInverseConv3d, SubMConv2d, SubMConv3d, SubMConv4d):
+    register_everywhere("conv", _cls)

@@ -30,15 +30,14 @@ class RulebookConvFunction(Function):
     def forward(ctx, features, filters, rulebook):
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, filters)
-        return ops.sparse_conv(features, filters, rulebook.nbr, rulebook.num_out)
+        return ops.sparse_conv(features, filters, rulebook.conv_tables()[0], rulebook.num_out)
 
     @staticmethod
     @custom_bwd
     def backward(ctx, grad_output):
         features, filters = ctx.saved_tensors
-        rb = ctx.rulebook
-        in_grad, f_grad = ops.sparse_conv_backward(features, filters, grad_output, rb.nbr, rb.nbr_transposed(),
-                                                   features.shape[0])
+        nbr, nbr_t = ctx.rulebook.conv_tables()
+        in_grad, f_grad = ops.sparse_conv_backward(features, filters, grad_output, nbr, nbr_t, features.shape[0])
         return in_grad, f_grad.to(filters.dtype), None
 
 
@@ -101,7 +100,41 @@ class SubMConvFunction(_PairsConvFunction):
         return SubMConvFunction._bwd(ctx, grad_output)
 
 
+class SparseMaxPoolFunction(Function):
+    """functional.py:100-121 on reference-shaped pairs."""
+
+    @staticmethod
+    def forward(ctx, features, indice_pairs, indice_pair_num, num_activate_out):
+        out = ops.indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out)
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, out = ctx.saved_tensors
+        input_bp = ops.indice_maxpool_backward(features, out, grad_output, indice_pairs, indice_pair_num)
+        return input_bp, None, None, None
+
+
+class RulebookMaxPoolFunction(Function):
+    """Native entry of the pooling modules: carries the output-stationary table instead of pair lists."""
+
+    @staticmethod
+    def forward(ctx, features, rulebook):
+        out = ops.sparse_maxpool(features, rulebook.nbr, rulebook.num_out)
+        ctx.rulebook = rulebook
+        ctx.save_for_backward(features, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        features, out = ctx.saved_tensors
+        return ops.sparse_maxpool_backward(features, out, grad_output, ctx.rulebook.nbr_transposed()), None
+
+
 indice_conv = SparseConvFunction.apply
 indice_inverse_conv = SparseInverseConvFunction.apply
 indice_subm_conv = SubMConvFunction.apply
+indice_maxpool = SparseMaxPoolFunction.apply
 rulebook_conv = RulebookConvFunction.apply
+rulebook_maxpool = RulebookMaxPoolFunction.apply

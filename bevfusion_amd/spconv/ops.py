@@ -65,7 +65,10 @@ class Rulebook:
     nbr [K, stride] int32: nbr[k, o] = input row feeding output row o through kernel offset k, or -1.
     `indice_pairs()` materialises the reference-shaped arrays on demand."""
 
-    def __init__(self, out_indices, nbr, num_out, num_in, kernel_volume, subm, out_spatial_shape):
+    def __init__(self, out_indices, nbr, num_out, num_in, kernel_volume, subm, out_spatial_shape, symmetric=None):
+        # symmetric: offset k of row o reads row i  <=>  offset K-1-k of row i reads row o.  True for a SubM
+        # rulebook with odd kernel sizes and no dilation (padding k/2 centres the window only then).
+        self.symmetric = bool(subm) if symmetric is None else bool(symmetric)
         self.out_indices = out_indices
         self.nbr = nbr
         self.num_out = int(num_out)
@@ -75,15 +78,29 @@ class Rulebook:
         self.out_spatial_shape = list(out_spatial_shape)
         self._nbr_t = None
         self._pairs = None
+        self._conv_tables = None
 
     @property
     def nbr_stride(self):
         return self.nbr.shape[1]
 
+    def conv_tables(self):
+        """(nbr, nbr_t) the convolution kernels walk.  They are the rulebook itself except for a SubM rulebook without
+        the mirror symmetry (dilated, or even kernel sizes), where the reference's identity shortcut is applied to the
+        offset with the most pairs (see `_subm_shortcut_`) so that results match its indice_subm_conv."""
+        if not self.subm or self.symmetric:
+            return self.nbr, self.nbr_transposed()
+        if self._conv_tables is None:
+            counts = (self.nbr[:, :max(self.num_out, 1)] >= 0).sum(1)
+            nbr = _subm_shortcut_(self.nbr.clone(), counts, self.num_out)
+            nbr_t = _subm_shortcut_(self.nbr_transposed().clone(), counts, self.num_in)
+            self._conv_tables = (nbr, nbr_t)
+        return self._conv_tables
+
     def nbr_transposed(self):
         """Input-stationary view (rows = inputs) for the input-gradient pass."""
         if self._nbr_t is None:
-            if self.subm:
+            if self.subm and self.symmetric:
                 # submanifold symmetry: in = out + (k - c)  <=>  out = in + ((K-1-k) - c)
                 self._nbr_t = self.nbr.flip(0).contiguous()
             else:
@@ -120,32 +137,57 @@ class Rulebook:
         return self._pairs
 
 
-def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, subm=False):
-    """Native counterpart of `get_indice_pairs`: returns a `Rulebook` (and syncs once, for strided convs,
-    to learn the number of active outputs — tensor shapes need it on the host)."""
+def _lift_to_3d(indices, lists, ndim):
+    """2D geometry as 3D with a unit last axis (kernel 1, stride 1, padding 0, dilation 1): the offset numbering
+    (kx*Ky + ky) and the ascending-linear-index row order are unchanged by it."""
+    if ndim == 3:
+        return indices, lists
+    pad_col = torch.zeros((indices.shape[0], 1), dtype=indices.dtype, device=indices.device)
+    indices = torch.cat([indices, pad_col], dim=1)
+    fill = dict(shape=1, out_shape=1, ksize=1, stride=1, padding=0, dilation=1)
+    return indices, {k: list(v) + [fill[k]] for k, v in lists.items()}
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, subm=False,
+                   transpose=False, out_padding=0, out_shape=None):
+    """Native counterpart of `get_indice_pairs` (ops.py:45-125): returns a `Rulebook` (and syncs once, for strided
+    convs, to learn the number of active outputs — tensor shapes need it on the host).  2D and 3D; `transpose` builds
+    the rulebook of a transposed convolution (geometry.h:86-141)."""
     _require_cuda(indices, "indices")
     lib = _capi.load()
     ndim = indices.shape[1] - 1
-    if ndim != 3:
-        raise NotImplementedError("only 3D sparse convolutions are implemented (BEVFusion uses no 2D/4D spconv)")
-    ksize, stride, padding, dilation = (_as_list(v, 3) for v in (ksize, stride, padding, dilation))
-    if any(d != 1 for d in dilation):
-        raise NotImplementedError("dilation != 1 is not supported")
+    if ndim not in (2, 3):
+        raise NotImplementedError(f"{ndim}D sparse convolution is not implemented (2D and 3D are)")
+    ksize, stride, padding, dilation, out_padding = (_as_list(v, ndim) for v in (ksize, stride, padding, dilation,
+                                                                                out_padding))
+    in_shape = [int(s) for s in spatial_shape]
+    if subm:
+        out_shape = list(in_shape)
+    elif out_shape is not None:          # the pybind entry points take it from the caller (spconv_ops.h:30)
+        out_shape = [int(v) for v in out_shape]
+    elif transpose:
+        out_shape = get_deconv_output_size(in_shape, ksize, stride, padding, dilation, out_padding)
+    else:
+        out_shape = get_conv_output_size(in_shape, ksize, stride, padding, dilation)
+    user_out_shape = list(out_shape)
+    user_indices = indices
     indices = indices.contiguous()
     if indices.dtype != torch.int32:
         indices = indices.int()
+    indices, g = _lift_to_3d(indices, dict(shape=in_shape, out_shape=out_shape, ksize=ksize, stride=stride,
+                                           padding=padding, dilation=dilation), ndim)
+    in_shape, out_shape, ksize, stride, padding, dilation = (g[k] for k in ("shape", "out_shape", "ksize", "stride",
+                                                                            "padding", "dilation"))
     n = indices.shape[0]
     dev = indices.device
     K = ksize[0] * ksize[1] * ksize[2]
-    in_shape = [int(s) for s in spatial_shape]
-    out_shape = in_shape if subm else get_conv_output_size(in_shape, ksize, stride, padding, dilation)
-    ks, st = _capi.ints(ksize), _capi.ints(stride)
+    ks, st, dl = _capi.ints(ksize), _capi.ints(stride), _capi.ints(dilation)
     import ctypes
 
     host = ctypes.c_int(0)
     count_dev = torch.zeros(1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        cap = max(int(lib.bevamd_spconv_max_outputs(n, ks, st, int(bool(subm)))), 1)
+        cap = max(int(lib.bevamd_spconv_max_outputs_ex(n, ks, st, dl, int(bool(subm)), int(bool(transpose)))), 1)
         if not subm:
             vol = batch_size * out_shape[0] * out_shape[1] * out_shape[2]
             cap = max(min(cap, vol), 1)
@@ -155,13 +197,27 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         rc = lib.bevamd_spconv_build_rulebook(
             _capi.ptr(indices), n, int(batch_size), _capi.ints(in_shape), _capi.ints(out_shape), ks, st,
-            _capi.ints(padding), _capi.ints(dilation), int(bool(subm)), _capi.ptr(out_indices), cap, _capi.ptr(nbr), cap,
-            _capi.ptr(count_dev), ctypes.byref(host), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+            _capi.ints(padding), dl, int(bool(subm)), int(bool(transpose)), _capi.ptr(out_indices), cap, _capi.ptr(nbr),
+            cap, _capi.ptr(count_dev), ctypes.byref(host), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
     _capi.check(rc, "spconv_build_rulebook")
     m = int(host.value)
-    if not subm:
+    if subm:
+        out_indices = user_indices
+    else:
         out_indices = out_indices[:m]
-    return Rulebook(out_indices, nbr, m, n, K, subm, out_shape)
+        if ndim == 2:
+            out_indices = out_indices[:, :3].contiguous()
+    symmetric = bool(subm) and all(k % 2 == 1 for k in ksize) and all(d == 1 for d in dilation)
+    return Rulebook(out_indices, nbr, m, n, K, subm, user_out_shape, symmetric)
+
+
+def inverse_rulebook(rulebook, in_indices, in_spatial_shape):
+    """Rulebook of the "inverse" convolution coupled to `rulebook` (conv.py:153-158): the same pairs with the roles
+    of inputs and outputs swapped, so its output rows are the coupled convolution's input rows."""
+    inv = Rulebook(in_indices, rulebook.nbr_transposed(), rulebook.num_in, rulebook.num_out, rulebook.kernel_volume,
+                   False, in_spatial_shape, symmetric=False)
+    inv._nbr_t = rulebook.nbr
+    return inv
 
 
 def prepare_filters(filters, transpose_io=False):
@@ -322,11 +378,11 @@ def sparse_conv_backward(features, filters, out_grad, rulebook_nbr, nbr_t, num_i
 # reference-named API (ops.py:45-211) and the pybind module's functions (all.cc:21-51)
 # --------------------------------------------------------------------------------------------
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
-                     subm=False, transpose=False, grid=None):
-    """ops.py:45-125 -> (out_indices [M,4], indice_pairs [K,2,N] int32, indice_num [K] int32)."""
-    if transpose:
-        raise NotImplementedError("transposed sparse convolution is not implemented (no BEVFusion config uses it)")
-    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm)
+                     subm=False, transpose=False, grid=None, out_shape=None):
+    """ops.py:45-125 -> (out_indices [M,1+ndim], indice_pairs [K,2,N] int32, indice_num [K] int32).  `grid` (the
+    reference's optional caller-owned dense grid) is accepted and unused: no dense grid exists here."""
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, transpose, out_padding,
+                        out_shape)
     pairs, num = rb.indice_pairs()
     return rb.out_indices, pairs, num
 
@@ -344,17 +400,35 @@ def _nbr_from_pairs(indice_pairs, indice_num, num_rows, inverse):
     return nbr
 
 
+def _subm_shortcut_(nbr, counts, rows):
+    """The reference's SubM shortcut, in place and without a host sync (spconv_ops.h:272-276,300-303,309): the offset
+    with the most pairs (first maximum) is run as the identity map over all rows.  It already is the identity for any
+    undilated SubM rulebook, where this changes nothing; for a dilated one no offset is, and the reference's result is
+    reproduced all the same.  `counts` [K] = pairs per offset."""
+    K = nbr.shape[0]
+    order = torch.arange(K - 1, -1, -1, device=nbr.device, dtype=torch.int64)
+    kmax = (counts.to(torch.int64) * K + order).argmax().view(1)   # scores are unique: the FIRST maximum count wins
+    ident = torch.full((1, nbr.shape[1]), -1, dtype=torch.int32, device=nbr.device)
+    ident[0, :rows] = torch.arange(rows, dtype=torch.int32, device=nbr.device)
+    nbr.index_copy_(0, kmax, ident)
+    return nbr
+
+
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
     """ops.py:128-163 / spconv_ops.h:260-361 on reference-shaped pairs."""
     if filters.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         raise NotImplementedError
     nbr = _nbr_from_pairs(indice_pairs, indice_pair_num, num_activate_out, inverse)
+    if subm:
+        _subm_shortcut_(nbr, indice_pair_num.to(nbr.device), int(num_activate_out))
     return sparse_conv(features, filters, nbr, int(num_activate_out))
 
 
 def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
     """ops.py:166-182: `indice_conv` with the bias added by the same kernel."""
     nbr = _nbr_from_pairs(indice_pairs, indice_pair_num, num_activate_out, inverse)
+    if subm:
+        _subm_shortcut_(nbr, indice_pair_num.to(nbr.device), int(num_activate_out))
     return sparse_conv(features, filters, nbr, int(num_activate_out), bias=bias)
 
 
@@ -363,17 +437,108 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     num_out = out_bp.shape[0]
     nbr = _nbr_from_pairs(indice_pairs, indice_pair_num, num_out, inverse)
     nbr_t = _nbr_from_pairs(indice_pairs, indice_pair_num, features.shape[0], not inverse)
+    if subm:
+        counts = indice_pair_num.to(nbr.device)
+        _subm_shortcut_(nbr, counts, num_out)
+        _subm_shortcut_(nbr_t, counts, features.shape[0])
     return list(sparse_conv_backward(features, filters, out_bp, nbr, nbr_t, features.shape[0]))
 
 
+# --------------------------------------------------------------------------------------------
+# sparse max pooling (ops.py:192-211 / pool_ops.h:25-97)
+# --------------------------------------------------------------------------------------------
+def sparse_maxpool(features, nbr, num_out):
+    """out[o] = max(0, max_k features[nbr[k, o]]) in one launch (the reference's output starts from zeros)."""
+    _require_cuda(features, "features")
+    lib = _capi.load()
+    if features.stride(1) != 1:
+        features = features.contiguous()
+    out = torch.empty((int(num_out), features.shape[1]), dtype=features.dtype, device=features.device)
+    if num_out == 0 or features.shape[1] == 0:
+        return out
+    with torch.cuda.device(features.device):
+        rc = lib.bevamd_spconv_maxpool_forward(_capi.ptr(features), _dtype_code(features), features.stride(0),
+                                               _capi.ptr(nbr), nbr.stride(0), int(num_out), nbr.shape[0],
+                                               features.shape[1], _capi.ptr(out), out.stride(0),
+                                               _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_maxpool_forward")
+    return out
+
+
+def sparse_maxpool_backward(features, out_features, out_grad, nbr_t):
+    """in_grad[i] = sum_k [out_features[nbr_t[k, i]] == features[i]] * out_grad[nbr_t[k, i]] (element-wise)."""
+    _require_cuda(features, "features")
+    lib = _capi.load()
+    features = features.contiguous()
+    out_features = out_features.contiguous().to(features.dtype)
+    out_grad = out_grad.contiguous().to(features.dtype)
+    in_grad = torch.zeros_like(features)
+    if features.numel() == 0 or out_features.shape[0] == 0:
+        return in_grad
+    with torch.cuda.device(features.device):
+        rc = lib.bevamd_spconv_maxpool_backward(_capi.ptr(features), _capi.ptr(out_features), _capi.ptr(out_grad),
+                                                _dtype_code(features), _capi.ptr(nbr_t), nbr_t.stride(0),
+                                                features.shape[0], nbr_t.shape[0], features.shape[1], _capi.ptr(in_grad),
+                                                _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_maxpool_backward")
+    return in_grad
+
+
+def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    """ops.py:192-202 on reference-shaped pairs."""
+    if features.dtype not in _DT:
+        raise NotImplementedError
+    nbr = _nbr_from_pairs(indice_pairs, indice_pair_num, num_activate_out, False)
+    return sparse_maxpool(features, nbr, int(num_activate_out))
+
+
+def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
+    """ops.py:205-211."""
+    if features.dtype not in _DT:
+        raise NotImplementedError
+    nbr_t = _nbr_from_pairs(indice_pairs, indice_pair_num, features.shape[0], True)
+    return sparse_maxpool_backward(features, out_features, out_bp, nbr_t)
+
+
 class _SparseConvExt:
-    """Drop-in for the pybind module `sparse_conv_ext` (3D entries of all.cc:21-51)."""
+    """Drop-in for the pybind module `sparse_conv_ext` (all.cc:21-51).  The 4D entry raises: no 4D rulebook here."""
 
     @staticmethod
     def get_indice_pairs_3d(indices, batch_size, out_shape, spatial_shape, ksize, stride, padding, dilation,
                             out_padding, subm, transpose):
         return list(get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding,
-                                     bool(subm), bool(transpose)))
+                                     bool(subm), bool(transpose), out_shape=out_shape))
+
+    get_indice_pairs_2d = get_indice_pairs_3d   # the dimensionality is read off `indices`
+
+    @staticmethod
+    def get_indice_pairs_4d(*args, **kwargs):
+        raise NotImplementedError("4D sparse convolution is not implemented (2D and 3D are)")
+
+    @staticmethod
+    def get_indice_pairs_grid_3d(indices, grid, batch_size, out_shape, spatial_shape, ksize, stride, padding, dilation,
+                                 out_padding, subm, transpose):
+        """all.cc:24-27: same result with a caller-owned dense grid, which this implementation has no use for."""
+        return list(get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding,
+                                     bool(subm), bool(transpose), out_shape=out_shape))
+
+    get_indice_pairs_grid_2d = get_indice_pairs_grid_3d
+
+    @staticmethod
+    def indice_maxpool_fp32(features, indice_pairs, indice_num, num_act_out):
+        return indice_maxpool(features.float(), indice_pairs, indice_num, num_act_out)
+
+    @staticmethod
+    def indice_maxpool_half(features, indice_pairs, indice_num, num_act_out):
+        return indice_maxpool(features.half(), indice_pairs, indice_num, num_act_out)
+
+    @staticmethod
+    def indice_maxpool_backward_fp32(features, out_features, out_grad, indice_pairs, indice_num):
+        return indice_maxpool_backward(features.float(), out_features.float(), out_grad.float(), indice_pairs, indice_num)
+
+    @staticmethod
+    def indice_maxpool_backward_half(features, out_features, out_grad, indice_pairs, indice_num):
+        return indice_maxpool_backward(features.half(), out_features.half(), out_grad.half(), indice_pairs, indice_num)
 
     @staticmethod
     def indice_conv_fp32(features, filters, indice_pairs, indice_num, num_act_out, inverse, subm):

@@ -245,14 +245,21 @@ int bevamd_voxel_compact(const float* feats, const int* coords4, const int* size
  * subm == 0: out_indices [out_cap, 4] receives the active outputs in ASCENDING linear index
  *   (b, x, y, z) — the row order of the reference's CUDA path (torch::_unique, spconv_ops.h:130).
  *   out_cap / nbr_stride must be >= bevamd_spconv_max_outputs(...) unless the caller knows better.
+ * dilation (HOST int[3], NULL = 1): in = out*stride - padding + k*dilation (geometry.h:24-85); SubM keeps
+ *   padding = ksize/2 whatever the dilation, as the reference does (spconv_ops.h:78-81).
+ * transpose != 0 (ignored for subm): out = in*stride - padding + k*dilation (geometry.h:86-141
+ *   getValidOutPosTranspose); out_shape is the caller's get_deconv_output_size.
+ * 2D convolutions run as 3D ones with a unit z axis (ksize 1, stride 1, padding 0); 4D is not implemented.
  * num_out_dev [1] always receives the row count; num_out_host (optional) makes the call
- * synchronise and return it to the host.  transpose / dilation != 1 are not supported. */
+ * synchronise and return it to the host. */
 size_t bevamd_spconv_rulebook_workspace_bytes(int n, int batch_size, const int* out_shape, int subm);
 int bevamd_spconv_max_outputs(int n, const int* ksize, const int* stride, int subm);
+int bevamd_spconv_max_outputs_ex(int n, const int* ksize, const int* stride, const int* dilation, int subm,
+                                 int transpose);
 int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, const int* in_shape,
                                  const int* out_shape, const int* ksize, const int* stride,
-                                 const int* padding, const int* dilation, int subm, int* out_indices,
-                                 int out_cap, int* nbr, int nbr_stride, int* num_out_dev,
+                                 const int* padding, const int* dilation, int subm, int transpose,
+                                 int* out_indices, int out_cap, int* nbr, int nbr_stride, int* num_out_dev,
                                  int* num_out_host, void* ws, size_t ws_bytes, void* stream);
 
 /* Sync-free building blocks of the same rulebook (what the inference path of SparseEncoder chains): every
@@ -302,6 +309,23 @@ int bevamd_spconv_nbr_from_pairs(const int* indice_pairs, int pairs_len, const i
 /* input-stationary view: nbr_t[k][nbr[k][o]] = o (nbr_t pre-filled with -1 by the call). */
 int bevamd_spconv_transpose_nbr(const int* nbr, int nbr_stride, int m, int kernel_volume, int* nbr_t,
                                 int nbr_t_stride, void* stream);
+
+/* Sparse max pooling.  Replace sparse_conv_ext.indice_maxpool_{fp32,half} and indice_maxpool_backward_{fp32,half}
+ *   (spconv/src/all.cc:39-46 -> pool_ops.h:25-97 indiceMaxPool / indiceMaxPoolBackward; arithmetic of
+ *    maxpool_cpu.cc:22-66).
+ * forward : out[o][c] = max(0, max over offsets k with nbr[k][o] >= 0 of features[nbr[k][o]][c]) — the reference's
+ *           output starts from zeros and only takes strictly larger inputs.  features [num_in, feat_stride],
+ *           out [num_out, out_stride] (strides in elements, >= channels).
+ * backward: in_grad[i][c] = sum over offsets k (ascending) with o = nbr_t[k][i] >= 0 and
+ *           out_features[o][c] == features[i][c] of out_grad[o][c]; all four tensors contiguous [rows, channels];
+ *           nbr_t is the input-stationary table (bevamd_spconv_transpose_nbr / nbr_from_pairs with inverse = 1).
+ * dtype: 0 fp32, 1 fp16, 2 bf16.  One launch each, no atomics, results bit-reproducible. */
+int bevamd_spconv_maxpool_forward(const void* features, int dtype, int feat_stride, const int* nbr, int nbr_stride,
+                                  int num_out, int kernel_volume, int channels, void* out, int out_stride,
+                                  void* stream);
+int bevamd_spconv_maxpool_backward(const void* features, const void* out_features, const void* out_grad, int dtype,
+                                   const int* nbr_t, int nbr_t_stride, int num_in, int kernel_volume, int channels,
+                                   void* in_grad, void* stream);
 
 /* Filters [kx,ky,kz,cin,cout] (conv.py:100) -> MFMA-friendly image [cout_pad][K][cin_pad], zero
  * padded.  transpose_io != 0 prepares W^T (cin and cout swap roles) for the input-gradient pass. */

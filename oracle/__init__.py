@@ -201,14 +201,30 @@ def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
             for i in range(len(input_size))]
 
 
-def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, order="cuda"):
-    """spconv_ops.h:27-141 (getIndicePair<3>) on CPU semantics.
-    indices [N,4] int32 (b,x,y,z).  Returns (out_indices [M,4], indice_pairs [K,2,N] (-1 padded),
-    indice_num [K], out_shape).
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    """spconv/ops.py:34-42."""
+    return [(input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i]
+            for i in range(len(input_size))]
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm, order="cuda",
+                     transpose=False, out_padding=None):
+    """spconv_ops.h:27-141 (getIndicePair<NDim>) on CPU semantics, NDim = 2 or 3 (a 2D problem is run as the 3D one with
+    a unit last axis — same offsets, same row order — and the padding column is dropped again).
+    indices [N,1+NDim] int32 (b, spatial...).  Returns (out_indices [M,1+NDim], indice_pairs [K,2,N] (-1 padded),
+    indice_num [K], out_shape).  transpose: the rulebook of a transposed convolution (geometry.h:196-245).
     order="cpu":  output rows of a strided conv in first-appearance order (geometry.h:181-187);
     order="cuda": rows renumbered by ascending linear index b*vol + x*Y*Z + y*Z + z, which is what the
                   CUDA path produces (torch::_unique at spconv_ops.h:130, indice.cu.h:112-145).  D8."""
     indices = _i32arr(indices)
+    ndim = indices.shape[1] - 1
+    if ndim == 2:
+        lifted = np.concatenate([indices, np.zeros((indices.shape[0], 1), np.int32)], 1)
+        op = list(out_padding) + [0] if out_padding is not None else None
+        oi, pairs, num, oshape = get_indice_pairs(lifted, batch_size, list(spatial_shape) + [1], list(ksize) + [1],
+                                                  list(stride) + [1], list(padding) + [0], list(dilation) + [1], subm,
+                                                  order, transpose, op)
+        return np.ascontiguousarray(oi[:, :3]), pairs, num, oshape[:2]
     n = indices.shape[0]
     ks, st, pd, dl = _i32arr(ksize), _i32arr(stride), _i32arr(padding), _i32arr(dilation)
     K = int(np.prod(ks))
@@ -218,10 +234,14 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding,
         shape = _i32arr(spatial_shape)
         lib().oracle_subm_indice_pairs(_p(indices), _i64(n), _p(shape), _p(ks), _p(dl), _p(pairs), _p(num))
         return indices.copy(), pairs[:, :, :n] if n else pairs[:, :, :0], num, list(spatial_shape)
-    out_shape = get_conv_output_size(list(spatial_shape), list(ks), list(st), list(pd), list(dl))
+    if transpose:
+        out_shape = get_deconv_output_size(list(spatial_shape), list(ks), list(st), list(pd), list(dl),
+                                           list(out_padding) if out_padding is not None else [0, 0, 0])
+    else:
+        out_shape = get_conv_output_size(list(spatial_shape), list(ks), list(st), list(pd), list(dl))
     oshape = _i32arr(out_shape)
     out_inds = np.zeros((max(n * K, 1), 4), dtype=np.int32)
-    fn = lib().oracle_conv_indice_pairs
+    fn = lib().oracle_deconv_indice_pairs if transpose else lib().oracle_conv_indice_pairs
     fn.restype = ctypes.c_int64
     m = fn(_p(indices), _i64(n), _p(ks), _p(st), _p(pd), _p(dl), _p(oshape), _p(out_inds), _p(pairs), _p(num))
     out_inds = out_inds[:m].copy()
@@ -239,12 +259,29 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding,
     return out_inds, pairs, num, out_shape
 
 
-def indice_conv(features, filters, indice_pairs, indice_num, num_act_out, inverse=False):
+def _subm_shortcut(pairs, num, n_rows):
+    """spconv_ops.h:272-276,300-303,309: with subM set, the offset holding the most pairs (first maximum) is taken to be
+    the identity map and runs as one dense GEMM over all rows instead of through its pairs.  That IS the identity for an
+    undilated odd (or even) kernel; for a dilated SubM rulebook no offset is, and the reference still does it — the
+    restatement follows the reference."""
+    pairs, num = pairs.copy(), num.copy()
+    kmax = int(np.argmax(num))                      # first maximum, like std::max_element
+    if pairs.shape[2] < n_rows:
+        pairs = np.concatenate([pairs, np.full((pairs.shape[0], 2, n_rows - pairs.shape[2]), -1, np.int32)], 2)
+    pairs[kmax, :, :] = -1
+    pairs[kmax, :, :n_rows] = np.arange(n_rows, dtype=np.int32)
+    num[kmax] = n_rows
+    return np.ascontiguousarray(pairs), num
+
+
+def indice_conv(features, filters, indice_pairs, indice_num, num_act_out, inverse=False, subm=False):
     """spconv_ops.h:260-361, float64 accumulation.  filters [kx,ky,kz,Cin,Cout]. -> [M, Cout] float64."""
     features = np.ascontiguousarray(features, dtype=np.float32)
     filters = np.ascontiguousarray(filters, dtype=np.float32)
     pairs = _i32arr(indice_pairs)
     num = _i32arr(indice_num)
+    if subm:
+        pairs, num = _subm_shortcut(pairs, num, num_act_out)
     K, _, L = pairs.shape
     cin, cout = filters.shape[-2], filters.shape[-1]
     out = np.empty((num_act_out, cout), dtype=np.float64)
@@ -253,13 +290,15 @@ def indice_conv(features, filters, indice_pairs, indice_num, num_act_out, invers
     return out
 
 
-def indice_conv_backward(features, filters, out_grad, indice_pairs, indice_num, inverse=False):
+def indice_conv_backward(features, filters, out_grad, indice_pairs, indice_num, inverse=False, subm=False):
     """spconv_ops.h:363-456, float64 accumulation -> (in_grad [N,Cin], filter_grad like filters)."""
     features = np.ascontiguousarray(features, dtype=np.float32)
     filters = np.ascontiguousarray(filters, dtype=np.float32)
     out_grad = np.ascontiguousarray(out_grad, dtype=np.float32)
     pairs = _i32arr(indice_pairs)
     num = _i32arr(indice_num)
+    if subm:
+        pairs, num = _subm_shortcut(pairs, num, features.shape[0])
     K, _, L = pairs.shape
     cin, cout = filters.shape[-2], filters.shape[-1]
     gi = np.empty((features.shape[0], cin), dtype=np.float64)
@@ -268,6 +307,30 @@ def indice_conv_backward(features, filters, out_grad, indice_pairs, indice_num, 
                                           _i64(features.shape[0]), _i64(cin), _i64(cout), ctypes.c_int32(int(inverse)),
                                           _p(gi), _p(gw))
     return gi, gw.reshape(filters.shape)
+
+
+def indice_maxpool(features, indice_pairs, indice_num, num_act_out):
+    """pool_ops.h:25-58 with the CPU functor's arithmetic (maxpool_cpu.cc:22-40), fp32 -> [M, C] float32."""
+    features = np.ascontiguousarray(features, dtype=np.float32)
+    pairs, num = _i32arr(indice_pairs), _i32arr(indice_num)
+    K, _, L = pairs.shape
+    out = np.empty((num_act_out, features.shape[1]), dtype=np.float32)
+    lib().oracle_indice_maxpool_f32(_p(features), _p(pairs), _p(num), _i64(K), _i64(L), _i64(num_act_out),
+                                    _i64(features.shape[1]), _p(out))
+    return out
+
+
+def indice_maxpool_backward(features, out_features, out_grad, indice_pairs, indice_num):
+    """pool_ops.h:60-97 / maxpool_cpu.cc:43-66, fp32 -> [N, C] float32."""
+    features = np.ascontiguousarray(features, dtype=np.float32)
+    out_features = np.ascontiguousarray(out_features, dtype=np.float32)
+    out_grad = np.ascontiguousarray(out_grad, dtype=np.float32)
+    pairs, num = _i32arr(indice_pairs), _i32arr(indice_num)
+    K, _, L = pairs.shape
+    gi = np.empty_like(features)
+    lib().oracle_indice_maxpool_backward_f32(_p(features), _p(out_features), _p(out_grad), _p(pairs), _p(num), _i64(K),
+                                             _i64(L), _i64(features.shape[0]), _i64(features.shape[1]), _p(gi))
+    return gi
 
 
 def pairs_as_sets(indice_pairs, indice_num):
