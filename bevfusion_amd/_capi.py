@@ -53,6 +53,10 @@ _SIGNATURES = {
     "bevamd_spconv_max_outputs": (I, [I, P, P, I]),
     "bevamd_spconv_build_rulebook": (I, [P, I, I, P, P, P, P, P, P, I, I, P, I, P, I, P, P, P, Z, P]),
     "bevamd_spconv_max_outputs_ex": (I, [I, P, P, P, I, I]),
+    "bevamd_dynamic_scatter_workspace_bytes": (Z, [I]),
+    "bevamd_dynamic_scatter_index": (I, [P, I, I, P, P, P, P, P, P, P, P, Z, P]),
+    "bevamd_dynamic_scatter_reduce": (I, [P, I, P, P, I, I, P, P]),
+    "bevamd_dynamic_scatter_backward": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
     "bevamd_spconv_maxpool_forward": (I, [P, I, I, P, I, I, I, I, P, I, P]),
     "bevamd_spconv_maxpool_backward": (I, [P, P, P, I, P, I, I, I, I, P, P]),
     "bevamd_spconv_dense_bev": (I, [P, I, I, I, I, P, I, I, P, P, P]),

@@ -17,7 +17,9 @@ from torch.nn.modules.utils import _pair
 
 from . import _capi
 
-__all__ = ["Voxelization", "voxelization", "voxel_layer", "voxelize_batch"]
+__all__ = ["Voxelization", "voxelization", "voxel_layer", "voxelize_batch", "DynamicScatter", "dynamic_scatter"]
+
+_REDUCE = {"sum": 0, "mean": 1, "max": 2}   # reduce_t, scatter_points_cuda.cu:7 / voxelization.h:83-92
 
 
 def _check_points(points):
@@ -73,9 +75,141 @@ class _VoxelLayer:
         _capi.check(rc, "dynamic_voxelize")
 
 
+    @staticmethod
+    def dynamic_point_to_voxel_forward(feats, coors, reduce_type):
+        """voxelization.h:108-120 -> scatter_points_cuda.cu:197-250.  feats [N, C] fp32, coors [N, ndim] int ->
+        [reduced_feats [M, C], out_coors [M, ndim] (ascending lexicographic order, dtype of `coors`),
+        coors_map [N] int32 (-1 for rows with a negative coordinate), reduce_count [M] int32]."""
+        if reduce_type not in _REDUCE:
+            raise RuntimeError(f"do not support reduce type {reduce_type}")       # voxelization.h:91
+        if not feats.is_cuda or not coors.is_cuda:
+            raise RuntimeError("do not support cpu yet")                          # voxelization.h:118
+        if feats.dtype != torch.float32:
+            raise RuntimeError(f"feats must be float32 (got {feats.dtype})")
+        if not feats.is_contiguous() or not coors.is_contiguous():
+            raise RuntimeError("feats and coors must be contiguous")             # CHECK_INPUT, :201-202
+        n, c = feats.shape
+        if n == 0:                                                               # :207-211
+            return [feats.clone().detach(), coors.clone().detach(), coors.new_empty((0,), dtype=torch.int32),
+                    coors.new_empty((0,), dtype=torch.int32)]
+        ndim = coors.shape[1]
+        c32 = coors if coors.dtype == torch.int32 else coors.to(torch.int32)
+        dev = feats.device
+        lib = _capi.load()
+        import ctypes
+
+        out_coors = torch.empty((n, ndim), dtype=torch.int32, device=dev)
+        coors_map = torch.empty((n,), dtype=torch.int32, device=dev)
+        count = torch.empty((n,), dtype=torch.int32, device=dev)
+        order = torch.empty((n,), dtype=torch.int32, device=dev)
+        seg = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+        m_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        host = ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            wsb = lib.bevamd_dynamic_scatter_workspace_bytes(n)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            rc = lib.bevamd_dynamic_scatter_index(_capi.ptr(c32), n, ndim, _capi.ptr(out_coors), _capi.ptr(coors_map),
+                                                  _capi.ptr(count), _capi.ptr(order), _capi.ptr(seg), _capi.ptr(m_dev),
+                                                  ctypes.byref(host), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+            _capi.check(rc, "dynamic_scatter_index")
+            m = int(host.value)
+            reduced = torch.empty((m, c), dtype=torch.float32, device=dev)
+            rc = lib.bevamd_dynamic_scatter_reduce(_capi.ptr(feats), c, _capi.ptr(order), _capi.ptr(seg), m,
+                                                   _REDUCE[reduce_type], _capi.ptr(reduced), _capi.stream_ptr(dev))
+            _capi.check(rc, "dynamic_scatter_reduce")
+        out_coors = out_coors[:m]
+        if coors.dtype != torch.int32:
+            out_coors = out_coors.to(coors.dtype)
+        return [reduced, out_coors, coors_map, count[:m]]
+
+    @staticmethod
+    def dynamic_point_to_voxel_backward(grad_feats, grad_reduced_feats, feats, reduced_feats, coors_idx, reduce_count,
+                                        reduce_type):
+        """voxelization.h:122-140 -> scatter_points_cuda.cu:252-330: fills `grad_feats` [N, C] in place."""
+        if reduce_type not in _REDUCE:
+            raise RuntimeError(f"do not support reduce type {reduce_type}")
+        if not grad_feats.is_cuda:
+            raise RuntimeError("do not support cpu yet")
+        for t, nm in ((grad_feats, "grad_feats"), (grad_reduced_feats, "grad_reduced_feats"), (feats, "feats"),
+                      (reduced_feats, "reduced_feats"), (coors_idx, "coors_idx"), (reduce_count, "reduce_count")):
+            if not t.is_contiguous():
+                raise RuntimeError(f"{nm} must be contiguous")
+        if grad_feats.dtype != torch.float32 or grad_reduced_feats.dtype != torch.float32:
+            raise RuntimeError("gradients must be float32")
+        n, c = feats.shape
+        m = reduced_feats.shape[0]
+        dev = grad_feats.device
+        lib = _capi.load()
+        mode = _REDUCE[reduce_type]
+        with torch.cuda.device(dev):
+            scratch = torch.empty((max(m * c, 1),), dtype=torch.int32, device=dev) if mode == 2 else None
+            rc = lib.bevamd_dynamic_scatter_backward(
+                _capi.ptr(grad_feats), _capi.ptr(grad_reduced_feats), _capi.ptr(feats), _capi.ptr(reduced_feats),
+                _capi.ptr(coors_idx.int() if coors_idx.dtype != torch.int32 else coors_idx),
+                _capi.ptr(reduce_count.int() if reduce_count.dtype != torch.int32 else reduce_count), n, m, c, mode,
+                _capi.ptr(scratch), _capi.stream_ptr(dev))
+        _capi.check(rc, "dynamic_scatter_backward")
+
+
 voxel_layer = _VoxelLayer()
 hard_voxelize = voxel_layer.hard_voxelize
 dynamic_voxelize = voxel_layer.dynamic_voxelize
+dynamic_point_to_voxel_forward = voxel_layer.dynamic_point_to_voxel_forward
+dynamic_point_to_voxel_backward = voxel_layer.dynamic_point_to_voxel_backward
+
+
+class _dynamic_scatter(Function):
+    """scatter_points.py:8-47: (feats [N, C], coors [N, ndim], reduce_type) -> (voxel_feats [M, C], voxel_coors [M, ndim])."""
+
+    @staticmethod
+    def forward(ctx, feats, coors, reduce_type="max"):
+        voxel_feats, voxel_coors, point2voxel_map, voxel_points_count = dynamic_point_to_voxel_forward(feats, coors,
+                                                                                                       reduce_type)
+        ctx.reduce_type = reduce_type
+        ctx.save_for_backward(feats, voxel_feats, point2voxel_map, voxel_points_count)
+        ctx.mark_non_differentiable(voxel_coors)
+        return voxel_feats, voxel_coors
+
+    @staticmethod
+    def backward(ctx, grad_voxel_feats, grad_voxel_coors=None):
+        feats, voxel_feats, point2voxel_map, voxel_points_count = ctx.saved_tensors
+        grad_feats = torch.empty_like(feats)       # every element is written by the call below
+        dynamic_point_to_voxel_backward(grad_feats, grad_voxel_feats.contiguous(), feats, voxel_feats, point2voxel_map,
+                                        voxel_points_count, ctx.reduce_type)
+        return grad_feats, None, None
+
+
+dynamic_scatter = _dynamic_scatter.apply
+
+
+class DynamicScatter(nn.Module):
+    """scatter_points.py:53-108: mean (average_points) or max reduction of the points of every voxel, per sample when
+    the coordinates carry a batch column."""
+
+    def __init__(self, voxel_size, point_cloud_range, average_points: bool):
+        super().__init__()
+        self.voxel_size = voxel_size
+        self.point_cloud_range = point_cloud_range
+        self.average_points = average_points
+
+    def forward_single(self, points, coors):
+        return dynamic_scatter(points.contiguous(), coors.contiguous(), "mean" if self.average_points else "max")
+
+    def forward(self, points, coors):
+        if coors.size(-1) == 3:
+            return self.forward_single(points, coors)
+        batch_size = int(coors[-1, 0]) + 1          # scatter_points.py:89: samples are concatenated in order
+        voxels, voxel_coors = [], []
+        for i in range(batch_size):
+            inds = torch.where(coors[:, 0] == i)
+            voxel, voxel_coor = self.forward_single(points[inds], coors[inds][:, 1:])
+            voxel_coors.append(nn.functional.pad(voxel_coor, (1, 0), mode="constant", value=i))
+            voxels.append(voxel)
+        return torch.cat(voxels, dim=0), torch.cat(voxel_coors, dim=0)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range={self.point_cloud_range}, "
+                f"average_points={self.average_points})")
 
 
 class _Voxelization(Function):

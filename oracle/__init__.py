@@ -188,6 +188,62 @@ def voxelize_batch(points_list, voxel_size, coors_range, max_points, max_voxels)
     return np.concatenate(feats), np.concatenate(coords), np.concatenate(sizes)
 
 
+def dynamic_scatter(feats, coors, reduce_type, dtype=np.float64):
+    """voxel_layer.dynamic_point_to_voxel_forward (scatter_points_cuda.cu:197-250) in numpy: rows of `coors` with a
+    negative entry are dropped (:213); the distinct rows in ascending lexicographic order are the voxels
+    (at::unique_dim(sorted), :215-222); features reduce by sum / mean (= sum / count, :237-238) / max.
+    Returns (reduced [M, C] `dtype`, out_coors [M, ndim], coors_map [N] int32 with -1 for dropped rows,
+    reduce_count [M] int32).  Sums accumulate in `dtype` in ascending point order (the reference's atomicAdd order is
+    unspecified, so sum / mean carry a tolerance; max is exact)."""
+    feats = np.asarray(feats, dtype=np.float32)
+    coors = np.asarray(coors)
+    n, c = feats.shape
+    valid = ~(coors < 0).any(1)
+    coors_map = np.full(n, -1, dtype=np.int32)
+    if not valid.any():
+        return (np.zeros((0, c), dtype), coors[:0].copy(), coors_map, np.zeros(0, np.int32))
+    out_coors, inv, count = np.unique(coors[valid], axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    coors_map[valid] = inv.astype(np.int32)
+    m = out_coors.shape[0]
+    f = feats[valid].astype(dtype)
+    if reduce_type == "max":
+        red = np.full((m, c), -np.inf, dtype)
+        np.maximum.at(red, inv, f)
+    elif reduce_type in ("sum", "mean"):
+        red = np.zeros((m, c), dtype)
+        np.add.at(red, inv, f)                       # unbuffered, in index order
+        if reduce_type == "mean":
+            red = red / count[:, None].astype(dtype)
+    else:
+        raise ValueError(reduce_type)
+    return red, out_coors, coors_map, count.astype(np.int32)
+
+
+def dynamic_scatter_backward(grad_reduced, feats, reduced, coors_map, reduce_count, reduce_type):
+    """voxel_layer.dynamic_point_to_voxel_backward (scatter_points_cuda.cu:252-330) -> grad_feats [N, C] float32."""
+    feats = np.asarray(feats, dtype=np.float32)
+    g = np.asarray(grad_reduced, dtype=np.float32)
+    n, c = feats.shape
+    out = np.zeros((n, c), np.float32)
+    keep = coors_map >= 0
+    if reduce_type == "sum":
+        out[keep] = g[coors_map[keep]]
+    elif reduce_type == "mean":
+        out[keep] = g[coors_map[keep]] / reduce_count[coors_map[keep]][:, None].astype(np.float32)
+    elif reduce_type == "max":
+        red = np.asarray(reduced, dtype=np.float32)
+        first = np.full(red.shape, n, dtype=np.int64)                    # lowest point id attaining the maximum (:144-170)
+        for p in np.nonzero(keep)[0][::-1]:
+            hit = feats[p] == red[coors_map[p]]
+            first[coors_map[p]][hit] = p
+        vv, cc = np.nonzero(first < n)
+        out[first[vv, cc], cc] = g[vv, cc]
+    else:
+        raise ValueError(reduce_type)
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # spconv: rulebook + sparse convolution
 # --------------------------------------------------------------------------------------------
