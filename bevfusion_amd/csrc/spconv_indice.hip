@@ -49,9 +49,18 @@ __device__ __forceinline__ bool axis_reach(const ConvGeom& g, int a, int src, in
   dst = src * g.stride[a] - g.pad[a] + k * g.dil[a];
   return dst >= 0 && dst < dst_size;
 }
-// output cell fed by input coordinate `in` through kernel tap k, on axis a
+// output cell fed by input coordinate `in` through kernel tap k, on axis a.  GENERAL = false is the undilated regular
+// convolution (every layer of the SparseEncoder): no dilation multiply, no transposed branch.
+template <bool GENERAL>
 __device__ __forceinline__ bool axis_in_to_out(const ConvGeom& g, int a, int in, int k, int& out) {
-  return g.transpose ? axis_reach(g, a, in, k, g.out_shape[a], out) : axis_scatter(g, a, in, k, g.out_shape[a], out);
+  if constexpr (!GENERAL) {
+    const int t = in + g.pad[a] - k;
+    if (t < 0 || t % g.stride[a]) return false;
+    out = t / g.stride[a];
+    return out < g.out_shape[a];
+  } else {
+    return g.transpose ? axis_reach(g, a, in, k, g.out_shape[a], out) : axis_scatter(g, a, in, k, g.out_shape[a], out);
+  }
 }
 // input cell read by output coordinate `out` through kernel tap k, on axis a
 __device__ __forceinline__ bool axis_out_to_in(const ConvGeom& g, int a, int out, int k, int& in) {
@@ -158,6 +167,7 @@ __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out
 // Strided convolution, neighbour table from the INPUT side: each input row knows the <= prod(ceil(k/s))
 // (output cell, offset) pairs it feeds; the output row is the rank of that cell.  ~10x fewer lookups than
 // probing all K offsets of every output row (most of which have no input).  nbr must be pre-filled with -1.
+template <bool GENERAL>
 __global__ __launch_bounds__(256) void sp_nbr_from_inputs_kernel(const int* __restrict__ indices, int n_cap,
                                                                  const int* __restrict__ n_dev, ConvGeom g,
                                                                  const uint2* __restrict__ out_words, int m_cap,
@@ -168,11 +178,11 @@ __global__ __launch_bounds__(256) void sp_nbr_from_inputs_kernel(const int* __re
     const int4 c = ((const int4*)indices)[j];
     for (int kx = 0; kx < g.ksize[0]; ++kx) {
       int ox, oy, oz;
-      if (!axis_in_to_out(g, 0, c.y, kx, ox)) continue;
+      if (!axis_in_to_out<GENERAL>(g, 0, c.y, kx, ox)) continue;
       for (int ky = 0; ky < g.ksize[1]; ++ky) {
-        if (!axis_in_to_out(g, 1, c.z, ky, oy)) continue;
+        if (!axis_in_to_out<GENERAL>(g, 1, c.z, ky, oy)) continue;
         for (int kz = 0; kz < g.ksize[2]; ++kz) {
-          if (!axis_in_to_out(g, 2, c.w, kz, oz)) continue;
+          if (!axis_in_to_out<GENERAL>(g, 2, c.w, kz, oz)) continue;
           uint32_t key = (uint32_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz);
           const int row = rank_lookup(out_words, key);
           if (row >= 0 && row < m_cap) nbr[(size_t)((kx * g.ksize[1] + ky) * g.ksize[2] + kz) * nbr_stride + row] = j;
@@ -233,6 +243,7 @@ __global__ __launch_bounds__(256) void sp_nbr_subm_sym_kernel(const int* __restr
 // stores.  A bitmap would need device-scope atomicOr, and device-scope atomics leave the XCD (the 8 L2s are not coherent
 // with each other): 540 k of them cost 25-50 us per level.  Byte stores of the same value race benignly (L2 lines carry
 // byte-granular dirty masks), are fire-and-forget, and the map is folded into bitmap words by the popcount pass below.
+template <bool GENERAL>
 __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restrict__ indices, int n_cap,
                                                               const int* __restrict__ n_dev, ConvGeom g,
                                                               uint8_t* __restrict__ cellmap) {
@@ -242,11 +253,11 @@ __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restr
     const int4 c = ((const int4*)indices)[j];
     for (int kx = 0; kx < g.ksize[0]; ++kx) {
       int ox, oy, oz;
-      if (!axis_in_to_out(g, 0, c.y, kx, ox)) continue;
+      if (!axis_in_to_out<GENERAL>(g, 0, c.y, kx, ox)) continue;
       for (int ky = 0; ky < g.ksize[1]; ++ky) {
-        if (!axis_in_to_out(g, 1, c.z, ky, oy)) continue;
+        if (!axis_in_to_out<GENERAL>(g, 1, c.z, ky, oy)) continue;
         for (int kz = 0; kz < g.ksize[2]; ++kz) {
-          if (!axis_in_to_out(g, 2, c.w, kz, oz)) continue;
+          if (!axis_in_to_out<GENERAL>(g, 2, c.w, kz, oz)) continue;
           cellmap[(size_t)((((long long)c.x * g.out_shape[0] + ox) * g.out_shape[1] + oy) * g.out_shape[2] + oz)] = 1;
         }
       }
@@ -540,6 +551,7 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
     return BEVAMD_ERR_WORKSPACE;
   }
   const size_t nw = grid_words(g.batch, g.out_shape), nt = (nw + RANK_TILE - 1) / RANK_TILE;
+  const bool general = g.transpose || g.dil[0] != 1 || g.dil[1] != 1 || g.dil[2] != 1;
   Carver cv(out_index, bytes);
   uint2* words = cv.take<uint2>(nw);   // must stay first: the rank index IS this array
   uint32_t* tile_sums = cv.take<uint32_t>(nt + 1);
@@ -549,7 +561,8 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
   int frc = fill_u32(cellmap, nw * 32, 0u, stream);
   if (frc) return frc;
   if (n_cap > 0) {
-    sp_mark_outputs_kernel<<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, cellmap);
+    if (general) sp_mark_outputs_kernel<true><<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, cellmap);
+    else sp_mark_outputs_kernel<false><<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, cellmap);
     BEVAMD_LAUNCH_CHECK("sp_mark_outputs");
   }
   sp_rank_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(cellmap, words, nw, tile_sums);
@@ -564,8 +577,10 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
     sp_nbr_clear_kernel<<<dim3(stride_grid(((long long)out_cap + 3) / 4), g.K), dim3(256), 0, stream>>>(nbr, nbr_stride, out_cap, num_out_dev, 0);
     BEVAMD_LAUNCH_CHECK("sp_nbr_clear");
     if (n_cap > 0) {
-      sp_nbr_from_inputs_kernel<<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words, out_cap,
-                                                                                   nbr, nbr_stride);
+      if (general) sp_nbr_from_inputs_kernel<true><<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words,
+                                                                                                      out_cap, nbr, nbr_stride);
+      else sp_nbr_from_inputs_kernel<false><<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, words,
+                                                                                               out_cap, nbr, nbr_stride);
       BEVAMD_LAUNCH_CHECK("sp_nbr_from_inputs");
     }
   }

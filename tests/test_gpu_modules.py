@@ -138,7 +138,9 @@ class _OracleRulebook:
         self.out_spatial_shape = list(oshape)
 
 
-def _oracle_build(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, subm=False):
+def _oracle_build(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, subm=False,
+                  transpose=False, out_padding=0):
+    assert not transpose
     ks, st, pd = (sops._as_list(v, 3) for v in (ksize, stride, padding))
     ind = indices.cpu().numpy()
     oi, pairs, num, oshape = oracle.get_indice_pairs(ind, batch_size, spatial_shape, ks, st, pd, [1, 1, 1], int(subm),
