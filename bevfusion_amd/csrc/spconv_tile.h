@@ -515,206 +515,6 @@ __global__ __launch_bounds__(NW * 64) void spconv_stream_kernel(Args a) {
   wt.store(a);
 }
 
-// ---- STAGED: the input rows a workgroup's tile can touch are copied into LDS once ----------------------
-// In a convolution over rows sorted by linear voxel index (every level below the first: the rank-index order), the
-// inputs of a block of consecutive output rows through the offsets of one kernel x-plane are the block's own index
-// window translated by a constant: a CONTIGUOUS range of input rows (plus the few rows of that window nobody reads).
-// On the flagship frame 128 consecutive rows read 19 neighbours each (2400 row gathers) out of only 240-440 distinct
-// rows.  So: per x-plane of the kernel take [min, max] of the tile's neighbour ids (from the table already sitting in
-// LDS), copy those ranges into LDS with coalesced contiguous loads, and serve every MFMA operand from there — a
-// ds_read_b128 at (row slot * pitch), straight in MFMA layout: no texture-path gather per (row, offset), no
-// ds_bpermute.  Tiles whose ranges do not fit `umax` rows (unsorted rows, pathological densities) take the stream
-// kernel's gather loop instead: same sums, same order, bit-identical results either way.
-template <int DT, int CINP, int NT, int MT, int NW, int CPO>
-__global__ __launch_bounds__(NW * 64) void spconv_staged_kernel(Args a, int umax, int dbg) {
-  static_assert(CINP >= 32, "staged rows are read in whole 32-channel chunks");
-  extern __shared__ u32x4 lds[];
-  typedef WaveTile<DT, CINP, NT, MT, CPO> WT;
-  typedef StepShape<CINP, CPO> SS;
-  constexpr int NK = WT::NK;
-  constexpr int STEP = CPO * NT * 64;
-  constexpr int WPT = (STEP + NW * 64 - 1) / (NW * 64);
-  constexpr bool EXACT = STEP % (NW * 64) == 0;
-  constexpr int R = 16 * MT, BM = NW * R;
-  constexpr int PITCH = CINP * 2 + 32;  // bytes = 32 mod 64: the 16 lanes of a ds_read_b128 group reading consecutive slots hit 64 distinct banks
-  constexpr int LPR = CINP / 8;         // 16-byte pieces per row
-  const int m = a.m_dev ? (*a.m_dev < a.m_cap ? *a.m_dev : a.m_cap) : a.m_cap;
-  const int nblk = (m + BM - 1) / BM;
-  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
-  const int per = (nblk + 7) >> 3;
-  const int tb = xcd * per + bix;
-  if (bix >= per || tb >= nblk) return;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int* nbl = (int*)(lds + 2 * STEP) + w * a.K * R;
-  u32x4* eps_all = lds + 2 * STEP + (NW * a.K * R + 3) / 4;
-  int* meta = (int*)(eps_all + NW * EpiScratch<NT>::U4);  // [NW][3][2] lo / hi per wave and kernel x-plane
-  char* stage = (char*)(meta + 32);
-  WT wt;
-  wt.init(a, tb * BM + w * R, m, nbl, eps_all + w * EpiScratch<NT>::U4);
-  wt.preload_nb(a);
-
-  // ranges: offsets are grouped by kernel x-plane (k / kspan); any grouping is correct, this one makes them tight
-  const int kspan = a.K % 3 == 0 ? a.K / 3 : a.K, ngroups = a.K / kspan;
-#pragma unroll
-  for (int grp = 0; grp < 3; ++grp) {
-    int lo = 0x7FFFFFFF, hi = -1;
-    if (grp < ngroups) {
-      for (int i = lane; i < kspan * R; i += 64) {
-        const int v = nbl[grp * kspan * R + i];
-        if (v >= 0) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
-      lo = l2 < lo ? l2 : lo;
-      hi = h2 > hi ? h2 : hi;
-    }
-    if (lane == 0) { meta[(w * 3 + grp) * 2] = lo; meta[(w * 3 + grp) * 2 + 1] = hi; }
-  }
-  __syncthreads();
-  int glo[3], gbase[3], total = 0;
-#pragma unroll
-  for (int grp = 0; grp < 3; ++grp) {
-    int lo = 0x7FFFFFFF, hi = -1;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) {
-      const int l2 = meta[(ww * 3 + grp) * 2], h2 = meta[(ww * 3 + grp) * 2 + 1];
-      lo = l2 < lo ? l2 : lo;
-      hi = h2 > hi ? h2 : hi;
-    }
-    glo[grp] = lo;
-    gbase[grp] = total;
-    total += hi >= lo ? hi - lo + 1 : 0;
-  }
-  if (total > umax) {  // workgroup-uniform: this tile gathers through the texture path like the stream kernel
-    stream_loop<DT, CINP, NT, MT, NW, CPO, 0>(a, wt, lds);
-    wt.store(a);
-    return;
-  }
-
-  // Filter fragments stream through a 2-buffer LDS ring, but are fetched THREE steps ahead into three register sets:
-  // a staged tile fills the LDS, so a CU holds one or two workgroups and nothing else covers the ~1 us an L2 read
-  // takes; with one step (~0.2 us of MFMAs) of lead the ring starved (measured: 67 us vs 38 us for the gather kernel).
-  const u32x4* wg = (const u32x4*)a.wimg;
-  u32x4 wreg[3][WPT];
-  auto fetch_w = [&](int sc, u32x4 (&dst)[WPT]) {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = threadIdx.x + i * NW * 64;
-      dst[i] = (EXACT || e < STEP) ? wg[(size_t)sc * STEP + e] : u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-  auto put_w = [&](int buf, const u32x4 (&src)[WPT]) {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = threadIdx.x + i * NW * 64;
-      if (EXACT || e < STEP) lds[buf * STEP + e] = src[i];
-    }
-  };
-  const int nsteps = SS::nsteps(a.K);
-  const int last = nsteps - 1;
-  auto cl = [&](int st) { return st < last ? st : last; };
-  fetch_w(0, wreg[0]);
-  fetch_w(cl(1), wreg[1]);
-  fetch_w(cl(2), wreg[2]);
-
-  // staging copy: slot j of group grp <- input row glo[grp] + (j - gbase[grp]); 16 bytes per thread and load
-  {
-    const unsigned row_bytes = (unsigned)a.feat_stride * 2u;
-    const char* fb = (const char*)a.feat;
-    const int pieces = total * LPR;
-    constexpr int UNR = 8;
-    for (int b0 = threadIdx.x; b0 < ((dbg & 2) ? 0 : pieces); b0 += NW * 64 * UNR) {
-      u32x4 v[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        int i = b0 + u * NW * 64;
-        i = i < pieces ? i : pieces - 1;
-        const int slot = i / LPR, piece = i - slot * LPR;
-        const int grp = (slot >= gbase[1] ? 1 : 0) + (slot >= gbase[2] ? 1 : 0);
-        const int src = (grp == 0 ? glo[0] : grp == 1 ? glo[1] : glo[2]) + slot - (grp == 0 ? gbase[0] : grp == 1 ? gbase[1] : gbase[2]);
-        v[u] = *(const u32x4*)(fb + (size_t)src * row_bytes + piece * 16);
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int i = b0 + u * NW * 64;
-        if (i < pieces) {
-          const int slot = i / LPR, piece = i - slot * LPR;
-          *(u32x4*)(stage + slot * PITCH + piece * 16) = v[u];
-        }
-      }
-    }
-    if (threadIdx.x < LPR) *(u32x4*)(stage + umax * PITCH + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};  // the "no neighbour" row
-  }
-  // neighbour ids -> LDS byte offsets of the staged rows (wave-private table, rewritten in place)
-  const int zero_off = umax * PITCH;
-  for (int i = lane; i < a.K * R; i += 64) {
-    const int v = nbl[i];
-    const int grp = (i / R) / kspan;
-    const int lo = grp == 0 ? glo[0] : grp == 1 ? glo[1] : glo[2];
-    const int bs = grp == 0 ? gbase[0] : grp == 1 ? gbase[1] : gbase[2];
-    nbl[i] = v >= 0 ? (bs + v - lo) * PITCH : zero_off;
-  }
-  put_w(0, wreg[0]);
-  __syncthreads();
-
-  // LDS byte offsets of this lane's row (MFMA layout: row = lane & 15) for the offsets of step s
-  auto load_off = [&](int s, int (&off)[MT][NK]) {
-#pragma unroll
-    for (int q = 0; q < NK; ++q) {
-      const int k = s * NK + q;
-      const int kc = k < a.K ? k : a.K - 1;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int o = nbl[kc * R + mt * 16 + wt.c];
-        off[mt][q] = (k < a.K && wt.row0 + mt * 16 + wt.c < m) ? o : zero_off;
-      }
-    }
-  };
-  auto fetch = [&](const u32x4* wl, const int (&off)[MT][NK], int cc, u32x4 (&b)[NT], u32x4 (&xm)[MT]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = wl[(cc * NT + nt) * 64 + lane];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xm[mt] = *(const u32x4*)(stage + off[mt][SS::slot_of(cc)] + SS::byte_of(cc, wt.g));
-  };
-  auto multiply = [&](const u32x4* wl, const int (&off)[MT][NK]) {
-    u32x4 b0[NT], b1[NT], x0[MT], x1[MT];
-    fetch(wl, off, 0, b0, x0);
-#pragma unroll
-    for (int cc = 0; cc < CPO; cc += 2) {
-      if (cc + 1 < CPO) fetch(wl, off, cc + 1, b1, x1);
-      __builtin_amdgcn_sched_barrier(0);
-      wt.mma_chunk(b0, x0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (cc + 1 < CPO) {
-        if (cc + 2 < CPO) fetch(wl, off, cc + 2, b0, x0);
-        __builtin_amdgcn_sched_barrier(0);
-        wt.mma_chunk(b1, x1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  int off[2][MT][NK];
-  load_off(0, off[0]);
-  // step s (phase P = s mod 6): register set s%3 is free (its fragments went to LDS during step s-1) -> fetch step s+3
-  // into it; multiply from LDS buffer s%2; then set (s+1)%3, fetched two steps ago, goes to buffer (s+1)%2.
-#define BEVAMD_STAGED_STEP(P)                                    \
-  if (s + P < nsteps) {                                          \
-    fetch_w(cl(s + P + 3), wreg[P % 3]);                         \
-    load_off(cl(s + P + 1), off[(P + 1) % 2]);                   \
-    multiply(lds + (P % 2) * STEP, off[P % 2]);                  \
-    put_w((P + 1) % 2, wreg[(P + 1) % 3]);                       \
-    __syncthreads();                                             \
-  }
-  for (int s = 0; s < ((dbg & 1) ? 0 : nsteps); s += 6) {
-    BEVAMD_STAGED_STEP(0) BEVAMD_STAGED_STEP(1) BEVAMD_STAGED_STEP(2)
-    BEVAMD_STAGED_STEP(3) BEVAMD_STAGED_STEP(4) BEVAMD_STAGED_STEP(5)
-  }
-#undef BEVAMD_STAGED_STEP
-  wt.store(a);
-}
-
 // ---- filter image ---------------------------------------------------------------------------------------
 // filters [K][cin][cout] (reference layout [kx,ky,kz,cin,cout], conv.py:100) -> image [chunk][nt][lane][8]:
 // element e of lane (c = lane&15, g = lane>>4) of chunk j is W[k][ci][nt*16 + c] with flat = 32j + 8g + e,
@@ -765,7 +565,7 @@ int launch_bf16(const Args& a, int cinp, int nt, int variant, hipStream_t stream
 int image_f16(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream);
 int image_bf16(const void* w, int K, int cin, int cout, int transpose_io, void* img, hipStream_t stream);
 
-// variant encoding: 0 = auto; otherwise kind*1000 + MT*100 + (NW/4)*10 + SPS  (kind 1 = resident, 2 = stream, 3 = staged;
+// variant encoding: 0 = auto; otherwise kind*1000 + MT*100 + (NW/4)*10 + SPS  (kind 1 = resident, 2 = stream;
 // SPS = kernel offsets per step for Cin >= 32, chunks per step below)
 template <int DT>
 int launch_impl(const Args& a, int cinp, int nt, int variant, hipStream_t stream);

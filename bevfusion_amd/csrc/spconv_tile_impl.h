@@ -2,8 +2,6 @@
 #pragma once
 #include "spconv_tile.h"
 
-#include <stdlib.h>
-
 namespace bevamd {
 namespace tile {
 
@@ -50,46 +48,6 @@ static int run_stream(const Args& a, hipStream_t stream) {
   const long long blocks = (nblk + 7) / 8 * 8;
   spconv_stream_kernel<DT, CINP, NT, MT, NW, CPO><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a);
   BEVAMD_LAUNCH_CHECK("spconv_stream");
-  return BEVAMD_OK;
-}
-
-// rows a staged tile may hold in LDS: as many as fit beside the filter ring and the tables, at most `staged_rows_per_row`
-// per output row of the tile (0 = default 5: the flagship frame needs 2-3.5, the rest is margin before the gather path)
-static int staged_rows_per_row() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("BEVAMD_STAGED_ROWS");   // tuning knob (tools/staged_probe.py)
-    v = e ? atoi(e) : 0;
-    if (v <= 0) v = 5;
-  }
-  return v;
-}
-
-template <int DT, int CINP, int NT, int MT, int NW, int SPS>
-static int run_staged(const Args& a, hipStream_t stream) {
-  constexpr int CPO = SPS * Chunks<CINP>::CPB;
-  constexpr int BM = NW * 16 * MT, PITCH = CINP * 2 + 32;
-  const size_t fixed = (size_t)2 * CPO * NT * 1024 + (size_t)(NW * a.K * 16 * MT + 3) / 4 * 16 + (size_t)NW * EpiScratch<NT>::U4 * 16 + 128;
-  const size_t budget = 160 * 1024 - 1024;
-  if (fixed + (size_t)(2 * BM + 1) * PITCH > budget) {
-    set_error("spconv tiled: staged variant does not fit LDS (%zu B fixed)", fixed);
-    return BEVAMD_ERR_UNSUPPORTED;
-  }
-  long long umax = (long long)BM * staged_rows_per_row();
-  const long long fit = (long long)((budget - fixed) / PITCH) - 1;
-  if (umax > fit) umax = fit;
-  const size_t lds = fixed + (size_t)(umax + 1) * PITCH;
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute((const void*)&spconv_staged_kernel<DT, CINP, NT, MT, NW, CPO>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    raised = true;
-  }
-  const long long nblk = ((long long)a.m_cap + BM - 1) / BM;
-  const long long blocks = (nblk + 7) / 8 * 8;
-  spconv_staged_kernel<DT, CINP, NT, MT, NW, CPO><<<dim3((unsigned)blocks), dim3(NW * 64), lds, stream>>>(a, (int)umax, getenv("BEVAMD_STAGED_DBG") ? atoi(getenv("BEVAMD_STAGED_DBG")) : 0);
-  BEVAMD_LAUNCH_CHECK("spconv_staged");
   return BEVAMD_OK;
 }
 
@@ -159,12 +117,7 @@ static int run_shape(const Args& a, int variant, hipStream_t stream) {
   case 2000 + MT * 100 + (NW / 4) * 10 + SPS:                                                          \
     if constexpr (stream_built<CINP, NT, MT, NW, SPS>()) return run_stream<DT, CINP, NT, MT, NW, SPS>(a, stream); \
     break
-#define BEVAMD_STG(MT, NW, SPS)                                                                       \
-  case 3000 + MT * 100 + (NW / 4) * 10 + SPS:                                                          \
-    if constexpr (CINP >= 32 && stream_built<CINP, NT, MT, NW, SPS>()) return run_staged<DT, CINP, NT, MT, NW, SPS>(a, stream); \
-    break
   switch (variant) {
-    BEVAMD_STG(1, 4, 1); BEVAMD_STG(2, 4, 1); BEVAMD_STG(1, 8, 1);
     BEVAMD_RES(2, 8, 1); BEVAMD_RES(2, 8, 2); BEVAMD_RES(2, 8, 3);
     BEVAMD_RES(4, 8, 1); BEVAMD_RES(4, 8, 2);
     BEVAMD_RES(2, 4, 1);
@@ -176,7 +129,6 @@ static int run_shape(const Args& a, int variant, hipStream_t stream) {
   }
 #undef BEVAMD_RES
 #undef BEVAMD_STR
-#undef BEVAMD_STG
   set_error("spconv tiled: variant %d is not built for cin_pad=%d, cout tiles=%d", variant, CINP, NT);
   return BEVAMD_ERR_UNSUPPORTED;
 }
