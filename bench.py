@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--feat-dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--spconv-dtype", choices=["fp16", "fp32", "bf16"], default="fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU (BASELINE config 4 quotes batch 8 on one GPU)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="frames per step per GPU (default 8: BASELINE.json's C+L inference config is quoted at batch 8 on one GPU; "
+                         "--batch 1 = single-frame latency)")
     ap.add_argument("--no-graph", action="store_true", help="launch the LiDAR branch kernel by kernel instead of replaying a HIP graph")
     return ap.parse_args()
 
@@ -307,7 +309,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "bev_pool_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                # PMC figure collected at one frame per launch (tools/pmc_bev_pool.sh); per-frame traffic x frames per launch
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") * B
             except Exception:
                 traffic = None
         res = {
@@ -327,8 +330,8 @@ def main():
                      + ("" if elem == 4 else ", bf16 camera features"),
             "data": "synthetic",
             "config": {
-                "workload": "hot path of configs[1]+[2] (the C+L model's camera view-transform reduction and LiDAR "
-                            f"voxel pipeline), {B} frame(s)/step/GPU: bev_pool N'={geom.shape[0]} frustum points ({n_kept} kept) "
+                "workload": "hot path of the C+L model (BASELINE configs[1]+[2]: camera view-transform reduction and LiDAR "
+                            f"voxel pipeline) at {B} frame(s)/step/GPU (configs[3] quotes batch 8): bev_pool N'={geom.shape[0]} frustum points ({n_kept} kept) "
                             f"x C={C} -> {n_int} non-empty of {B * D * H * W} cells; hard voxelize {sum(p.shape[0] for p in pts_all)} points -> "
                             f"{state['n_voxels']} voxels; SparseEncoder 1440x1440x41 (17 SubM + 4 strided convs) -> "
                             f"[{B},256,180,180]. bev_pool rank/sort/CSR precompute cached per calibration.",

@@ -10,6 +10,9 @@ MI355X-native addition: `voxelize_batch()` = `BEVFusion.voxelize` (bevfusion.py:
 batch with the mean-reduce fused, no `[max_voxels, max_points, F]` intermediate and one host sync
 for the whole batch (the reference syncs once per sample).
 """
+import contextlib
+import os
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -20,6 +23,17 @@ from . import _capi
 __all__ = ["Voxelization", "voxelization", "voxel_layer", "voxelize_batch", "DynamicScatter", "dynamic_scatter"]
 
 _REDUCE = {"sum": 0, "mean": 1, "max": 2}   # reduce_t, scatter_points_cuda.cu:7 / voxelization.h:83-92
+
+
+_VOXEL_LANES = int(os.environ.get("BEVAMD_VOXEL_STREAMS", "4"))   # concurrent per-sample voxelizations (1 = serial)
+_lanes = {}
+
+
+def _voxel_lanes(dev, n):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    if key not in _lanes:
+        _lanes[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _lanes[key]
 
 
 def _check_points(points):
@@ -289,15 +303,28 @@ def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, m
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
     vs, cr = _capi.floats(voxel_size), _capi.floats(point_cloud_range)
     nmax = max(int(p.shape[0]) for p in points_list)
+    points_list = [_check_points(p) for p in points_list]
     with torch.cuda.device(dev):
         wsb = lib.bevamd_hard_voxelize_workspace_bytes(nmax)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        # The samples are independent and each one's ~20 kernels (300 k points) fill a fraction of the GPU: spread them
+        # over a few HIP streams (fork from / join into the caller's stream, so the call stays graph-capturable).
+        lanes = _voxel_lanes(dev, min(B, _VOXEL_LANES)) if B > 1 and _VOXEL_LANES > 1 else [None]
+        ws = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in lanes]
+        main = torch.cuda.current_stream(dev)
+        for lane in lanes:
+            if lane is not None:
+                lane.wait_stream(main)
         for k, pts in enumerate(points_list):
-            pts = _check_points(pts)
-            rc = lib.bevamd_voxelize_mean(_capi.ptr(pts), _capi.ptr(feats[k]), _capi.ptr(coords[k]), _capi.ptr(sizes[k]),
-                                          vs, cr, int(max_num_points), int(max_voxels), pts.shape[0], F, k,
-                                          _capi.ptr(counts[k:]), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+            lane = lanes[k % len(lanes)]
+            with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
+                rc = lib.bevamd_voxelize_mean(_capi.ptr(pts), _capi.ptr(feats[k]), _capi.ptr(coords[k]), _capi.ptr(sizes[k]),
+                                              vs, cr, int(max_num_points), int(max_voxels), pts.shape[0], F, k,
+                                              _capi.ptr(counts[k:]), _capi.ptr(ws[k % len(lanes)]), wsb,
+                                              _capi.stream_ptr(dev))
             _capi.check(rc, "voxelize_mean")
+        for lane in lanes:
+            if lane is not None:
+                main.wait_stream(lane)
     if not sync:
         return feats, coords, sizes, counts
 
