@@ -309,8 +309,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "bev_pool_traffic.json")
         if os.path.exists(tpath):
             try:
-                # PMC figure collected at one frame per launch (tools/pmc_bev_pool.sh); per-frame traffic x frames per launch
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch") * B
+                # PMC figure of tools/pmc_bev_pool.sh, per frame x frames per launch (the traffic is linear in the frames)
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_frame") * B
             except Exception:
                 traffic = None
         res = {
