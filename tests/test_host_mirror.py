@@ -168,3 +168,44 @@ def test_fused_encoder_path_is_gated_on_cpu_and_keeps_module_semantics():
         with pytest.raises(RuntimeError, match="GPU tensor"):
             enc(x, c, 1)
     assert fused.INDEX_HASH == 0 and fused.INDEX_RANK == 1
+
+
+def test_spconv_family_is_registered_with_reference_signatures():
+    """The ten classes the reference registers in CONV_LAYERS (spconv/conv.py:226-455) build through build_conv_layer with
+    its keyword set, keep its parameter layout ([k..., Cin, Cout]) and flags; the pooling and scatter modules construct."""
+    from bevfusion_amd import spconv
+    from bevfusion_amd.voxel import DynamicScatter
+
+    names = ["SparseConv2d", "SparseConv3d", "SparseConv4d", "SparseConvTranspose2d", "SparseConvTranspose3d",
+             "SparseInverseConv2d", "SparseInverseConv3d", "SubMConv2d", "SubMConv3d", "SubMConv4d"]
+    for n in names:
+        assert n in CONV_LAYERS and hasattr(spconv, n)
+    up = build_conv_layer(dict(type="SparseConvTranspose3d", indice_key="up1"), 8, 4, 3, stride=2, padding=1, bias=False)
+    assert up.transposed and not up.subm and not up.inverse and tuple(up.weight.shape) == (3, 3, 3, 8, 4)
+    inv = build_conv_layer(dict(type="SparseInverseConv3d", indice_key="down1"), 8, 4, 3, bias=False)
+    assert inv.inverse and inv.indice_key == "down1" and inv.stride == [1, 1, 1]
+    c2 = build_conv_layer(dict(type="SubMConv2d"), 4, 6, (3, 5), bias=True)
+    assert c2.ndim == 2 and c2.subm and tuple(c2.weight.shape) == (3, 5, 4, 6) and tuple(c2.bias.shape) == (6,)
+    c4 = spconv.SparseConv4d(2, 2, 3)
+    assert c4.ndim == 4 and tuple(c4.weight.shape) == (3, 3, 3, 3, 2, 2)
+    with pytest.raises(AssertionError):                       # dilation and stride both != 1: conv.py:85
+        spconv.SparseConv3d(2, 2, 3, stride=2, dilation=2)
+    pool = spconv.SparseMaxPool3d(3, 2, 1)
+    assert pool.kernel_size == [3, 3, 3] and pool.stride == [2, 2, 2] and pool.padding == [1, 1, 1] and not pool.subm
+    assert spconv.SparseMaxPool2d((2, 3)).kernel_size == [2, 3]
+    ds = DynamicScatter([0.1, 0.1, 0.2], [0, 0, 0, 1, 1, 1], True)
+    assert ds.average_points and "average_points=True" in repr(ds)
+    assert spconv.get_deconv_output_size([5, 6], [3, 3], [2, 2], [1, 1], [1, 1], [1, 0]) == [10, 11]
+
+
+def test_lift_to_3d_keeps_offsets_and_order():
+    from bevfusion_amd.spconv.ops import _lift_to_3d
+
+    ind = torch.tensor([[0, 3, 4], [1, 0, 2]], dtype=torch.int32)
+    g = dict(shape=[8, 9], out_shape=[4, 5], ksize=[3, 2], stride=[2, 2], padding=[1, 0], dilation=[1, 1])
+    ind3, g3 = _lift_to_3d(ind, g, 2)
+    assert ind3.tolist() == [[0, 3, 4, 0], [1, 0, 2, 0]]
+    assert g3 == dict(shape=[8, 9, 1], out_shape=[4, 5, 1], ksize=[3, 2, 1], stride=[2, 2, 1], padding=[1, 0, 0],
+                      dilation=[1, 1, 1])
+    same, gs = _lift_to_3d(ind3, g3, 3)
+    assert same is ind3 and gs is g3
