@@ -158,8 +158,12 @@ template <typename VecT, int VEC, int U>
 __global__ __launch_bounds__(256) void bev_pool_fwd_cells_vec_kernel(
     const VecT* __restrict__ x, const uint32_t* __restrict__ order, const uint32_t* __restrict__ cell_start,
     uint32_t ncells, float* __restrict__ out, int lpr, int rpi, BevDims s) {
-  const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (cell >= ncells) return;
+  // cells are numbered b-fastest (the reference's rank); waves walk them frame-major, so that neighbouring waves read one
+  // frame's slab of the feature volume and write neighbouring output rows (ncells = B*D*H*W)
+  const uint32_t lin = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (lin >= ncells) return;
+  const uint32_t per_frame = ncells / (uint32_t)s.B;
+  const uint32_t cell = (lin % per_frame) * (uint32_t)s.B + lin / per_frame;
   const int lane = threadIdx.x & 63;
   const int slot = lane / lpr;
   const int cv = lane - slot * lpr;

@@ -50,8 +50,12 @@ __global__ __launch_bounds__(256) void bev_pool_fused_cells_kernel(
     const float* __restrict__ depth, const VecT* __restrict__ ctx, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ cell_start, uint32_t ncells, float* __restrict__ out, int lpr, int rpi, uint32_t dfhw,
     uint32_t fhw, FusedDims s) {
-  const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (cell >= ncells) return;
+  // Cells are numbered b-fastest (the reference's rank); waves walk them FRAME-major instead: neighbouring waves then share
+  // one frame's context (5.4 MB, L2-resident) rather than all B of them, and write neighbouring output rows of one frame.
+  const uint32_t lin = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (lin >= ncells) return;
+  const uint32_t per_frame = ncells / (uint32_t)s.B;
+  const uint32_t cell = (lin % per_frame) * (uint32_t)s.B + lin / per_frame;
   const int lane = threadIdx.x & 63;
   const int slot = lane / lpr;
   const int cv = lane - slot * lpr;
