@@ -173,11 +173,15 @@ def main():
     cfg = synth.CL_CONFIG
     B = max(1, args.batch)
     # ---- synthetic frame (per rank: its own seed -> its own features / point cloud; same calibration) ----
-    inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank)   # B frames: same calibration, independent features
+    inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank, with_feats=False)   # B frames: same calibration
     H, W, D = (int(v) for v in inp["nx"])
     C = inp["channels"]
     geom = torch.from_numpy(inp["geom"]).to(dev)
-    feats = torch.from_numpy(inp["feats"]).to(dev)
+    # independent random features per frame and rank, drawn on the device (5 GB at 8 frames: minutes of host RNG + PCIe)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    feats = torch.randn((geom.shape[0], C), generator=gen, device=dev, dtype=torch.float32)
+    n_cam = cfg["num_cameras"]
+    inp["feats"] = feats[: 2 * (geom.shape[0] // (n_cam * B))].cpu().numpy()   # what the CPU baseline's sample reads
     if args.feat_dtype == "bf16":
         feats = feats.bfloat16()
     elem = feats.element_size()
