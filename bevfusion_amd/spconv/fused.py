@@ -239,8 +239,22 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
     K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
     out = torch.empty((out_lvl.n_cap, cout), dtype=dtype, device=x.features.device)
     ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
-                          residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out)
+                          residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
+                          variant=_variant_for(lvl.batch, K, cin, cout))
     return FusedTensor(out, out_lvl)
+
+
+# Tiling per layer shape when a step carries several frames.  The library's own choice (variant 0) is tuned on one frame's row
+# counts, where the 128-channel layers have fewer row blocks than the GPU has CUs and want the smallest tile; the live row count is
+# unknown to the host here (capacity launches), so the frame count stands in for it.  tools/sweep_spconv.py --frames 8:
+# 128->128 228 -> 194 us, 64->128 128 -> 102 us, 32->64 153 -> 145 us, 32->32 274 -> 266 us, 64->64 251 -> 246 us.
+_BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 2211, (128, 128): 2221}
+
+
+def _variant_for(batch, K, cin, cout):
+    if batch >= 6 and K == 27:   # measured neutral at 4 frames (3.15 vs 3.17 ms per step), +4 % at 8
+        return _BATCHED_VARIANTS.get((ops.padded_channels(cin), cout), 0)
+    return 0
 
 
 def _sequential(seq, x):

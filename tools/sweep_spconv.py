@@ -43,30 +43,35 @@ def timeit(fn, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--frames", type=int, default=1, help="frames in the batch (row counts scale with it)")
+    ap.add_argument("--quick", action="store_true", help="skip the round-0 kernel and the layers with < 32 input channels")
     ap.add_argument("--ablate", action="store_true", help="time the 64->64 / 128->128 SubM layers with parts of the kernel compiled out")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     dev = torch.device("cuda", 0)
     cfg = synth.CL_CONFIG
-    pts = torch.from_numpy(synth.lidar_points(seed=0)).to(dev)
-    vf, vc, _ = voxelize_batch([pts], cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][1])
+    pts = [torch.from_numpy(synth.lidar_points(seed=b)).to(dev) for b in range(args.frames)]
+    vf, vc, _ = voxelize_batch(pts, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][1])
     shape = list(cfg["sparse_shape"])
     ind = vc.int().contiguous()
+    NB = args.frames
     layers = []   # (name, rulebook, n_in, cin, cout)
     stages = [(16, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (32, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
               (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 0)), (128, 128, (1, 1, 3), (1, 1, 2), (0, 0, 0))]
     c = 16
-    rb = sops.build_rulebook(ind, 1, shape, 3, 1, 1, 1, True)
+    rb = sops.build_rulebook(ind, NB, shape, 3, 1, 1, 1, True)
     layers.append(("subm1 5(8)->16", rb, ind.shape[0], 8, 16))
     for i, (cin, cout, ks, st, pd) in enumerate(stages):
         layers.append((f"subm{i + 1} {cin}->{cin}", rb, ind.shape[0], cin, cin))
-        rbs = sops.build_rulebook(ind, 1, shape, list(ks), list(st), list(pd), 1, False)
+        rbs = sops.build_rulebook(ind, NB, shape, list(ks), list(st), list(pd), 1, False)
         layers.append((f"spconv{i + 1} {cin}->{cout} k{ks} s{st}", rbs, ind.shape[0], cin, cout))
         ind, shape = rbs.out_indices.contiguous(), rbs.out_spatial_shape
         if i < 3:
-            rb = sops.build_rulebook(ind, 1, shape, 3, 1, 1, 1, True)
+            rb = sops.build_rulebook(ind, NB, shape, 3, 1, 1, 1, True)
     print(f"# tiled sparse conv sweep, dtype={args.dtype}; time = us per launch, 20 back-to-back launches behind a busy GPU (host overhead excluded)")
     for name, rb, n_in, cin, cout in layers:
+        if args.quick and cin < 32:
+            continue
         K = rb.nbr.shape[0]
         f = torch.randn(n_in, cin, device=dev).to(dt)
         w = (torch.randn(K, cin, cout, device=dev) / (K * cin) ** 0.5).to(dt)
@@ -93,6 +98,8 @@ def main():
             except RuntimeError:
                 continue   # not built for this shape
             print(f"    variant {v:4d}: {med:8.1f} us ({mn:8.1f})  {gflop / med * 1e3:8.1f} TFLOP/s eff")
+        if args.quick:
+            continue
         # old kernel for comparison
         from bevfusion_amd import _capi
         prep = sops.prepare_filters(w.view(K, 1, 1, cin, cout))
