@@ -247,7 +247,9 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
 # Tiling per layer shape when a step carries several frames.  The library's own choice (variant 0) is tuned on one frame's row
 # counts, where the 128-channel layers have fewer row blocks than the GPU has CUs and want the smallest tile; the live row count is
 # unknown to the host here (capacity launches), so the frame count stands in for it.  tools/sweep_spconv.py --frames 8:
-# 128->128 228 -> 194 us, 64->128 128 -> 102 us, 32->64 153 -> 145 us, 32->32 274 -> 266 us, 64->64 251 -> 246 us.
+# 128->128 228 -> 194 us, 64->128 128 -> 102 us, 32->64 153 -> 145 us, 32->32 274 -> 266 us, 64->64 251 -> 246 us
+# (A/B on one box, 8 frames: LiDAR branch 6.11-6.18 -> 5.91-5.94 ms; entries for the 5->16 and 16->32 layers, 10-16 % faster
+# in isolation, changed nothing inside the graph and were left out).
 _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 2211, (128, 128): 2221}
 
 

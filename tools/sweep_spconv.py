@@ -44,6 +44,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--frames", type=int, default=1, help="frames in the batch (row counts scale with it)")
+    ap.add_argument("--small", action="store_true", help="only the layers with < 32 input channels (and no round-0 kernel)")
     ap.add_argument("--quick", action="store_true", help="skip the round-0 kernel and the layers with < 32 input channels")
     ap.add_argument("--ablate", action="store_true", help="time the 64->64 / 128->128 SubM layers with parts of the kernel compiled out")
     args = ap.parse_args()
@@ -70,7 +71,7 @@ def main():
             rb = sops.build_rulebook(ind, NB, shape, 3, 1, 1, 1, True)
     print(f"# tiled sparse conv sweep, dtype={args.dtype}; time = us per launch, 20 back-to-back launches behind a busy GPU (host overhead excluded)")
     for name, rb, n_in, cin, cout in layers:
-        if args.quick and cin < 32:
+        if (args.quick and cin < 32) or (args.small and cin >= 32):
             continue
         K = rb.nbr.shape[0]
         f = torch.randn(n_in, cin, device=dev).to(dt)
@@ -98,7 +99,7 @@ def main():
             except RuntimeError:
                 continue   # not built for this shape
             print(f"    variant {v:4d}: {med:8.1f} us ({mn:8.1f})  {gflop / med * 1e3:8.1f} TFLOP/s eff")
-        if args.quick:
+        if args.quick or args.small:
             continue
         # old kernel for comparison
         from bevfusion_amd import _capi
