@@ -72,16 +72,24 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t k) {
   return k;
 }
 
+// Home slot of a key: sample b's keys start in region b of the table (`region` slots each, a power of two; probing still
+// wraps over the whole table, so an over-full region spills into the next one instead of failing).  The rows of one
+// sample are consecutive, so the workgroups looking up its neighbours touch 1/B of the table at a time — it stays in L2
+// when a step carries several frames (a 32 MB table at 8 frames otherwise misses on most probes).
+__device__ __forceinline__ uint32_t hash_home(uint32_t key, uint32_t b, uint32_t mask, uint32_t region) {
+  return (b * region + (hash_u32(key) & (region - 1u))) & mask;
+}
+
 __global__ __launch_bounds__(256) void sp_hash_insert_kernel(const int* __restrict__ indices, int n_cap,
                                                              const int* __restrict__ n_dev, ConvGeom g,
-                                                             uint2* __restrict__ slots, uint32_t mask) {
+                                                             uint2* __restrict__ slots, uint32_t mask, uint32_t region) {
   int i = blockIdx.x * 256 + threadIdx.x;
   int n = n_dev ? *n_dev : n_cap;
   if (n > n_cap) n = n_cap;
   if (i >= n) return;
   const int4 c = ((const int4*)indices)[i];  // (b, x, y, z)
   uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + c.y) * g.in_shape[1] + c.z) * g.in_shape[2] + c.w);
-  uint32_t slot = hash_u32(key) & mask;
+  uint32_t slot = hash_home(key, (uint32_t)c.x, mask, region);
   for (uint32_t probe = 0; probe <= mask; ++probe) {  // bounded: a full table drops the row instead of spinning
     uint32_t prev = atomicCAS(&slots[slot].x, HASH_EMPTY, key);
     if (prev == HASH_EMPTY || prev == key) { slots[slot].y = (uint32_t)i; return; }
@@ -90,8 +98,9 @@ __global__ __launch_bounds__(256) void sp_hash_insert_kernel(const int* __restri
 }
 
 // slots are (key, row) pairs: a probe is ONE 8-byte load (keys and rows in separate arrays cost two cache lines per hit)
-__device__ __forceinline__ int hash_lookup(const uint2* __restrict__ slots, uint32_t mask, uint32_t key) {
-  uint32_t slot = hash_u32(key) & mask;
+__device__ __forceinline__ int hash_lookup(const uint2* __restrict__ slots, uint32_t mask, uint32_t region, uint32_t b,
+                                           uint32_t key) {
+  uint32_t slot = hash_home(key, b, mask, region);
   for (uint32_t probe = 0; probe <= mask; ++probe) {
     const uint2 e = slots[slot];
     if (e.x == key) return (int)e.y;
@@ -127,13 +136,13 @@ enum { INDEX_HASH = 0, INDEX_RANK = 1 };
 
 struct IndexRef {  // how to find the row of an input cell
   const uint2* slots;
-  uint32_t mask;
+  uint32_t mask, region;
   const uint2* words;
 };
 
 template <int KIND>
-__device__ __forceinline__ int index_lookup(const IndexRef& ix, uint32_t key) {
-  if constexpr (KIND == INDEX_HASH) return hash_lookup(ix.slots, ix.mask, key);
+__device__ __forceinline__ int index_lookup(const IndexRef& ix, uint32_t b, uint32_t key) {
+  if constexpr (KIND == INDEX_HASH) return hash_lookup(ix.slots, ix.mask, ix.region, b, key);
   else return rank_lookup(ix.words, key);
 }
 
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out
     int r = -1;
     if (axis_out_to_in(g, 0, c.y, kx, ix_) && axis_out_to_in(g, 1, c.z, ky, iy) && axis_out_to_in(g, 2, c.w, kz, iz)) {
       uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
-      r = index_lookup<KIND>(ix, key);
+      r = index_lookup<KIND>(ix, (uint32_t)c.x, key);
     }
     nbr[(size_t)k * nbr_stride + o] = r;
   }
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256) void sp_nbr_subm_sym_kernel(const int* __restr
     int r = -1;
     if (ix_ >= 0 && ix_ < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && iz >= 0 && iz < g.in_shape[2]) {
       uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
-      r = index_lookup<KIND>(ix, key);
+      r = index_lookup<KIND>(ix, (uint32_t)c.x, key);
     }
     nbr[(size_t)k * nbr_stride + o] = r;
     if (r >= 0 && r < m) nbr[(size_t)(g.K - 1 - k) * nbr_stride + r] = o;
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(256) void sp_dense_bev_kernel(const T* __restrict__
   for (int t = threadIdx.x; t < 64 * Z; t += 256) {
     const int d = t >> 6, w = w0 + (t & 63);
     int r = -1;
-    if (w < Y) r = index_lookup<KIND>(ix, (uint32_t)((((long long)b * X + h) * Y + w) * Z + d));
+    if (w < Y) r = index_lookup<KIND>(ix, (uint32_t)b, (uint32_t)((((long long)b * X + h) * Y + w) * Z + d));
     rows[t] = r;
   }
   __syncthreads();
@@ -473,6 +482,12 @@ static int make_geom(int batch, const int* in_shape, const int* out_shape, const
   return BEVAMD_OK;
 }
 
+static uint32_t hash_region(uint32_t cap, int batch) {  // slots per sample region: cap / (batch rounded up to a power of two)
+  uint32_t parts = 1;
+  while ((int)parts < batch && parts < cap) parts <<= 1;
+  return cap / parts;
+}
+
 static uint32_t hash_capacity(size_t n) {
   uint32_t cap = 1024;
   while (cap < 2 * n + 16) cap <<= 1;
@@ -508,17 +523,18 @@ static int hash_build(const int* indices, int n_cap, const int* n_dev, const Con
   int frc = fill_u32(slots, (size_t)cap * 8, HASH_EMPTY, stream);   // rows are overwritten by the insert
   if (frc) return frc;
   if (n_cap > 0) {
-    sp_hash_insert_kernel<<<dim3(cdiv(n_cap, 256)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, slots, cap - 1);
+    sp_hash_insert_kernel<<<dim3(cdiv(n_cap, 256)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, slots, cap - 1, hash_region(cap, g.batch));
     BEVAMD_LAUNCH_CHECK("sp_hash_insert");
   }
   return BEVAMD_OK;
 }
 
-static IndexRef hash_ref(const void* index, int n_cap) {
+static IndexRef hash_ref(const void* index, int n_cap, int batch) {
   const uint32_t cap = hash_capacity((size_t)n_cap);
   IndexRef r;
   r.slots = (const uint2*)index;
   r.mask = cap - 1;
+  r.region = hash_region(cap, batch);
   r.words = nullptr;
   return r;
 }
@@ -527,6 +543,7 @@ static IndexRef rank_ref(const void* index) {
   IndexRef r;
   r.slots = nullptr;
   r.mask = 0;
+  r.region = 1;
   r.words = (const uint2*)index;
   return r;
 }
@@ -657,7 +674,7 @@ int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev,
   BEVAMD_REQUIRE(m_cap >= 0 && nbr_stride >= m_cap, "spconv_neighbors: nbr_stride %d < m_cap %d", nbr_stride, m_cap);
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(out_indices && in_index && nbr, "spconv_neighbors: null buffer");
-  const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(in_index, in_index_n_cap) : rank_ref(in_index);
+  const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(in_index, in_index_n_cap, batch_size) : rank_ref(in_index);
   return neighbors(out_indices, m_cap, m_dev, g, index_kind, ix, nbr, nbr_stride, subm != 0, (hipStream_t)stream_);
 }
 
@@ -672,7 +689,7 @@ int bevamd_spconv_dense_bev(const void* features, int elem_bytes, int pitch, int
   const int X = shape[0], Y = shape[1], Z = shape[2];
   BEVAMD_REQUIRE(X > 0 && Y > 0 && Z > 0 && Z <= 512 && X <= 65535 && batch_size <= 65535, "spconv_dense_bev: bad shape");
   BEVAMD_REQUIRE((unsigned long long)batch_size * X * Y * Z < 0xFFFFFFF0ull, "spconv_dense_bev: batch * volume must be < 2^32 - 16");
-  const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(index, index_n_cap) : rank_ref(index);
+  const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(index, index_n_cap, batch_size) : rank_ref(index);
   dim3 grid(cdiv(Y, 64), X, batch_size), block(256);
   const size_t lds = (size_t)64 * Z * sizeof(int);
 #define BEVAMD_DENSE(T, KIND) \
@@ -744,7 +761,7 @@ int bevamd_spconv_build_rulebook(const int* indices, int n, int batch_size, cons
     BEVAMD_REQUIRE(nbr_stride >= n, "spconv_build_rulebook: nbr_stride %d < n %d", nbr_stride, n);
     rc = hash_build(indices, n, nullptr, g, ws, hbytes, stream);
     if (rc) return rc;
-    rc = neighbors(indices, n, nullptr, g, INDEX_HASH, hash_ref(ws, n), nbr, nbr_stride, true, stream);
+    rc = neighbors(indices, n, nullptr, g, INDEX_HASH, hash_ref(ws, n, batch_size), nbr, nbr_stride, true, stream);
     if (rc) return rc;
     if (out_indices && out_indices != indices)
       BEVAMD_HIP_CHECK(hipMemcpyAsync(out_indices, indices, (size_t)n * 4 * sizeof(int), hipMemcpyDeviceToDevice, stream));
