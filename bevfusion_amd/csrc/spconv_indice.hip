@@ -456,6 +456,62 @@ __global__ __launch_bounds__(256) void sp_dense_bev_kernel(const T* __restrict__
   }
 }
 
+// Same result with the tile's rows staged through LDS: the 64*Z rows of a tile are copied in with coalesced loads (a row
+// per wave instruction) instead of being read 2 bytes at a time, one row per lane, once per channel; the transposed
+// reads then come out of LDS (pitch = row + 4 bytes: an odd number of dwords, conflict-free along the row index).
+// Needs row bytes % 4 == 0 and 64*Z*(row + 4) bytes of LDS; the host falls back to the kernel above otherwise.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void sp_dense_bev_staged_kernel(const T* __restrict__ feat, int pitch, int C, IndexRef ix,
+                                                                  int X, int Y, int Z, T* __restrict__ out) {
+  extern __shared__ int rows[];  // [Z][64] row ids, then the staged rows
+  const int b = blockIdx.z, h = blockIdx.y, w0 = blockIdx.x * 64;
+  const int nrows = 64 * Z;
+  for (int t = threadIdx.x; t < nrows; t += 256) {
+    const int d = t >> 6, w = w0 + (t & 63);
+    int r = -1;
+    if (w < Y) r = index_lookup<KIND>(ix, (uint32_t)b, (uint32_t)((((long long)b * X + h) * Y + w) * Z + d));
+    rows[t] = r;
+  }
+  __syncthreads();
+  const int row_dw = C * (int)sizeof(T) / 4, lpitch = row_dw + 1;   // dwords
+  uint32_t* tile = (uint32_t*)(rows + nrows);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < nrows; t += 4) {   // one staged row per wave and trip; all loads of a trip are independent
+    const int r = rows[t];
+    const uint32_t* src = (const uint32_t*)(feat + (size_t)(r >= 0 ? r : 0) * pitch);
+    for (int j = lane; j < row_dw; j += 64) tile[t * lpitch + j] = r >= 0 ? src[j] : 0u;
+  }
+  __syncthreads();
+  const int CZ = C * Z;
+  const T* tl = (const T*)tile;
+  constexpr int EPD = 4 / (int)sizeof(T);   // elements per dword
+  constexpr int YPL = 8 / (int)sizeof(T);   // y positions per lane: one 8-byte store
+  if (Y % YPL == 0) {
+    // a lane stores YPL consecutive y of one (channel, z) plane (8 bytes: rows of the output start 8-byte aligned when
+    // Y % YPL == 0), a wave 64*YPL/64 planes per instruction — 4x fewer store instructions than one element per lane
+    constexpr int LPP = 64 / YPL;            // lanes per plane row of the tile
+    constexpr int PPI = 64 / LPP;            // planes per wave instruction
+    const int sub = lane / LPP, chunk = lane % LPP;
+    for (int idx0 = wave * PPI; idx0 < CZ; idx0 += 4 * PPI) {
+      const int idx = idx0 + sub;
+      if (idx >= CZ) continue;
+      const int c = idx / Z, d = idx - c * Z;
+      T v[YPL];
+#pragma unroll
+      for (int e = 0; e < YPL; ++e) v[e] = tl[(size_t)(d * 64 + chunk * YPL + e) * lpitch * EPD + c];
+      const int w = w0 + chunk * YPL;
+      if (w < Y) *(uint2*)(out + (((size_t)b * CZ + idx) * X + h) * Y + w) = *(const uint2*)v;   // w + YPL <= Y: both multiples of YPL
+    }
+    return;
+  }
+  const int w = w0 + lane;
+  for (int idx = wave; idx < CZ; idx += 4) {
+    const int c = idx / Z, d = idx - c * Z;
+    const T v = tl[(size_t)(d * 64 + lane) * lpitch * EPD + c];
+    if (w < Y) out[(((size_t)b * CZ + idx) * X + h) * Y + w] = v;
+  }
+}
+
 static int make_geom(int batch, const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
                      const int* pad, const int* dil, int subm, ConvGeom& g, int transpose = 0) {
   BEVAMD_REQUIRE(in_shape && out_shape && ksize && stride && pad, "spconv: null geometry (host pointers)");
@@ -691,9 +747,15 @@ int bevamd_spconv_dense_bev(const void* features, int elem_bytes, int pitch, int
   BEVAMD_REQUIRE((unsigned long long)batch_size * X * Y * Z < 0xFFFFFFF0ull, "spconv_dense_bev: batch * volume must be < 2^32 - 16");
   const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(index, index_n_cap, batch_size) : rank_ref(index);
   dim3 grid(cdiv(Y, 64), X, batch_size), block(256);
-  const size_t lds = (size_t)64 * Z * sizeof(int);
-#define BEVAMD_DENSE(T, KIND) \
-  sp_dense_bev_kernel<T, KIND><<<grid, block, lds, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out)
+  size_t lds = (size_t)64 * Z * sizeof(int);
+  const size_t row_bytes = (size_t)channels * elem_bytes;
+  const size_t staged = lds + (size_t)64 * Z * (row_bytes + 4);
+  const bool stage = ((uintptr_t)out & 7) == 0 && row_bytes % 4 == 0 && ((size_t)pitch * elem_bytes) % 4 == 0 && ((uintptr_t)features & 3) == 0 && staged <= 64 * 1024;
+#define BEVAMD_DENSE(T, KIND)                                                                                               \
+  do {                                                                                                                      \
+    if (stage) sp_dense_bev_staged_kernel<T, KIND><<<grid, block, staged, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out); \
+    else sp_dense_bev_kernel<T, KIND><<<grid, block, lds, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out);          \
+  } while (0)
   if (elem_bytes == 2) {
     if (index_kind == INDEX_HASH) BEVAMD_DENSE(uint16_t, INDEX_HASH); else BEVAMD_DENSE(uint16_t, INDEX_RANK);
   } else {
