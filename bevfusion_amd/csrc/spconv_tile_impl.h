@@ -102,7 +102,7 @@ static int run_shape(const Args& a, int variant, hipStream_t stream) {
     const size_t img = (size_t)StepShape<CINP, Chunks<CINP>::CPB>::nsteps(a.K) * Chunks<CINP>::CPB * NT * 1024;  // unpadded image
     if (NT >= 8) variant = 2121;
     else if (CINP >= 64) variant = 2211;
-    else if (CINP == 32) variant = 2212;
+    else if (CINP == 32) variant = 2213;   // 3 offsets per barrier: 37.7 vs 38.8 us on 32->32, 22.1 vs 23.2 on 32->64
     else if (resident_built<CINP, NT, 2, 1>() &&
              img + (size_t)8 * a.K * 32 * 4 + (size_t)8 * EpiScratch<NT>::U4 * 16 <= 65536) variant = 1221;   // 8 waves
     else if (resident_built<CINP, NT, 2, 1>() &&
