@@ -5,6 +5,17 @@ package.  Nothing under `bevfusion_amd/` imports it; the product path has no CPU
 
 `oracle/*.c` is plain C (gcc); `build()` compiles it into `oracle/_build/liboracle.so`.
 The numpy wrappers below cite the reference lines they follow.
+
+Parity pins (tests/golden/, each with the script that generated it from the reference's own code):
+  bev_pool            bev_pool_ref_small.npz   reference kernel (hipified, run on an MI355X)     test_oracle_bev_pool.py
+  hard voxelization   voxel_ref_{a,b,c}.npz    reference hard_voxelize_cpu                       test_oracle_voxel.py
+  spconv (encoder)    spconv_ref_*.npz         reference CPU functors                            test_oracle_spconv.py
+  spconv (ext rest)   spconv_ext_*.npz         reference CPU functors (transposed, dilated, 2D,
+                                               inverse conv, max pooling)                        test_oracle_spconv_ext.py
+  dynamic scatter     scatter_ref.npz          reference GPU kernels (hipified, run on an MI355X) test_oracle_scatter.py
+  iou3d               iou3d_ref.npz            reference GPU kernels (hipified, run on an MI355X) test_oracle_iou3d.py
+  view-transform glue (Python in the reference): restated in numpy and checked against the module's torch formulation
+                                                                                                 test_host_mirror.py
 """
 import ctypes
 import os
