@@ -6,7 +6,7 @@ PyTorch is used by callers for device memory and streams only.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbevfusion_amd.so")
@@ -16,6 +16,7 @@ _lib = None
 P = c_void_p
 I = c_int
 Z = c_size_t
+LL = c_longlong
 
 # name -> (restype, argtypes); must list every function of include/bevfusion_amd.h
 _SIGNATURES = {
@@ -37,6 +38,8 @@ _SIGNATURES = {
     "bevamd_depth_raster_workspace_bytes": (Z, [I, I, I]),
     "bevamd_depth_raster": (I, [P, I, I, P, P, P, P, I, I, I, P, P, Z, P]),
     "bevamd_lss_geometry": (I, [P, I, P, P, P, P, P, P, I, I, P, P]),
+    "bevamd_mat3_inverse": (I, [P, LL, LL, I, P, P]),
+    "bevamd_lss_camera_matrices": (I, [P, P, P, LL, LL, I, P, P, P]),
     # voxelization
     "bevamd_hard_voxelize_workspace_bytes": (Z, [I]),
     "bevamd_hard_voxelize": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, Z, P]),

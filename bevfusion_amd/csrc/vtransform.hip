@@ -7,13 +7,22 @@
 //   camera.  Here: one thread per (point, camera); colliding points are resolved as "the LAST point in input order wins"
 //   (what the reference's assignment gives on CPU; on GPU its index_put is unordered) with an atomicMax on the point
 //   index followed by a second pass that lets only the winner write — deterministic, no sort.
-//   Arithmetic follows the reference op by op in fp32 (subtract, 3x3 products as k-ordered fma chains, true division,
-//   truncation toward zero like `.long()`); `dist` is the CLAMPED depth, because the reference's `dist` is a view of
-//   the tensor it clamps in place (base.py:300-302).
+//   Arithmetic follows the reference op by op in fp32: subtract, the three GEMMs ([3,3]x[3,n], [N,3,3]x[3,n],
+//   [N,3,3]x[N,3,n] -> BLAS sgemm) as k-ascending chains of FUSED multiply-adds, true division, truncation toward zero like
+//   `.long()`; `dist` is the CLAMPED depth, because the reference's `dist` is a view of the tensor it clamps in place
+//   (base.py:300-302).  Bit-exact against tests/golden/vtransform_ref.npz (the reference's own function body on CPU torch).
 //
 // frustum geometry — BaseTransform.get_geometry (base.py:92-135): frustum (u, v, d) -> lidar frame, one thread per
-//   frustum point and camera, same op order.  Static per calibration; it exists so that building a pooling plan for a new
-//   calibration is two launches (this + bevamd_bev_pool_prepare_from_geom) instead of ~10 broadcasting matmuls.
+//   frustum point and camera, same op order.  Its 3x3 products are per-point broadcast bmm's (ATen's naive kernel:
+//   acc = 0; acc += a_k * b_k, k ascending, product and sum rounded SEPARATELY) -> __fmul_rn / __fadd_rn here, never
+//   contracted to an fma.  Bit-exact against the same fixture at the flagship size (SHA-256 of the 24 MB result).
+//   Static per calibration; it exists so that building a pooling plan for a new calibration is two launches (this +
+//   bevamd_bev_pool_prepare_from_geom) instead of ~10 broadcasting matmuls.
+//
+// camera matrices — the 3x3 inverses in front of both (torch.inverse = LAPACK getrf/getrs in the reference, third-party
+//   arithmetic that is not even layout-stable on CPU): `mat3_inverse_kernel` evaluates adjugate / determinant in fp64 and
+//   rounds once to fp32 (within 1-2 ulp of any fp32 LU), one thread per matrix, so that a new calibration costs no
+//   host-side LAPACK call and no host sync.
 #include "common.h"
 
 namespace bevamd {
@@ -28,11 +37,20 @@ __device__ __forceinline__ Mat3 load_mat3(const float* __restrict__ p, int row_s
     for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = p[i * row_stride + j];
   return r;
 }
-// y = M x as torch's matmul evaluates a k = 3 product: one multiply, two fused multiply-adds, k ascending
+// y = M x as a BLAS sgemm evaluates a k = 3 product: one multiply, two fused multiply-adds, k ascending
 __device__ __forceinline__ void mat3_apply(const Mat3& M, float x, float y, float z, float& ox, float& oy, float& oz) {
   ox = fmaf(M.m[2], z, fmaf(M.m[1], y, M.m[0] * x));
   oy = fmaf(M.m[5], z, fmaf(M.m[4], y, M.m[3] * x));
   oz = fmaf(M.m[8], z, fmaf(M.m[7], y, M.m[6] * x));
+}
+// y = M x as ATen's naive bmm kernel evaluates it: every product and every sum rounded on its own (0 + p is exact)
+__device__ __forceinline__ float dot3_rn(float a0, float a1, float a2, float x, float y, float z) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(a0, x), __fmul_rn(a1, y)), __fmul_rn(a2, z));
+}
+__device__ __forceinline__ void mat3_apply_rn(const Mat3& M, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = dot3_rn(M.m[0], M.m[1], M.m[2], x, y, z);
+  oy = dot3_rn(M.m[3], M.m[4], M.m[5], x, y, z);
+  oz = dot3_rn(M.m[6], M.m[7], M.m[8], x, y, z);
 }
 
 struct RasterArgs {
@@ -108,23 +126,72 @@ __global__ __launch_bounds__(256) void lss_geometry_kernel(GeomArgs a, float* __
   const float* pt = a.post_trans + (size_t)cam * 3;
   float x = f[0] - pt[0], y = f[1] - pt[1], z = f[2] - pt[2];
   float u, v, w;
-  mat3_apply(load_mat3(a.post_rot_inv + (size_t)cam * 9, 3), x, y, z, u, v, w);
-  u = u * w;   // (x*z, y*z, z)  base.py:110-116
-  v = v * w;
-  mat3_apply(load_mat3(a.combine + (size_t)cam * 9, 3), u, v, w, x, y, z);
+  mat3_apply_rn(load_mat3(a.post_rot_inv + (size_t)cam * 9, 3), x, y, z, u, v, w);
+  u = __fmul_rn(u, w);   // (x*z, y*z, z)  base.py:110-116
+  v = __fmul_rn(v, w);
+  mat3_apply_rn(load_mat3(a.combine + (size_t)cam * 9, 3), u, v, w, x, y, z);
   const float* ct = a.c2l_trans + (size_t)cam * 3;
-  x += ct[0]; y += ct[1]; z += ct[2];
+  x = __fadd_rn(x, ct[0]); y = __fadd_rn(y, ct[1]); z = __fadd_rn(z, ct[2]);
   const int b = cam / a.cams_per_sample;
   if (a.extra_rot) {
-    mat3_apply(load_mat3(a.extra_rot + (size_t)b * 9, 3), x, y, z, u, v, w);
+    mat3_apply_rn(load_mat3(a.extra_rot + (size_t)b * 9, 3), x, y, z, u, v, w);
     x = u; y = v; z = w;
   }
   if (a.extra_trans) {
     const float* et = a.extra_trans + (size_t)b * 3;
-    x += et[0]; y += et[1]; z += et[2];
+    x = __fadd_rn(x, et[0]); y = __fadd_rn(y, et[1]); z = __fadd_rn(z, et[2]);
   }
   float* o = geom + (size_t)t * 3;
   o[0] = x; o[1] = y; o[2] = z;
+}
+
+// ---- per-camera matrices ------------------------------------------------------------------------------------------------
+// out[i] = inverse(m[i]) for `count` 3x3 matrices addressed m + i*mat_stride + r*row_stride + c (so the top-left block of a
+// 4x4 is mat_stride 16, row_stride 4): cofactors and determinant in fp64 (exact products of fp32 inputs, <= 3 roundings per
+// entry), one rounding to fp32.
+__device__ __forceinline__ void mat3_inverse_f64(const float* __restrict__ m, long long row_stride, float* __restrict__ o) {
+  double a[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[r * 3 + c] = (double)m[r * row_stride + c];
+  const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  const double r = 1.0 / det;
+  o[0] = (float)(c00 * r);
+  o[1] = (float)((a[2] * a[7] - a[1] * a[8]) * r);
+  o[2] = (float)((a[1] * a[5] - a[2] * a[4]) * r);
+  o[3] = (float)(c01 * r);
+  o[4] = (float)((a[0] * a[8] - a[2] * a[6]) * r);
+  o[5] = (float)((a[2] * a[3] - a[0] * a[5]) * r);
+  o[6] = (float)(c02 * r);
+  o[7] = (float)((a[1] * a[6] - a[0] * a[7]) * r);
+  o[8] = (float)((a[0] * a[4] - a[1] * a[3]) * r);
+}
+
+__global__ void mat3_inverse_kernel(const float* __restrict__ m, long long mat_stride, long long row_stride, int count,
+                                    float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) mat3_inverse_f64(m + (size_t)i * mat_stride, row_stride, out + (size_t)i * 9);
+}
+
+// post_rot_inv[i] = inverse(post_rots[i]); combine[i] = c2l_rots[i] @ inverse(intrins[i]) (base.py:106, 118; the product
+// in the naive-bmm order: acc = 0; acc += a[r][k] * b[k][c], k ascending, separate roundings)
+__global__ void lss_camera_matrices_kernel(const float* __restrict__ post_rots, const float* __restrict__ c2l_rots,
+                                           const float* __restrict__ intrins, long long mat_stride, long long row_stride,
+                                           int count, float* __restrict__ post_rot_inv, float* __restrict__ combine) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  mat3_inverse_f64(post_rots + (size_t)i * mat_stride, row_stride, post_rot_inv + (size_t)i * 9);
+  float ik[9];
+  mat3_inverse_f64(intrins + (size_t)i * mat_stride, row_stride, ik);
+  const float* R = c2l_rots + (size_t)i * mat_stride;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      combine[(size_t)i * 9 + r * 3 + c] =
+          dot3_rn(R[r * row_stride + 0], R[r * row_stride + 1], R[r * row_stride + 2], ik[c], ik[3 + c], ik[6 + c]);
 }
 
 }  // namespace bevamd
@@ -178,6 +245,33 @@ int bevamd_lss_geometry(const float* frustum, int frustum_points, const float* p
   const long long total = (long long)frustum_points * a.ncam_total;
   lss_geometry_kernel<<<dim3(cdiv(total, 256)), dim3(256), 0, stream>>>(a, geom);
   BEVAMD_LAUNCH_CHECK("lss_geometry");
+  return BEVAMD_OK;
+}
+
+/* out[i] = inverse of the 3x3 at m + i*mat_stride + r*row_stride + c, i < count (fp64 adjugate / determinant, one rounding).
+ * Replaces torch.inverse at base.py:106, 118, 292 on the device path; no workspace, no host sync. */
+int bevamd_mat3_inverse(const float* m, long long mat_stride, long long row_stride, int count, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(count >= 0 && row_stride >= 3 && mat_stride >= 0, "mat3_inverse: bad sizes");
+  if (count == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(m && out, "mat3_inverse: null buffer");
+  mat3_inverse_kernel<<<dim3(cdiv(count, 64)), dim3(64), 0, stream>>>(m, mat_stride, row_stride, count, out);
+  BEVAMD_LAUNCH_CHECK("mat3_inverse");
+  return BEVAMD_OK;
+}
+
+/* The two per-camera matrices bevamd_lss_geometry consumes, from the raw calibration (all three inputs share one
+ * (mat_stride, row_stride) addressing, e.g. 16 / 4 for the top-left blocks of [B, N, 4, 4] tensors):
+ * post_rot_inv[i] = inverse(post_rots[i]), combine[i] = camera2lidar_rots[i] @ inverse(intrins[i]), i < ncam_total. */
+int bevamd_lss_camera_matrices(const float* post_rots, const float* camera2lidar_rots, const float* intrins,
+                               long long mat_stride, long long row_stride, int ncam_total, float* post_rot_inv,
+                               float* combine, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(ncam_total > 0 && row_stride >= 3 && mat_stride >= 0, "lss_camera_matrices: bad sizes");
+  BEVAMD_REQUIRE(post_rots && camera2lidar_rots && intrins && post_rot_inv && combine, "lss_camera_matrices: null buffer");
+  lss_camera_matrices_kernel<<<dim3(cdiv(ncam_total, 64)), dim3(64), 0, stream>>>(post_rots, camera2lidar_rots, intrins, mat_stride,
+                                                                           row_stride, ncam_total, post_rot_inv, combine);
+  BEVAMD_LAUNCH_CHECK("lss_camera_matrices");
   return BEVAMD_OK;
 }
 

@@ -7,7 +7,8 @@ Same class names, constructor kwargs, attributes (`dx, bx, nx, frustum, D, C`), 
 What changed underneath (`BaseTransform.bev_pool`, base.py:141-176):
   * index computation + batch index + range mask + rank + sort + interval search happen in ONE device pipeline
     (`BevPoolPlan.from_geometry`) with no boolean gather of the feature volume and no host sync; with
-    `cache_geometry=True` (static calibration at inference) it is done once and reused;
+    `cache_geometry=True` (static calibration at inference; keyed on the calibration / augmentation matrices or a
+    caller-supplied `calibration_id`, ignored while training) it is done once and reused;
   * the reduction reads the feature rows through the sort permutation (no `feats[indices]` copy) and writes
     every BEV cell once; the result is returned as a channels-last VIEW of that buffer ([B, C*D, H, W] values
     identical to the reference's `torch.cat(x.unbind(dim=2), 1)`).
@@ -83,9 +84,14 @@ class BaseTransform(nn.Module):
         self.fp16_enabled = False
         # MI355X-native knobs (not in the reference): reuse the bev_pool precompute across frames; keep depth and
         # context factored and fold their outer product into the pooling kernel, forward and backward
-        self.cache_geometry = False
+        self.cache_geometry = False     # eval only; keyed on the calibration (see _calibration_key), never on shapes alone
         self._plan = None
+        self._plan_key = None
+        self._pending_key = None
         self.fused_cam_feats = True
+        # 3x3 inverses of the calibration on the device path: False = bevamd_lss_camera_matrices / bevamd_mat3_inverse
+        # (fp64 adjugate, no LAPACK call, no host sync); True = torch.inverse like the reference, call for call
+        self.lapack_inverse = False
 
     def create_frustum(self):
         """base.py:66-89."""
@@ -123,22 +129,38 @@ class BaseTransform(nn.Module):
         return points
 
     def _get_geometry_native(self, c2l_rots, c2l_trans, intrins, post_rots, post_trans, **kwargs):
-        """Same result from one kernel (csrc/vtransform.hip::lss_geometry_kernel): the 3x3 inverses / products of the
-        per-camera matrices stay in torch (B*N tiny matrices), the [B,N,D,fH,fW,3] point cloud is one launch."""
+        """Same result from two launches (csrc/vtransform.hip): `lss_camera_matrices_kernel` (the B*N 3x3 inverses and the
+        rot @ inverse(intrinsics) products, base.py:106/118 — no torch.inverse, no host sync) + `lss_geometry_kernel`
+        (the [B,N,D,fH,fW,3] point cloud, fp32 op for op in the reference's order)."""
         lib = _capi.load()
         B, N, _ = c2l_trans.shape
         dev = c2l_trans.device
-        post_rot_inv = torch.inverse(post_rots).reshape(B * N, 3, 3).contiguous()
-        combine = c2l_rots.matmul(torch.inverse(intrins)).reshape(B * N, 3, 3).contiguous()
+        if self.lapack_inverse:
+            post_rot_inv = torch.inverse(post_rots).reshape(B * N, 3, 3).contiguous()
+            combine = c2l_rots.matmul(torch.inverse(intrins)).reshape(B * N, 3, 3).contiguous()
+        else:
+            post_rot_inv = torch.empty((B * N, 3, 3), dtype=torch.float32, device=dev)
+            combine = torch.empty((B * N, 3, 3), dtype=torch.float32, device=dev)
+            pr, cr, kr = (m.reshape(B * N, 3, 3).contiguous() for m in (post_rots, c2l_rots, intrins))   # 54 floats each
+            with torch.cuda.device(dev):
+                rc = lib.bevamd_lss_camera_matrices(_capi.ptr(pr), _capi.ptr(cr), _capi.ptr(kr), 9, 3, B * N,
+                                                    _capi.ptr(post_rot_inv), _capi.ptr(combine), _capi.stream_ptr(dev))
+            _capi.check(rc, "lss_camera_matrices")
         extra_rots = _fp32(kwargs["extra_rots"])[0].reshape(B, 3, 3).contiguous() if "extra_rots" in kwargs else None
         extra_trans = _fp32(kwargs["extra_trans"])[0].reshape(B, 3).contiguous() if "extra_trans" in kwargs else None
+        return self.geometry_from_camera_matrices(post_rot_inv, post_trans.reshape(B * N, 3).contiguous(), combine,
+                                                  c2l_trans.reshape(B * N, 3).contiguous(), extra_rots, extra_trans, B, N)
+
+    def geometry_from_camera_matrices(self, post_rot_inv, post_trans, combine, c2l_trans, extra_rots, extra_trans, B, N):
+        """bevamd_lss_geometry on prepared per-camera matrices ([B*N,3,3] / [B*N,3], extra_* per sample or None)."""
+        lib = _capi.load()
+        dev = c2l_trans.device
         frustum = self.frustum.detach().to(dev).float().contiguous()
         D, fH, fW, _ = frustum.shape
         geom = torch.empty((B, N, D, fH, fW, 3), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.bevamd_lss_geometry(_capi.ptr(frustum), D * fH * fW, _capi.ptr(post_rot_inv),
-                                         _capi.ptr(post_trans.reshape(B * N, 3).contiguous()), _capi.ptr(combine),
-                                         _capi.ptr(c2l_trans.reshape(B * N, 3).contiguous()), _capi.ptr(extra_rots),
+            rc = lib.bevamd_lss_geometry(_capi.ptr(frustum), D * fH * fW, _capi.ptr(post_rot_inv), _capi.ptr(post_trans),
+                                         _capi.ptr(combine), _capi.ptr(c2l_trans), _capi.ptr(extra_rots),
                                          _capi.ptr(extra_trans), B, N, _capi.ptr(geom), _capi.stream_ptr(dev))
         _capi.check(rc, "lss_geometry")
         return geom
@@ -153,23 +175,69 @@ class BaseTransform(nn.Module):
         return BevPoolPlan.from_geometry(geom_feats.reshape(-1, 3), B, origin, self.dx.detach().cpu().tolist(),
                                          self.nx.detach().cpu().tolist())
 
+    # -- plan cache: a pooling plan is valid for ONE set of calibration + augmentation matrices --------------
+    def invalidate_plan(self):
+        """Drop the cached pooling plan (new calibration, new device, ...)."""
+        self._plan = self._plan_key = self._pending_key = None
+
+    @staticmethod
+    def _calibration_key(tensors, calibration_id=None):
+        """Hashable identity of the matrices a geometry depends on.  A caller-supplied `calibration_id` is used as is
+        (zero device work); otherwise the matrices' bytes are fingerprinted — host tensors directly, device tensors through
+        ONE small read-back (a few hundred bytes; pass `calibration_id` to stay sync-free)."""
+        if calibration_id is not None:
+            return ("id", calibration_id)
+        flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+        return ("bytes", str(flat.device), flat.cpu().numpy().tobytes())
+
+    def _geometry_or_cached(self, c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots, extra_trans,
+                            calibration_id=None):
+        """forward()'s geometry step: with `cache_geometry` (eval only) and an unchanged calibration the cached plan is still
+        valid and NOTHING is recomputed (returns None); otherwise the geometry, with the key its plan will be stored under."""
+        self._pending_key = None
+        if self.cache_geometry and not self.training:
+            B, N, _ = c2l_trans.shape
+            D, fH, fW, _ = self.frustum.shape
+            key = self._calibration_key((c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots, extra_trans),
+                                        calibration_id)
+            self._pending_key = (key, B * N * D * fH * fW, B, str(c2l_trans.device))
+            if self._plan is not None and self._plan_key == self._pending_key:
+                return None
+        return self.get_geometry(c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots=extra_rots,
+                                 extra_trans=extra_trans)
+
+    def _cached_plan(self, geom_feats, Nprime, B):
+        use_cache = self.cache_geometry and not self.training      # train-time augmentation changes the geometry per step
+        key, self._pending_key = self._pending_key, None
+        if geom_feats is None:                                     # forward() found the calibration unchanged
+            assert use_cache and self._plan is not None and self._plan_key == key
+            return self._plan
+        if use_cache:
+            if key is None:   # bev_pool() called directly: the geometry tensor itself is the identity
+                key = (("geom", geom_feats.data_ptr(), geom_feats._version, tuple(geom_feats.shape)), Nprime, B,
+                       str(geom_feats.device))
+            if self._plan is not None and self._plan_key == key:
+                return self._plan
+        plan = self.make_plan(geom_feats, B)
+        if use_cache:
+            self._plan, self._plan_key = plan, key
+        return plan
+
     def bev_pool(self, geom_feats, x):
         """base.py:141-176: [B,N,D,H,W,3] geometry + [B,N,D,H,W,C] features -> [B, C*nz, nx, ny]."""
         factored = x if isinstance(x, FactoredCamFeats) else None
         if factored is not None:
-            (geom_feats,) = _fp32(geom_feats)
+            if geom_feats is not None:
+                (geom_feats,) = _fp32(geom_feats)
             B, N, D, H, W = factored.depth.shape
             C = factored.ctx.shape[2]
         else:
-            geom_feats, x = _fp32(geom_feats, x)
+            (x,) = _fp32(x)
+            if geom_feats is not None:
+                (geom_feats,) = _fp32(geom_feats)
             B, N, D, H, W, C = x.shape
         Nprime = B * N * D * H * W
-        plan = self._plan if (self.cache_geometry and self._plan is not None and self._plan.n == Nprime
-                              and self._plan.B == B) else None
-        if plan is None:
-            plan = self.make_plan(geom_feats, B)
-            if self.cache_geometry:
-                self._plan = plan
+        plan = self._cached_plan(geom_feats, Nprime, B)
         if factored is not None:
             ctx_cl = factored.ctx.float().permute(0, 1, 3, 4, 2).contiguous()     # [B, N, fH, fW, C] (5 MB)
             out = plan.fused(factored.depth.float().contiguous(), ctx_cl.view(-1, C), D, H, W)   # autograd-aware
@@ -196,8 +264,8 @@ class BaseTransform(nn.Module):
         """base.py:178-235."""
         intrins, post_rots, post_trans, c2l_rots, c2l_trans, extra_rots, extra_trans = self._split_mats(
             camera2ego, lidar2ego, camera_intrinsics, camera2lidar, img_aug_matrix, lidar_aug_matrix)
-        geom = self.get_geometry(c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots=extra_rots,
-                                 extra_trans=extra_trans)
+        geom = self._geometry_or_cached(c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots, extra_trans,
+                                        kwargs.get("calibration_id"))
         mats_dict = {"intrin_mats": camera_intrinsics, "ida_mats": img_aug_matrix, "bda_mat": lidar_aug_matrix,
                      "sensor2ego_mats": camera2ego}
         x = self.get_cam_feats(img, mats_dict)
@@ -230,7 +298,8 @@ class BaseDepthTransform(BaseTransform):
             cur_lidar2image = lidar2image[b].float()
             # inverse aug
             cur_coords = cur_coords - cur_lidar_aug_matrix[:3, 3]
-            cur_coords = torch.inverse(cur_lidar_aug_matrix[:3, :3]).matmul(cur_coords.transpose(1, 0))
+            # row-major inverse: MKL's sgemm arithmetic depends on the left operand's layout (tests/golden/make_vtransform_golden.py)
+            cur_coords = torch.inverse(cur_lidar_aug_matrix[:3, :3]).contiguous().matmul(cur_coords.transpose(1, 0))
             # lidar2image
             cur_coords = cur_lidar2image[:, :3, :3].matmul(cur_coords)
             cur_coords += cur_lidar2image[:, :3, 3].reshape(-1, 3, 1)
@@ -260,8 +329,15 @@ class BaseDepthTransform(BaseTransform):
         dev = points[0].device
         B = len(points)
         depth = torch.empty((B, n_cam, 1, iH, iW), dtype=torch.float32, device=dev)
-        inv_rot = torch.inverse(lidar_aug_matrix[:, :3, :3].float()).contiguous()
         trans = lidar_aug_matrix[:, :3, 3].float().contiguous()
+        if self.lapack_inverse:
+            inv_rot = torch.inverse(lidar_aug_matrix[:, :3, :3].float()).contiguous()
+        else:
+            la = lidar_aug_matrix.float().contiguous()                     # [B, 4, 4]
+            inv_rot = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _capi.check(lib.bevamd_mat3_inverse(_capi.ptr(la), 16, 4, B, _capi.ptr(inv_rot), _capi.stream_ptr(dev)),
+                            "mat3_inverse")
         l2i = lidar2image.float().contiguous()
         ia = img_aug_matrix.float().contiguous()
         with torch.cuda.device(dev):
@@ -288,8 +364,8 @@ class BaseDepthTransform(BaseTransform):
             raise NotImplementedError("only scalar 1-channel depth input is implemented (what DepthLSSTransform's "
                                       "Conv2d(1, 8, 1) stem and the released checkpoint use; SURVEY.md D3)")
         depth = self.depth_raster(img, points, lidar2image, img_aug_matrix, lidar_aug_matrix)
-        geom = self.get_geometry(c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots=extra_rots,
-                                 extra_trans=extra_trans)
+        geom = self._geometry_or_cached(c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots, extra_trans,
+                                        kwargs.get("calibration_id"))
         mats_dict = {"intrin_mats": intrins, "ida_mats": img_aug_matrix, "bda_mat": lidar_aug_matrix,
                      "sensor2ego_mats": sensor2ego}
         x = self.get_cam_feats(img, depth, mats_dict)

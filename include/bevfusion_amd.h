@@ -165,7 +165,9 @@ int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order,
  * camera.  points [num_points, num_features] fp32 (xyz first); lidar_aug_inv_rot [3,3] = inverse(lidar_aug_matrix[:3,:3]),
  * lidar_aug_trans [3] = lidar_aug_matrix[:3,3]; lidar2image, img_aug [ncam,4,4]; all DEVICE fp32.
  * depth [ncam, 1, ih, iw] fp32 is fully written (zeros where no point lands).  A pixel hit by several points takes the
- * LAST point in input order (deterministic).  ws: bevamd_depth_raster_workspace_bytes(ncam, ih, iw). */
+ * LAST point in input order (deterministic; = the reference's sequential assignment).  The three GEMMs of the reference are
+ * k-ascending fma chains (BLAS sgemm): pixel sets and depths are bit-exact against the reference's own function body on CPU
+ * torch given the same inverse.  ws: bevamd_depth_raster_workspace_bytes(ncam, ih, iw). */
 size_t bevamd_depth_raster_workspace_bytes(int ncam, int ih, int iw);
 int bevamd_depth_raster(const float* points, int num_points, int num_features, const float* lidar_aug_inv_rot,
                         const float* lidar_aug_trans, const float* lidar2image, const float* img_aug, int ncam,
@@ -174,10 +176,26 @@ int bevamd_depth_raster(const float* points, int num_points, int num_features, c
 /* Replaces BaseTransform.get_geometry (base.py:92-135): frustum [frustum_points, 3] (u, v, d) -> geom
  * [batch*cams, frustum_points, 3] in the lidar frame.  post_rot_inv [batch*cams,3,3] = inverse(img_aug[:3,:3]),
  * post_trans [batch*cams,3], combine [batch*cams,3,3] = camera2lidar_rot @ inverse(intrinsics), camera2lidar_trans
- * [batch*cams,3], extra_rot [batch,3,3] / extra_trans [batch,3] (LiDAR augmentation, either may be NULL). DEVICE fp32. */
+ * [batch*cams,3], extra_rot [batch,3,3] / extra_trans [batch,3] (LiDAR augmentation, either may be NULL). DEVICE fp32.
+ * fp32 op for op in the reference's order (products and sums rounded separately, as ATen's per-point bmm does): bit-exact
+ * against the reference's own function body on CPU torch given the same two inverse-derived matrices. */
 int bevamd_lss_geometry(const float* frustum, int frustum_points, const float* post_rot_inv, const float* post_trans,
                         const float* combine, const float* camera2lidar_trans, const float* extra_rot,
                         const float* extra_trans, int batch_size, int cams_per_sample, float* geom, void* stream);
+
+/* out[i] = inverse of the 3x3 matrix at m + i*mat_stride + r*row_stride + c (floats; the top-left block of a [.., 4, 4]
+ * tensor is mat_stride 16, row_stride 4), i < count; out [count, 3, 3] packed.  Replaces `torch.inverse` at
+ * base.py:106 (post_rots), :118 (intrins), :292 (lidar_aug_matrix[:3,:3]) on the device path: adjugate / determinant in
+ * fp64, one rounding to fp32; no workspace, no host sync (LAPACK's getrf/getrs result may differ in the last 1-2 ulp). */
+int bevamd_mat3_inverse(const float* m, long long mat_stride, long long row_stride, int count, float* out,
+                        void* stream);
+
+/* The per-camera matrices bevamd_lss_geometry consumes, from the raw calibration (base.py:106, 118):
+ * post_rot_inv[i] = inverse(post_rots[i]); combine[i] = camera2lidar_rots[i] @ inverse(intrins[i]) (product in the order
+ * of ATen's small-bmm kernel), i < ncam_total.  The three inputs share one (mat_stride, row_stride) addressing. */
+int bevamd_lss_camera_matrices(const float* post_rots, const float* camera2lidar_rots, const float* intrins,
+                               long long mat_stride, long long row_stride, int ncam_total, float* post_rot_inv,
+                               float* combine, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * voxelization  (reference: mmdet3d/ops/voxel)

@@ -14,8 +14,9 @@ Parity pins (tests/golden/, each with the script that generated it from the refe
                                                inverse conv, max pooling)                        test_oracle_spconv_ext.py
   dynamic scatter     scatter_ref.npz          reference GPU kernels (hipified, run on an MI355X) test_oracle_scatter.py
   iou3d               iou3d_ref.npz            reference GPU kernels (hipified, run on an MI355X) test_oracle_iou3d.py
-  view-transform glue (Python in the reference): restated in numpy and checked against the module's torch formulation
-                                                                                                 test_host_mirror.py
+  view-transform glue vtransform_ref.npz       the reference's own Python function bodies (base.py) exec'd on CPU torch
+                                               under mmcv stubs (tests/golden/make_vtransform_golden.py)
+                                                                                                 test_oracle_vtransform.py
 """
 import ctypes
 import os
@@ -412,58 +413,60 @@ def pairs_as_sets(indice_pairs, indice_num):
 
 
 # --------------------------------------------------------------------------------------------
-# view-transform glue (mmdet3d/models/vtransforms/base.py — Python in the reference; restated in numpy fp32)
+# view-transform glue (mmdet3d/models/vtransforms/base.py — Python in the reference; restated in C, vtransform_oracle.c,
+# with the rounding of the torch CPU kernels those lines dispatch to; pinned by tests/golden/vtransform_ref.npz)
 # --------------------------------------------------------------------------------------------
+def mat3_inverse(m):
+    """Stand-in for `torch.inverse` on [..., 3, 3] fp32 matrices when the caller has no reference-computed inverse: float64
+    LAPACK rounded to fp32.  NOT bit-identical to the reference's fp32 LAPACK call (MKL, un-vendored): the golden fixture
+    carries the reference's own inverses for the bit-exact checks."""
+    return np.linalg.inv(np.asarray(m, np.float64)).astype(np.float32)
+
+
 def lss_geometry(frustum, post_rots, post_trans, camera2lidar_rots, camera2lidar_trans, intrins, extra_rots=None,
-                 extra_trans=None):
+                 extra_trans=None, inv_post_rots=None, combine=None):
     """BaseTransform.get_geometry (base.py:92-135).  frustum [D,fH,fW,3]; per-camera matrices [B,N,3,3] / [B,N,3];
-    extra_rots [B,3,3], extra_trans [B,3] -> [B, N, D, fH, fW, 3] float32."""
+    extra_rots [B,3,3], extra_trans [B,3] -> [B, N, D, fH, fW, 3] float32.
+    `inv_post_rots` = torch.inverse(post_rots), `combine` = camera2lidar_rots.matmul(torch.inverse(intrins)) as the reference
+    computed them (fixture); when absent they come from `mat3_inverse` / a float64 product."""
     f32 = np.float32
-    frustum = np.asarray(frustum, f32)
-    B, N = camera2lidar_trans.shape[:2]
-    pts = frustum[None, None] - np.asarray(post_trans, f32).reshape(B, N, 1, 1, 1, 3)                      # :104
-    inv = np.linalg.inv(np.asarray(post_rots, np.float64)).astype(f32)
-    pts = np.einsum("bnij,bndhwj->bndhwi", inv, pts).astype(f32)                                            # :105-109
-    pts = np.concatenate([pts[..., :2] * pts[..., 2:3], pts[..., 2:3]], -1).astype(f32)                     # :111-117
-    combine = (np.asarray(camera2lidar_rots, np.float64) @ np.linalg.inv(np.asarray(intrins, np.float64))).astype(f32)
-    pts = np.einsum("bnij,bndhwj->bndhwi", combine, pts).astype(f32)                                        # :118-119
-    pts = pts + np.asarray(camera2lidar_trans, f32).reshape(B, N, 1, 1, 1, 3)                              # :120
-    if extra_rots is not None:                                                                               # :122-128
-        pts = np.einsum("bij,bndhwj->bndhwi", np.asarray(extra_rots, f32), pts).astype(f32)
-    if extra_trans is not None:                                                                              # :129-133
-        pts = pts + np.asarray(extra_trans, f32).reshape(B, 1, 1, 1, 1, 3)
-    return pts.astype(f32)
+    frustum = np.ascontiguousarray(frustum, f32)
+    B, N = np.asarray(camera2lidar_trans).shape[:2]
+    if inv_post_rots is None:
+        inv_post_rots = mat3_inverse(post_rots)
+    if combine is None:
+        combine = (np.asarray(camera2lidar_rots, np.float64) @ np.linalg.inv(np.asarray(intrins, np.float64))).astype(f32)
+    c = lambda a, shp: np.ascontiguousarray(np.asarray(a, f32).reshape(shp))  # noqa: E731
+    ipr, pt = c(inv_post_rots, (B * N, 9)), c(post_trans, (B * N, 3))
+    cmb, ct = c(combine, (B * N, 9)), c(camera2lidar_trans, (B * N, 3))
+    er = c(extra_rots, (B, 9)) if extra_rots is not None else None
+    et = c(extra_trans, (B, 3)) if extra_trans is not None else None
+    npts = frustum.size // 3
+    out = np.empty((B, N) + frustum.shape, f32)
+    lib().oracle_lss_geometry(_p(frustum), _i64(npts), _p(ipr), _p(pt), _p(cmb), _p(ct), _p(er) if er is not None else None,
+                              _p(et) if et is not None else None, _i64(B), _i64(N), _p(out))
+    return out
 
 
-def depth_raster(points, lidar2image, img_aug_matrix, lidar_aug_matrix, image_size):
+def depth_raster(points, lidar2image, img_aug_matrix, lidar_aug_matrix, image_size, inv_lidar_aug_rot=None):
     """One sample of BaseDepthTransform.forward's raster (base.py:283-329): points [n, >=3], lidar2image / img_aug_matrix
     [N,4,4], lidar_aug_matrix [4,4] -> (depth [N, 1, iH, iW] float32, winner [N, iH, iW] int32 = index of the point
-    written at each pixel or -1).  Colliding points: the last one in input order wins (sequential assignment)."""
+    written at each pixel or -1).  Colliding points: the last one in input order wins (sequential assignment).
+    `inv_lidar_aug_rot` = torch.inverse(lidar_aug_matrix[:3,:3]) as the reference computed it (fixture), else `mat3_inverse`."""
     f32 = np.float32
     iH, iW = image_size
-    pts = np.asarray(points, f32)[:, :3]
+    pts = np.ascontiguousarray(points, f32)
     lam = np.asarray(lidar_aug_matrix, f32)
-    l2i = np.asarray(lidar2image, f32)
-    ia = np.asarray(img_aug_matrix, f32)
-    cur = pts - lam[:3, 3]                                                                                   # :291
-    cur = (np.linalg.inv(lam[:3, :3].astype(np.float64)).astype(f32) @ cur.T).astype(f32)                   # :292-294 [3, n]
-    cur = np.einsum("cij,jn->cin", l2i[:, :3, :3], cur).astype(f32) + l2i[:, :3, 3].reshape(-1, 3, 1)       # :296-297
-    cur[:, 2, :] = np.clip(cur[:, 2, :], 1e-5, 1e5)                                                          # :300-301 (dist is a view)
-    dist = cur[:, 2, :].copy()
-    cur[:, :2, :] = cur[:, :2, :] / cur[:, 2:3, :]                                                           # :302
-    cur = np.einsum("cij,cjn->cin", ia[:, :3, :3], cur).astype(f32) + ia[:, :3, 3].reshape(-1, 3, 1)        # :305-306
-    rc = cur[:, :2, :].transpose(0, 2, 1)[..., [1, 0]]                                                       # :307-310 (row, col)
-    on = (rc[..., 0] < iH) & (rc[..., 0] >= 0) & (rc[..., 1] < iW) & (rc[..., 1] >= 0)                       # :312-317
+    l2i = np.ascontiguousarray(lidar2image, f32)
+    ia = np.ascontiguousarray(img_aug_matrix, f32)
+    inv = np.ascontiguousarray(mat3_inverse(lam[:3, :3]) if inv_lidar_aug_rot is None else inv_lidar_aug_rot, f32)
+    trans = np.ascontiguousarray(lam[:3, 3])
     n_cam = l2i.shape[0]
-    depth = np.zeros((n_cam, 1, iH, iW), f32)
-    winner = np.full((n_cam, iH, iW), -1, np.int32)
-    for c in range(n_cam):
-        idx = np.nonzero(on[c])[0]
-        pix = rc[c, idx].astype(np.int64)                                                                    # .long(): truncation
-        # sequential assignment: later points overwrite earlier ones
-        depth[c, 0, pix[:, 0], pix[:, 1]] = dist[c, idx]
-        winner[c, pix[:, 0], pix[:, 1]] = idx
-    return depth, winner, rc, on
+    depth = np.empty((n_cam, 1, iH, iW), f32)
+    winner = np.empty((n_cam, iH, iW), np.int32)
+    lib().oracle_depth_raster(_p(pts), _i64(pts.shape[0]), _i64(pts.shape[1] if pts.ndim == 2 else 3), _p(inv), _p(trans),
+                              _p(l2i), _p(ia), _i64(n_cam), _i64(iH), _i64(iW), _p(depth), _p(winner))
+    return depth, winner
 
 
 # --------------------------------------------------------------------------------------------

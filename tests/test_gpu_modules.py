@@ -229,3 +229,45 @@ def test_sparse_encoder_flagship_size_indices_and_dtypes(dev):
         assert np.array_equal(gnum.cpu().numpy(), onum)
         ind, shape = oi, list(oshape)
     assert shape == [180, 180, 2]
+
+
+def test_plan_cache_is_keyed_on_the_calibration(dev):
+    """`cache_geometry` must not reuse a pooling plan across a change of calibration / augmentation matrices
+    (same N', same B), must be ignored while training, and can be dropped explicitly."""
+    cfg = synth.LSS_SMALL_CONFIG
+    torch.manual_seed(0)
+    vt = LSSTransform(256, 80, cfg["image_size"], cfg["feature_size"], cfg["xbound"], cfg["ybound"], cfg["zbound"],
+                      cfg["dbound"], downsample=1).to(dev).eval()
+    B, n_cam = 2, 1
+    mats = _rig_tensors(n_cam, B, dev)
+    img = torch.randn(B, n_cam, 256, 32, 88, device=dev)
+    with torch.no_grad():
+        fresh = vt(img, None, None, **mats)
+        vt.cache_geometry = True
+        a = vt(img, None, None, **mats)
+        plan = vt._plan
+        assert plan is not None and torch.equal(a, fresh)
+        b = vt(img, None, None, **mats)                                  # unchanged calibration: plan reused, no geometry pass
+        assert vt._plan is plan and torch.equal(a, b)
+        c = vt(img, None, None, calibration_id="rig-0", **mats)          # caller-supplied identity: its own key
+        plan_id = vt._plan
+        assert torch.equal(c, fresh)
+        vt(img, None, None, calibration_id="rig-0", **mats)
+        assert vt._plan is plan_id
+        # a LiDAR augmentation (same shapes): stale plan must NOT be used
+        mats2 = dict(mats)
+        la = mats["lidar_aug_matrix"].clone()
+        ang = 0.3
+        la[:, :3, :3] = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]],
+                                     dtype=torch.float32, device=dev)
+        mats2["lidar_aug_matrix"] = la
+        vt.cache_geometry = False
+        want = vt(img, None, None, **mats2)
+        vt.cache_geometry = True
+        got = vt(img, None, None, **mats2)
+        assert vt._plan is not plan_id and torch.equal(got, want) and not torch.equal(got, fresh)
+        vt.invalidate_plan()
+        assert vt._plan is None
+    vt.train()
+    out = vt(img, None, None, **mats)                                    # training: never cached
+    assert vt._plan is None and out.requires_grad

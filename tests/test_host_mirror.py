@@ -106,8 +106,10 @@ def test_product_has_no_oracle_import():
 
 
 def test_oracle_vtransform_restatements_agree_with_module_and_rig():
-    """oracle.lss_geometry (numpy) == the module's broadcasting formulation (torch CPU) == synth.get_geometry; and
-    oracle.depth_raster == the module's torch formulation on inputs without pixel collisions."""
+    """oracle.lss_geometry == the module's broadcasting formulation (torch CPU) == synth.get_geometry up to the 3x3
+    inverse (the oracle's stand-in is float64-rounded, torch's is fp32 LAPACK; the bit-exact pin with the reference's own
+    inverses is tests/test_oracle_vtransform.py); oracle.depth_raster == the module's torch formulation on inputs without
+    pixel collisions."""
     import oracle
 
     cfg = synth.CL_CONFIG
@@ -131,7 +133,7 @@ def test_oracle_vtransform_restatements_agree_with_module_and_rig():
     ia[:, :3, :3], ia[:, :3, 3], ia[:, 3, 3] = rig["post_rots"], rig["post_trans"], 1
     l2i = (K.astype(np.float64) @ np.linalg.inv(c2l.astype(np.float64))).astype(np.float32)
     la = np.eye(4, dtype=np.float32)
-    ref_d, winner, _, _ = oracle.depth_raster(pts, l2i, ia, la, cfg["image_size"])
+    ref_d, winner = oracle.depth_raster(pts, l2i, ia, la, cfg["image_size"])
     got = vt.depth_raster(torch.zeros(1, 6, 1, 1, 1), [torch.from_numpy(pts)], torch.from_numpy(l2i)[None],
                           torch.from_numpy(ia)[None], torch.from_numpy(la)[None])
     assert int((ref_d > 0).sum()) > 20
