@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py — throughput of the MI355X BEVFusion hot path on synthetic nuScenes-shaped frames.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--spconv-dtype fp16|fp32|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B | --global-batch G] [--no-cpu-baseline]
+                    [--spconv-dtype fp16|fp32|bf16] [--feat-dtype fp32|bf16] [--dry-run]
+
+`--gpus N` with no launcher environment (WORLD_SIZE unset) re-executes this file under `torch.distributed.run` with N ranks on
+127.0.0.1, one rank per GPU (RCCL); under a launcher it uses the ranks it was given.  `--dry-run` swaps the GPU work for a
+stub on the host and the backend for gloo: the whole N>1 control flow (spawn, rendezvous, frame sharding, barriers,
+max-over-ranks timing, the JSON line) runs in a container without GPUs (tests/test_bench_launch.py).
 
 A "step" is ONE pass of the hot path over ONE synthetic frame per GPU at the C+L flagship sizes
 (SURVEY.md §8d), inputs already resident in HBM:
@@ -41,8 +47,71 @@ def parse():
     ap.add_argument("--batch", type=int, default=8,
                     help="frames per step per GPU (default 8: BASELINE.json's C+L inference config is quoted at batch 8 on one GPU; "
                          "--batch 1 = single-frame latency)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed number of frames per step for the WHOLE job, split over the ranks with sharding.frames_for_rank "
+                         "(strong scaling); default 0 = --batch frames on every GPU (weak scaling)")
     ap.add_argument("--no-graph", action="store_true", help="launch the LiDAR branch kernel by kernel instead of replaying a HIP graph")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: a host stub stands in for the hot path and gloo for RCCL, everything else (launch, sharding, "
+                         "barriers, timing, JSON) is the real code path")
     return ap.parse_args()
+
+
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` typed by hand: become N ranks.  (The driver launches torch.distributed.run itself; then
+    WORLD_SIZE is set and this is skipped.)  Mirrors the reference's `torchpack dist-run -np N` (tools/train.py:20-29)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world, frame_ids):
+    """The control flow of main() around a host stub: each rank 'processes' its frames (a seeded reduction per frame id),
+    ranks meet in the barriers only, rank 0 prints the JSON line.  No GPU, gloo instead of RCCL."""
+    import torch.distributed as dist
+
+    from bevfusion_amd.sharding import barrier, max_over_ranks, sum_over_ranks
+
+    def step():
+        acc = 0.0
+        for f in frame_ids:
+            g = torch.Generator().manual_seed(1000 + f)
+            acc += float(torch.randn(4096, generator=g).square().sum())
+        return acc
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    checksum = 0.0
+    for _ in range(args.steps):
+        checksum = step()
+    barrier()
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local)
+    frames_per_step = int(sum_over_ranks(len(frame_ids)))
+    total_checksum = sum_over_ranks(checksum)
+    per_rank = [None] * world
+    if world > 1:
+        dist.all_gather_object(per_rank, dict(rank=rank, frames=list(frame_ids), ms_per_step=elapsed_local / args.steps * 1e3))
+    else:
+        per_rank = [dict(rank=0, frames=list(frame_ids), ms_per_step=elapsed_local / args.steps * 1e3)]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "DRY RUN (host stub, no GPU work): launch / sharding / timing control flow of bench.py",
+            "value": frames_per_step * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+            "config": {"workload": "dry-run stub", "frames_per_step": frames_per_step, "backend": "gloo",
+                       "world_size": world, "per_rank": per_rank, "checksum": total_checksum},
+            "dry_run": True}), flush=True)
 
 
 def make_encoder(cfg, dev, dtype):
@@ -153,16 +222,40 @@ def cpu_baseline(inp, pts, cfg, B, D, H, W):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_launcher(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): using {world}", file=sys.stderr)
+    if not args.dry_run and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback); --dry-run exercises the launch logic")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+        if args.dry_run:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" == RCCL on ROCm
+
+    from bevfusion_amd.sharding import frames_for_rank
+
+    # frames of one step: weak scaling = --batch frames on every rank; strong = --global-batch split over the ranks
+    if args.global_batch:
+        frame_ids = list(frames_for_rank(args.global_batch, rank, world))
+    else:
+        frame_ids = [rank * max(1, args.batch) + b for b in range(max(1, args.batch))]
+    if args.dry_run:
+        dry_run(args, rank, world, frame_ids)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
+    if not frame_ids:
+        raise SystemExit(f"rank {rank}: no frames to process (--global-batch {args.global_batch} < {world} ranks)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -171,7 +264,7 @@ def main():
     from bevfusion_amd.voxel import voxelize_batch_device
 
     cfg = synth.CL_CONFIG
-    B = max(1, args.batch)
+    B = len(frame_ids)
     # ---- synthetic frame (per rank: its own seed -> its own features / point cloud; same calibration) ----
     inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank, with_feats=False)   # B frames: same calibration
     H, W, D = (int(v) for v in inp["nx"])
@@ -185,7 +278,7 @@ def main():
     if args.feat_dtype == "bf16":
         feats = feats.bfloat16()
     elem = feats.element_size()
-    pts_all = [synth.lidar_points(seed=rank * B + b) for b in range(B)]        # one point cloud per frame
+    pts_all = [synth.lidar_points(seed=f) for f in frame_ids]                  # one point cloud per frame id
     pts_np = pts_all[0]
     pts_list = [torch.from_numpy(p).to(dev) for p in pts_all]
     sp_dtype = {"fp16": torch.float16, "fp32": torch.float32, "bf16": torch.bfloat16}[args.spconv_dtype]
@@ -219,7 +312,7 @@ def main():
             out = enc(vf, vc, B, num_voxels=cnt)
         return out, cnt, mid
 
-    from bevfusion_amd.sharding import barrier, max_over_ranks
+    from bevfusion_amd.sharding import barrier, max_over_ranks, sum_over_ranks
 
     # eager passes: warm every cache (filter images, allocator) and time voxelize / encoder separately
     for _ in range(2):
@@ -301,10 +394,20 @@ def main():
     assert tuple(state["lidar_bev"].shape) == (B, 256, 180, 180)
     kern_ms = stage_ms[0]  # the bev_pool stage is exactly one kernel launch
 
+    elapsed_local = elapsed
     elapsed = max_over_ranks(elapsed, device=dev)  # slowest rank defines the step time
+    frames_per_step = int(sum_over_ranks(B, device=dev))
+    per_rank = [dict(rank=rank, frames=B, ms_per_step=elapsed_local / args.steps * 1e3,
+                     frames_per_s=B * args.steps / elapsed_local)]
+    if world > 1:
+        import torch.distributed as dist
+
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
     if rank == 0:
-        frames = args.steps * world * B
+        frames = args.steps * frames_per_step
         # algorithmic bytes of the bev_pool scatter: every kept feature row read once + one
         # (geom, start, length) record per interval + every output cell written once
         alg_bytes = n_kept * C * elem + n_int * 24 + B * D * H * W * C * 4
@@ -328,7 +431,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_frame": elapsed / args.steps * 1e3 / B,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None,
             "dtype": f"f32 (bev_pool acc, voxelize) + {args.spconv_dtype}/f32-acc (sparse conv)"
                      + ("" if elem == 4 else ", bf16 camera features"),
@@ -340,6 +443,10 @@ def main():
                             f"{state['n_voxels']} voxels; SparseEncoder 1440x1440x41 (17 SubM + 4 strided convs) -> "
                             f"[{B},256,180,180]. bev_pool rank/sort/CSR precompute cached per calibration.",
                 "frames_per_step_per_gpu": B,
+                "frames_per_step": frames_per_step,
+                "parallelism": f"frames sharded over {world} rank(s), one process per GPU, no data-path collective"
+                               + (f"; torch.distributed backend nccl (= RCCL) world size {world}" if world > 1 else ""),
+                "per_rank": per_rank,
                 "stages": ["bev_pool_forward_cells", "voxelize_mean + sparse_encoder"],
                 "stage_ms": dict(zip(["bev_pool", "lidar_branch"], stage_ms)),
                 "lidar_branch_eager_ms": {"voxelize": eager_vox_ms, "sparse_encoder": eager_enc_ms},

@@ -1,0 +1,39 @@
+"""CPU: the N>1 control flow of bench.py end to end — `python bench.py --gpus 2 --dry-run` with no launcher environment must
+spawn two ranks itself (torch.distributed.run on 127.0.0.1), shard the frames, time with barriers + max over ranks and print
+ONE JSON line with n_gpus = 2 (`--gpus` used to be ignored).  The GPU work is stubbed, the backend is gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_spawns_ranks_weak_scaling():
+    res = run_bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--batch", "3")
+    assert res["n_gpus"] == 2 and res["dry_run"] and res["scaling"] == "weak"
+    cfg = res["config"]
+    assert cfg["world_size"] == 2 and cfg["frames_per_step"] == 6
+    assert sorted(tuple(r["frames"]) for r in cfg["per_rank"]) == [(0, 1, 2), (3, 4, 5)]    # disjoint frame ids per rank
+    assert res["ms_per_step"] >= max(r["ms_per_step"] for r in cfg["per_rank"]) * 0.5
+    assert abs(res["value"] - 6 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]
+
+
+def test_global_batch_is_split_with_frames_for_rank():
+    res = run_bench("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0", "--global-batch", "5")
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert sorted(tuple(r["frames"]) for r in res["config"]["per_rank"]) == [(0, 1, 2), (3, 4)]
+    one = run_bench("--dry-run", "--steps", "2", "--warmup", "0", "--global-batch", "5")
+    assert one["n_gpus"] == 1 and one["config"]["per_rank"][0]["frames"] == [0, 1, 2, 3, 4]
+    # every frame is processed exactly once whatever the rank count: same checksum
+    assert abs(one["config"]["checksum"] - res["config"]["checksum"]) < 1e-6 * abs(one["config"]["checksum"])
