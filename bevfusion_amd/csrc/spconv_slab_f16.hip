@@ -1,0 +1,107 @@
+// fp16 instantiation of the slab (staged-rows) submanifold convolution (kernels: spconv_slab.h) + its C-ABI entry points.
+#include "spconv_slab_impl.h"
+
+namespace bevamd {
+namespace slab {
+int launch_f16(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t stream) {
+  return launch_impl<tile::T_F16>(sa, cin, nt, variant, stream);
+}
+}  // namespace slab
+}  // namespace bevamd
+
+using namespace bevamd;
+
+extern "C" {
+
+/* Rows per block of slab variant `variant` (0 = default) for a cin-channel SubM 3x3x3 convolution, 0 if none is built
+ * (cin must be 32, 64 or 128 and cout == cin).  The block size fixes the metadata layout of bevamd_spconv_slab_build. */
+int bevamd_spconv_slab_block_rows(int cin, int variant) {
+  const slab::Shape* s = slab::find_shape(cin, variant);
+  return s ? s->nw * 16 * s->mt : 0;
+}
+
+/* The variant codes built for `cin` (for sweeps): writes up to max_n codes, returns how many exist. */
+int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
+  int n = 0;
+  const slab::Shape* s = slab::shapes_of(cin, &n);
+  for (int i = 0; s && i < n && i < max_n; ++i) codes[i] = slab::variant_code(s[i]);
+  return n;
+}
+
+/* 1 if a voxel set on a [batch, X, Y, Z] grid whose rows are in ascending linear index can use the slab kernels: a line's
+ * input range is at most block_rows + (Y + 1) * Z + 2 rows, which must fit the 16-bit slots. */
+int bevamd_spconv_slab_grid_ok(const int* shape, int block_rows) {
+  if (!shape || block_rows <= 0) return 0;
+  const long long bound = (long long)block_rows + ((long long)shape[1] + 1) * shape[2] + 2;
+  return bound < 0xFFFE;
+}
+
+size_t bevamd_spconv_slab_hdr_bytes(int m_cap, int block_rows) {
+  if (m_cap <= 0 || block_rows <= 0) return 0;
+  return (size_t)((m_cap + block_rows - 1) / block_rows) * slab::LINES * sizeof(int2);
+}
+size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows) {
+  if (m_cap <= 0 || block_rows <= 0) return 0;
+  return (size_t)((m_cap + block_rows - 1) / block_rows) * 27 * block_rows * sizeof(uint16_t);
+}
+
+/* Block metadata of a 3x3x3 SubM neighbour table nbr [27, nbr_stride] over m rows (m = *m_dev clamped to m_cap, or m_cap):
+ * per block of block_rows (128 | 256) rows and kernel line (kx, ky): hdr = (first input row, row count) of the range its
+ * three kz taps read, slots = the table as 16-bit offsets into that range (0xFFFF = no neighbour).  Built once per voxel
+ * set, shared by every SubM convolution over it.  status (optional int32, device): bit 0 is set if a range exceeded the
+ * 16-bit slots (rows not in linear-index order on a grid bevamd_spconv_slab_grid_ok rejects). */
+int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const int* m_dev, int block_rows, void* hdr,
+                             void* slots, int* status, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(block_rows == 128 || block_rows == 256, "spconv_slab_build: block_rows %d (128 | 256)", block_rows);
+  BEVAMD_REQUIRE(m_cap >= 0 && nbr_stride >= m_cap, "spconv_slab_build: bad sizes");
+  if (m_cap == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(nbr && hdr && slots, "spconv_slab_build: null buffer");
+  const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows);
+  if (block_rows == 128)
+    slab::slab_build_kernel<128><<<dim3(nblk), dim3(128), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);
+  else
+    slab::slab_build_kernel<256><<<dim3(nblk), dim3(256), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);
+  BEVAMD_LAUNCH_CHECK("spconv_slab_build");
+  return BEVAMD_OK;
+}
+
+/* Replaces sparse_conv_ext.indice_conv_half (spconv/src/all.cc:30-33 -> spconv_ops.h:260-361, subM = 1) for a 3x3x3
+ * submanifold convolution over rows in ascending linear index, cin == cout in {32, 64, 128}, with the same fused epilogue as
+ * bevamd_spconv_conv_forward_tiled and the same results (bit-identical for cin <= 64).  hdr / slots: bevamd_spconv_slab_build
+ * with block_rows = bevamd_spconv_slab_block_rows(cin, variant). */
+int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_stride, int num_in, const void* image,
+                                    const void* hdr, const void* slots, int block_rows, int num_out,
+                                    const int* num_out_dev, int cin, int cout, void* out, int out_stride, const void* bias,
+                                    const float* bn_scale, const float* bn_shift, const void* residual,
+                                    int residual_stride, int relu, int variant, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype == tile::T_F16 || dtype == tile::T_BF16, "spconv_conv_forward_slab: dtype %d is not 16-bit", dtype);
+  BEVAMD_REQUIRE(cin == cout && (cin == 32 || cin == 64 || cin == 128), "spconv_conv_forward_slab: %d -> %d channels", cin, cout);
+  BEVAMD_REQUIRE(num_out >= 0 && num_in >= 0, "spconv_conv_forward_slab: bad sizes");
+  if (num_out == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(features && image && hdr && slots && out, "spconv_conv_forward_slab: null buffer");
+  BEVAMD_REQUIRE(block_rows == bevamd_spconv_slab_block_rows(cin, variant),
+                 "spconv_conv_forward_slab: metadata built for %d-row blocks, variant %d wants %d", block_rows, variant,
+                 bevamd_spconv_slab_block_rows(cin, variant));
+  BEVAMD_REQUIRE(feat_stride >= cin && feat_stride % 8 == 0 && ((uintptr_t)features & 15) == 0,
+                 "spconv_conv_forward_slab: feature pitch %d must be a multiple of 8 and >= %d, 16-byte aligned", feat_stride, cin);
+  BEVAMD_REQUIRE(((uintptr_t)image & 15) == 0 && ((uintptr_t)slots & 15) == 0, "spconv_conv_forward_slab: image / slots must be 16-byte aligned");
+  BEVAMD_REQUIRE(out_stride >= cout && (!residual || residual_stride >= cout), "spconv_conv_forward_slab: bad output pitch");
+  BEVAMD_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "spconv_conv_forward_slab: scale and shift go together");
+  slab::SlabArgs sa;
+  tile::Args& a = sa.a;
+  a.feat = features; a.wimg = image; a.nbr = nullptr; a.m_dev = num_out_dev; a.out = out;
+  a.bias = bias; a.scale = bn_scale; a.shift = bn_shift; a.residual = residual;
+  a.feat_stride = feat_stride; a.n_in = num_in; a.nbr_stride = 0; a.m_cap = num_out; a.K = 27;
+  a.cout = cout; a.out_stride = out_stride; a.res_stride = residual_stride; a.relu = relu;
+  a.row_epilogue = cout % 8 == 0 && out_stride % 8 == 0 && ((uintptr_t)out & 15) == 0 &&
+                   (!residual || (residual_stride % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                   (!bias || ((uintptr_t)bias & 15) == 0) && (!bn_scale || (((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0);
+  sa.hdr = (const int2*)hdr;
+  sa.slots = (const uint16_t*)slots;
+  return dtype == tile::T_F16 ? slab::launch_f16(sa, cin, cout / 16, variant, stream)
+                              : slab::launch_bf16(sa, cin, cout / 16, variant, stream);
+}
+
+}  // extern "C"

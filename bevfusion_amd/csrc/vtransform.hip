@@ -14,7 +14,7 @@
 //
 // frustum geometry — BaseTransform.get_geometry (base.py:92-135): frustum (u, v, d) -> lidar frame, one thread per
 //   frustum point and camera, same op order.  Its 3x3 products are per-point broadcast bmm's (ATen's naive kernel:
-//   acc = 0; acc += a_k * b_k, k ascending, product and sum rounded SEPARATELY) -> __fmul_rn / __fadd_rn here, never
+//   acc = 0; acc += a_k * b_k, k ascending, product and sum rounded SEPARATELY) -> `#pragma clang fp contract(off)` here, never
 //   contracted to an fma.  Bit-exact against the same fixture at the flagship size (SHA-256 of the 24 MB result).
 //   Static per calibration; it exists so that building a pooling plan for a new calibration is two launches (this +
 //   bevamd_bev_pool_prepare_from_geom) instead of ~10 broadcasting matmuls.
@@ -43,9 +43,22 @@ __device__ __forceinline__ void mat3_apply(const Mat3& M, float x, float y, floa
   oy = fmaf(M.m[5], z, fmaf(M.m[4], y, M.m[3] * x));
   oz = fmaf(M.m[8], z, fmaf(M.m[7], y, M.m[6] * x));
 }
-// y = M x as ATen's naive bmm kernel evaluates it: every product and every sum rounded on its own (0 + p is exact)
+// y = M x as ATen's naive bmm kernel evaluates it: every product and every sum rounded on its own (0 + p is exact).
+// HIP's __fmul_rn / __fadd_rn are plain operators that hipcc's default -ffp-contract=fast-honor-pragmas may still fuse:
+// the pragma is what keeps these a v_mul_f32 + v_add_f32 pair (checked in the ISA: no v_fma / v_fmac in lss_geometry_kernel).
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 __device__ __forceinline__ float dot3_rn(float a0, float a1, float a2, float x, float y, float z) {
-  return __fadd_rn(__fadd_rn(__fmul_rn(a0, x), __fmul_rn(a1, y)), __fmul_rn(a2, z));
+#pragma clang fp contract(off)
+  const float p0 = a0 * x, p1 = a1 * y, p2 = a2 * z;
+  const float s = p0 + p1;
+  return s + p2;
 }
 __device__ __forceinline__ void mat3_apply_rn(const Mat3& M, float x, float y, float z, float& ox, float& oy, float& oz) {
   ox = dot3_rn(M.m[0], M.m[1], M.m[2], x, y, z);
@@ -127,11 +140,11 @@ __global__ __launch_bounds__(256) void lss_geometry_kernel(GeomArgs a, float* __
   float x = f[0] - pt[0], y = f[1] - pt[1], z = f[2] - pt[2];
   float u, v, w;
   mat3_apply_rn(load_mat3(a.post_rot_inv + (size_t)cam * 9, 3), x, y, z, u, v, w);
-  u = __fmul_rn(u, w);   // (x*z, y*z, z)  base.py:110-116
-  v = __fmul_rn(v, w);
+  u = mul_rn(u, w);   // (x*z, y*z, z)  base.py:110-116
+  v = mul_rn(v, w);
   mat3_apply_rn(load_mat3(a.combine + (size_t)cam * 9, 3), u, v, w, x, y, z);
   const float* ct = a.c2l_trans + (size_t)cam * 3;
-  x = __fadd_rn(x, ct[0]); y = __fadd_rn(y, ct[1]); z = __fadd_rn(z, ct[2]);
+  x = add_rn(x, ct[0]); y = add_rn(y, ct[1]); z = add_rn(z, ct[2]);
   const int b = cam / a.cams_per_sample;
   if (a.extra_rot) {
     mat3_apply_rn(load_mat3(a.extra_rot + (size_t)b * 9, 3), x, y, z, u, v, w);
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(256) void lss_geometry_kernel(GeomArgs a, float* __
   }
   if (a.extra_trans) {
     const float* et = a.extra_trans + (size_t)b * 3;
-    x = __fadd_rn(x, et[0]); y = __fadd_rn(y, et[1]); z = __fadd_rn(z, et[2]);
+    x = add_rn(x, et[0]); y = add_rn(y, et[1]); z = add_rn(z, et[2]);
   }
   float* o = geom + (size_t)t * 3;
   o[0] = x; o[1] = y; o[2] = z;

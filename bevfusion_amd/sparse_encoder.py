@@ -10,6 +10,7 @@ sync-free (folded BatchNorm, device-side row counts, one gather for the dense ta
 one, making the same native calls the reference makes.
 """
 import os
+import warnings
 
 import torch
 from torch import nn
@@ -44,6 +45,11 @@ class SparseEncoder(nn.Module):
         # eval-mode 16-bit forward runs on the sync-free fused path (spconv/fused.py); set False (or
         # BEVAMD_SPCONV_FUSED=0) to force the module-by-module path that mirrors the reference call for call
         self.fused_inference = os.environ.get("BEVAMD_SPCONV_FUSED", "1") != "0"
+        # which path the last forward() took: "fused" | "modules" (+ why, in `last_path_reason`); the module path makes one
+        # host sync per strided convolution and cannot be captured into a HIP graph, so a silent demotion is a perf cliff
+        self.last_path = None
+        self.last_path_reason = None
+        self._warned = set()
 
         # stem: a pre-activation order keeps only the convolution here (sparse_encoder.py:62-80)
         stem_order = self.order if self.order[0] == "conv" else ("conv",)
@@ -60,13 +66,23 @@ class SparseEncoder(nn.Module):
         """voxel_features [N, C_in]; coors [N, 4] int32 (batch, x, y, z) -> dense BEV features [B, C*D, H, W]
         (sparse_encoder.py:100-132).  `num_voxels=` (int32 device tensor) marks capacity-padded inputs."""
         num_voxels = kwargs.get("num_voxels")
-        if self.fused_inference and _fused.encoder_supported(self, voxel_features):
-            try:
-                return _fused.run_encoder(self, voxel_features, coors, int(batch_size), num_voxels)
-            except _fused.NotThisCall:
-                pass                          # e.g. an empty frame: module path for this call only
-            except _fused.Unfusable:
-                self.fused_inference = False  # a module tree / state the fused path does not implement
+        reason = "fused_inference is off"
+        if self.fused_inference:
+            reason = _fused.unsupported_reason(self, voxel_features)
+            if reason is None:
+                try:
+                    out = _fused.run_encoder(self, voxel_features, coors, int(batch_size), num_voxels)
+                    self.last_path, self.last_path_reason = "fused", None
+                    return out
+                except _fused.NotThisCall as e:
+                    reason = f"this call only: {e}"          # e.g. an empty frame: module path for this call only
+                except _fused.Unfusable as e:
+                    self.fused_inference = False             # a module tree / state the fused path does not implement
+                    reason = f"encoder not fusable, fused path disabled for this module: {e}"
+                    self._warn_once(reason)
+            elif not self.training and not torch.is_grad_enabled():
+                self._warn_once(reason)                      # inference that silently misses the fast path
+        self.last_path, self.last_path_reason = "modules", reason
         if num_voxels is not None:            # the module path needs exact row counts on the host
             live = int(num_voxels.reshape(-1)[0])
             voxel_features, coors = voxel_features[:live], coors[:live]
@@ -79,6 +95,12 @@ class SparseEncoder(nn.Module):
         dense = self.conv_out(x).dense()                       # [B, C, H, W, D]
         b, c, h, w, d = dense.shape
         return dense.permute(0, 1, 4, 2, 3).contiguous().view(b, c * d, h, w)
+
+    def _warn_once(self, reason):
+        if reason not in self._warned:
+            self._warned.add(reason)
+            warnings.warn(f"SparseEncoder: module-by-module path instead of the sync-free fused path ({reason}); one host sync "
+                          "per strided convolution, not graph-capturable", RuntimeWarning, stacklevel=3)
 
     # ------------------------------------------------------------------------------------------------------
     def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type="conv_module",

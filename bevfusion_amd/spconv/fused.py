@@ -316,13 +316,22 @@ def dense_bev(x):
     return out
 
 
-def encoder_supported(enc, voxel_features):
-    if enc.training or torch.is_grad_enabled():
-        return False
+def unsupported_reason(enc, voxel_features):
+    """None when this call can take the fused path, else a one-line reason (logged once by SparseEncoder)."""
+    if enc.training:
+        return "module is in training mode"
+    if torch.is_grad_enabled():
+        return "autograd is enabled (wrap inference in torch.no_grad())"
     if not voxel_features.is_cuda:
-        return False
+        return "input is not on the GPU"
     dtype = enc.conv_input[0].weight.dtype
-    return dtype in (torch.float16, torch.bfloat16)
+    if dtype not in (torch.float16, torch.bfloat16):
+        return f"weights are {dtype} (the fused path runs fp16 / bf16 weights: .half() or .bfloat16() the encoder)"
+    return None
+
+
+def encoder_supported(enc, voxel_features):
+    return unsupported_reason(enc, voxel_features) is None
 
 
 @torch.no_grad()

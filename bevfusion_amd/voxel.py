@@ -314,17 +314,21 @@ def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, m
         for lane in lanes:
             if lane is not None:
                 lane.wait_stream(main)
-        for k, pts in enumerate(points_list):
-            lane = lanes[k % len(lanes)]
-            with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
-                rc = lib.bevamd_voxelize_mean(_capi.ptr(pts), _capi.ptr(feats[k]), _capi.ptr(coords[k]), _capi.ptr(sizes[k]),
-                                              vs, cr, int(max_num_points), int(max_voxels), pts.shape[0], F, k,
-                                              _capi.ptr(counts[k:]), _capi.ptr(ws[k % len(lanes)]), wsb,
-                                              _capi.stream_ptr(dev))
-            _capi.check(rc, "voxelize_mean")
-        for lane in lanes:
-            if lane is not None:
-                main.wait_stream(lane)
+        try:
+            for k, pts in enumerate(points_list):
+                lane = lanes[k % len(lanes)]
+                with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
+                    rc = lib.bevamd_voxelize_mean(_capi.ptr(pts), _capi.ptr(feats[k]), _capi.ptr(coords[k]), _capi.ptr(sizes[k]),
+                                                  vs, cr, int(max_num_points), int(max_voxels), pts.shape[0], F, k,
+                                                  _capi.ptr(counts[k:]), _capi.ptr(ws[k % len(lanes)]), wsb,
+                                                  _capi.stream_ptr(dev))
+                _capi.check(rc, "voxelize_mean")
+        finally:
+            # always join the lanes back (also when a launch raised): the buffers above were allocated on `main`, and the
+            # caching allocator may hand them out again as soon as `main` moves on
+            for lane in lanes:
+                if lane is not None:
+                    main.wait_stream(lane)
     if not sync:
         return feats, coords, sizes, counts
 
