@@ -318,6 +318,8 @@ def main():
     for _ in range(2):
         lidar_branch()
     torch.cuda.synchronize()
+    if sp_dtype != torch.float32 and enc.last_path != "fused":
+        raise SystemExit(f"bench: the SparseEncoder left its sync-free fused path ({enc.last_path_reason})")
     state["probe"] = True
     sub = []
     for _ in range(5):

@@ -74,6 +74,13 @@ _SIGNATURES = {
     "bevamd_spconv_filter_image_elems": (Z, [I, I, I, I]),
     "bevamd_spconv_make_filter_image": (I, [P, I, I, I, I, I, P, P]),
     "bevamd_spconv_conv_forward_tiled": (I, [P, I, I, I, P, P, I, I, P, I, I, I, P, I, P, P, P, P, I, I, I, P]),
+    "bevamd_spconv_slab_block_rows": (I, [I, I]),
+    "bevamd_spconv_slab_variants": (I, [I, P, I]),
+    "bevamd_spconv_slab_grid_ok": (I, [P, I]),
+    "bevamd_spconv_slab_hdr_bytes": (Z, [I, I]),
+    "bevamd_spconv_slab_slot_bytes": (Z, [I, I]),
+    "bevamd_spconv_slab_build": (I, [P, I, I, P, I, P, P, P, P]),
+    "bevamd_spconv_conv_forward_slab": (I, [P, I, I, I, P, P, P, I, I, P, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_wgrad_workspace_bytes": (Z, [I, I, I]),
     "bevamd_spconv_conv_wgrad": (I, [P, P, I, P, I, I, I, I, I, P, P, Z, P]),
     # iou3d

@@ -4,7 +4,10 @@ hipcc cross-compiles without a GPU.  The library has a plain C ABI
 (include/bevfusion_amd.h) and links only against the HIP runtime: no torch,
 no pybind.  Objects are rebuilt only when their sources are newer.
 
-    python -m bevfusion_amd.build [--force] [--verbose]
+    python -m bevfusion_amd.build [--force] [--verbose] [--profiling]
+
+`--profiling` (or BEVAMD_PROFILING=1) adds -DBEVAMD_PROFILING: the ablation instantiations of the tiled convolution that
+tools/sweep_spconv.py --ablate times (kernels with parts compiled out, wrong results by design) — never in the shipped build.
 """
 import os
 import subprocess
@@ -46,11 +49,11 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile_one(src, force, verbose):
+def _compile_one(src, force, verbose, extra=()):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     if not force and not _newer(obj, [src] + _headers()):
         return obj, False
-    cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + CFLAGS + list(extra) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -61,13 +64,23 @@ def _compile_one(src, force, verbose):
     return obj, True
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, profiling=None):
     os.makedirs(OBJDIR, exist_ok=True)
+    if profiling is None:
+        profiling = os.environ.get("BEVAMD_PROFILING", "0") == "1"
+    extra = ["-DBEVAMD_PROFILING"] if profiling else []
+    stamp = os.path.join(OBJDIR, ".profiling")
+    if os.path.exists(stamp) != bool(profiling):      # flavour changed: every object is stale
+        force = True
+        if profiling:
+            open(stamp, "w").close()
+        elif os.path.exists(stamp):
+            os.remove(stamp)
     srcs = _sources()
     if not srcs:
         raise RuntimeError("no .hip sources found in " + CSRC)
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile_one(s, force, verbose), srcs))
+        results = list(ex.map(lambda s: _compile_one(s, force, verbose, extra), srcs))
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or not os.path.exists(LIB) or force:
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
@@ -80,5 +93,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv,
+                 profiling=True if "--profiling" in sys.argv else None)
     print(path)

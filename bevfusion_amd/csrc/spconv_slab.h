@@ -35,14 +35,15 @@ namespace slab {
 
 using namespace tile;
 
-constexpr int LINES = 9;          // (kx, ky) pairs of the 3x3x3 kernel
-constexpr int TAPS = 3;           // kz taps per line
+constexpr int PLANES = 3;         // kx planes of the 3x3x3 kernel: the 9 (ky, kz) taps of a plane share one staged range
+constexpr int TAPS = 9;           // taps per plane
 constexpr unsigned NO_SLOT = 0xFFFFu;
 
 struct SlabArgs {
   Args a;                    // features, filter image, epilogue operands (nbr is unused)
-  const int2* hdr;           // [nblocks][LINES] (lo, cnt)
+  const int2* hdr;           // [nblocks][PLANES] (lo, cnt)
   const uint16_t* slots;     // [nblocks][27][BM]
+  unsigned wimg_bytes;       // size of the filter image (buffer descriptor bound)
 };
 
 // ---- metadata -----------------------------------------------------------------------------------------------------
@@ -51,7 +52,7 @@ template <int BM>
 __global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ nbr, int nbr_stride, int m_cap,
                                                         const int* __restrict__ m_dev, int2* __restrict__ hdr,
                                                         uint16_t* __restrict__ slots, int* __restrict__ status) {
-  __shared__ int s_lo[BM / 64][LINES], s_hi[BM / 64][LINES];
+  __shared__ int s_lo[BM / 64][PLANES], s_hi[BM / 64][PLANES];
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   const int blk = blockIdx.x, t = threadIdx.x, row = blk * BM + t;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ 
   for (int k = 0; k < 27; ++k) v[k] = live ? nbr[(size_t)k * nbr_stride + row] : -1;
   const int w = t >> 6;
 #pragma unroll
-  for (int j = 0; j < LINES; ++j) {
+  for (int j = 0; j < PLANES; ++j) {
     int lo = 0x7FFFFFFF, hi = -1;
 #pragma unroll
     for (int d = 0; d < TAPS; ++d) {
@@ -79,14 +80,14 @@ __global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ 
   __syncthreads();
   bool overflow = false;
 #pragma unroll
-  for (int j = 0; j < LINES; ++j) {
+  for (int j = 0; j < PLANES; ++j) {
     int lo = 0x7FFFFFFF, hi = -1;
 #pragma unroll
     for (int i = 0; i < BM / 64; ++i) { lo = s_lo[i][j] < lo ? s_lo[i][j] : lo; hi = s_hi[i][j] > hi ? s_hi[i][j] : hi; }
     int cnt = hi >= 0 ? hi - lo + 1 : 0;
     if (hi < 0) lo = 0;
     if (cnt > 0xFFFE) { cnt = 0xFFFE; overflow = true; }   // cannot happen for rows in linear-index order on grids the host admits
-    if (t == 0) hdr[(size_t)blk * LINES + j] = make_int2(lo, cnt);
+    if (t == 0) hdr[(size_t)blk * PLANES + j] = make_int2(lo, cnt);
 #pragma unroll
     for (int d = 0; d < TAPS; ++d) {
       const int k = j * TAPS + d, x = v[k];
@@ -107,43 +108,64 @@ template <> struct RowSwz<32> {    // 64-byte rows: 4 pieces; rows r and r+4 sha
   __device__ __forceinline__ static unsigned of(unsigned r) { return (r >> 1) & 2u; }
 };
 
-template <int KC, int CIN, int NT, int MT, int NW, int SPS, int CAP>
+// KC   channels staged per row (32 | 64; CIN / KC passes over the kernel)       SPS  taps per barrier (1 | 3 | 9)
+// MT   16-row tiles per wave, NW waves per workgroup (block = NW*16*MT rows)     WR   filter ring slots (2 | 3)
+// CAP  rows of one X buffer (ranges longer than that run in pieces)
+template <int KC, int CIN, int NT, int MT, int NW, int SPS, int WR, int CAP>
 struct Plan {
   static_assert(KC == 32 || KC == 64, "staged row = 32 or 64 channels");
-  static_assert(CIN % KC == 0 && TAPS % SPS == 0, "bad split");
+  static_assert(CIN % KC == 0 && TAPS % SPS == 0 && (WR == 2 || WR == 3), "bad split");
   static constexpr int BM = NW * 16 * MT;
   static constexpr int RB = KC * 2;                 // staged bytes per row
   static constexpr int PPR = RB / 16;               // 16-byte pieces per row
   static constexpr int RPI = 64 / PPR;              // rows per DMA instruction (1 KiB)
   static constexpr int CH = KC / 32;                // 32-channel chunks per staged row
   static constexpr int CPB = CIN / 32;              // chunks per kernel offset in the filter image
-  static constexpr int NH = CIN / KC;               // channel halves
-  static constexpr int GROUPS = TAPS / SPS;         // sync steps per line
+  static constexpr int NH = CIN / KC;               // channel passes
+  static constexpr int GROUPS = TAPS / SPS;         // sync steps per plane
+  static constexpr int WD = WR - 1;                 // steps of lookahead of the filter ring
+  static constexpr int DX = GROUPS >= 2 ? 1 : WD;   // planes of lookahead of the row staging (never less lead than the filter)
+  static constexpr int NXB = DX + 1;                // X buffers
   static constexpr int XB = ((CAP + 1) * RB + 1023) / 1024 * 1024;   // one X buffer incl. the zero row, KiB-aligned
   static constexpr int WS = SPS * CH * NT * 1024;   // filter bytes per sync step
+  static constexpr int PW = SPS * CH * NT;          // 1 KiB DMA pieces of one step's filter
+  static constexpr int NWS = (PW + NW - 1) / NW;    // ... per wave (waves past the end issue a dummy piece)
+  static constexpr int PX = CAP / RPI;              // 1 KiB DMA pieces of a full X buffer
+  static constexpr int NX = (PX + NW - 1) / NW;     // ... per wave: a FIXED count, so that s_waitcnt can count
   static constexpr int OFF_X = 0;
-  static constexpr int OFF_W = 2 * XB;
-  static constexpr int OFF_SLOT = OFF_W + 2 * WS;
-  static constexpr int BYTES = OFF_SLOT + 27 * BM * 2;
-  static_assert(NW * EpiScratch<NT>::U4 * 16 <= 2 * XB, "epilogue scratch must fit the X buffers it aliases");
+  static constexpr int OFF_W = NXB * XB;
+  static constexpr int OFF_SLOT = OFF_W + WR * WS;
+  static constexpr int OFF_DUMP = OFF_SLOT + 27 * BM * 2;   // landing zone of the dummy pieces
+  static constexpr int BYTES = OFF_DUMP + 1024;
+  static_assert(NW * EpiScratch<NT>::U4 * 16 <= NXB * XB, "epilogue scratch must fit the X buffers it aliases");
   static_assert(CAP % RPI == 0, "CAP must be a whole number of DMA instructions");
+  static_assert((CAP + 1) * RB < 65536, "row offsets are 16-bit");
+  static_assert(NX + WD * NWS < 60, "vmcnt is a 6-bit counter");
 };
 
-template <typename T>
-__device__ __forceinline__ void glds16(const T* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// LDS-DMA, buffer form: 16 bytes per lane from rsrc[voff + soff] to lds + lane*16 (wave-uniform lds / soff)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, (int)voff, (int)soff, 0, 0);
+}
+// at most N of this wave's DMA requests still in flight (they complete in issue order)
+template <int N>
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that does NOT drain the DMA queue (hipcc's __syncthreads puts vmcnt(0) in front of s_barrier while an
+// LDS-DMA is in flight): LDS reads of this wave are complete (their MFMAs were issued), requests stay in flight across it
+__device__ __forceinline__ void barrier_keep_dma() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 }
 
-// one staged range: channel half h, kernel line j, piece q of that line's rows
+// one staged range: channel pass h, kernel plane j, piece q of that plane's rows
 struct Sub {
   int h, j, q;
   bool done;
 };
 
-template <int DT, int KC, int CIN, int NT, int MT, int NW, int SPS, int CAP>
+template <int DT, int KC, int CIN, int NT, int MT, int NW, int SPS, int WR, int CAP>
 __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
-  typedef Plan<KC, CIN, NT, MT, NW, SPS, CAP> P;
+  typedef Plan<KC, CIN, NT, MT, NW, SPS, WR, CAP> P;
   typedef WaveTile<DT, (CIN > 64 ? 64 : CIN), NT, MT, (CIN > 64 ? 64 : CIN) / 32> WT;   // accumulators + epilogue only
   extern __shared__ u32x4 lds[];
   char* const L = (char*)lds;
@@ -155,127 +177,201 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
   const int per = (nblk + 7) >> 3;
   const int blk = xcd * per + bix;
   if (bix >= per || blk >= nblk) return;   // the whole workgroup leaves together
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to hipcc: without the readfirstlane every
+  // LDS-DMA below (uniform LDS base in M0, uniform soffset) is wrapped in a waterfall loop (cdna_hip_programming.md T20)
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g4 = lane >> 4;
 
-  // ---- slot table -> LDS; zero rows; block header -> one VGPR pair (lane j = line j) -------------------------------
+  // ---- slot table -> LDS; zero rows; block header -> one VGPR pair (lane j = plane j) ------------------------------
   uint16_t* slot = (uint16_t*)(L + P::OFF_SLOT);
   {
     const u32x4* src = (const u32x4*)(sa.slots + (size_t)blk * 27 * P::BM);
     constexpr int N16 = 27 * P::BM * 2 / 16;
     for (int i = tid; i < N16; i += NW * 64) ((u32x4*)slot)[i] = src[i];
-    if (tid < 2 * P::PPR) {
+    if (tid < P::NXB * P::PPR) {
       const int b = tid / P::PPR, p = tid % P::PPR;
       *(u32x4*)(L + P::OFF_X + b * P::XB + CAP * P::RB + p * 16) = u32x4{0u, 0u, 0u, 0u};
     }
   }
-  const int2 hl = sa.hdr[(size_t)blk * LINES + (lane < LINES ? lane : 0)];
-  const int vlo = hl.x, vcnt = lane < LINES ? hl.y : 0;
-  const unsigned live_lines = (unsigned)__builtin_amdgcn_readfirstlane((int)__ballot(vcnt > 0));   // bit j: line j has rows
-  auto line_lo = [&](int j) { return __builtin_amdgcn_readlane(vlo, j); };
-  auto line_cnt = [&](int j) { return __builtin_amdgcn_readlane(vcnt, j); };
-  auto next_line = [&](int from) {   // first line >= from with rows, LINES if none
-    const unsigned rest = from < LINES ? live_lines >> from : 0u;
-    return rest ? from + (int)__builtin_ctz(rest) : LINES;
+  const int2 hl = sa.hdr[(size_t)blk * PLANES + (lane < PLANES ? lane : 0)];
+  const int vlo = hl.x, vcnt = lane < PLANES ? hl.y : 0;
+  const unsigned live_planes = (unsigned)__builtin_amdgcn_readfirstlane((int)__ballot(vcnt > 0));   // bit j: plane j has rows
+  auto plane_lo = [&](int j) { return __builtin_amdgcn_readlane(vlo, j); };
+  auto plane_cnt = [&](int j) { return __builtin_amdgcn_readlane(vcnt, j); };
+  auto next_plane = [&](int from) {   // first plane >= from with rows, PLANES if none
+    const unsigned rest = from < PLANES ? live_planes >> from : 0u;
+    return rest ? from + (int)__builtin_ctz(rest) : PLANES;
   };
   auto next_sub = [&](Sub u) {
-    if ((u.q + 1) * CAP < line_cnt(u.j)) { ++u.q; return u; }
+    if (u.done) return u;
+    if ((u.q + 1) * CAP < plane_cnt(u.j)) { ++u.q; return u; }
     u.q = 0;
-    u.j = next_line(u.j + 1);
-    if (u.j < LINES) return u;
-    u.j = next_line(0);
+    u.j = next_plane(u.j + 1);
+    if (u.j < PLANES) return u;
+    u.j = next_plane(0);
     if (++u.h >= P::NH) u.done = true;
     return u;
   };
 
-  const typename Num<DT>::T* feat = (const typename Num<DT>::T*)a.feat;
-  const size_t row_elems = (size_t)a.feat_stride;
-  // rows of piece (j, q), channel half h -> X buffer xb: 1 KiB DMA instructions dealt round-robin to the waves
+  const unsigned row_bytes = (unsigned)a.feat_stride * 2u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat, 0, (unsigned)a.n_in * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, sa.wimg_bytes, 0x00020000);
+  char* const dump = L + P::OFF_DUMP;
+  // Lane constants of the row staging: lane -> (row lr of the instruction's RPI rows, physical 16-byte position sp).  The
+  // logical piece stored there is sp ^ swz(row) and swz only looks at row bits below RPI, so it is the same for every instruction.
+  const unsigned lr = (unsigned)(lane / P::PPR), sp = (unsigned)(lane % P::PPR);
+  const unsigned lane_piece_off = (sp ^ RowSwz<KC>::of(lr)) * 16u;
+  static_assert(P::RPI % 8 == 0, "swizzle must not depend on the instruction index");
+  // rows of piece (j, q), channel pass h -> X buffer xb.  Every wave issues exactly NX 1-KiB requests: pieces past the
+  // range re-read its last row (into rows no slot refers to, or into the dump)
   auto stage_x = [&](const Sub& u, int xb) {
-    const int n = line_cnt(u.j) - u.q * CAP;
-    const int rows = n < CAP ? n : CAP;
-    const int base = line_lo(u.j) + u.q * CAP;
-    const int ninstr = (rows + P::RPI - 1) / P::RPI;
+    const int n = plane_cnt(u.j) - u.q * CAP;
+    const unsigned rows = (unsigned)(n < CAP ? n : CAP);
+    const unsigned soff = (unsigned)(plane_lo(u.j) + u.q * CAP) * row_bytes + (unsigned)(u.h * KC * 2);
     char* dst = L + P::OFF_X + xb * P::XB;
-    for (int i = w; i < ninstr; i += NW) {
-      unsigned r = (unsigned)(i * P::RPI + lane / P::PPR);
-      const unsigned sp = (unsigned)(lane % P::PPR);
-      const unsigned p = sp ^ RowSwz<KC>::of(r);          // logical piece stored at physical position sp of LDS row r
-      r = r < (unsigned)rows ? r : (unsigned)(rows - 1);   // tail lanes re-read the last row (never referenced by a slot)
-      glds16(feat + (size_t)(base + (int)r) * row_elems + u.h * KC + p * 8, dst + i * 1024);
+#pragma unroll
+    for (int t = 0; t < P::NX; ++t) {
+      const int i = w + t * NW;
+      unsigned r = (unsigned)(i * P::RPI) + lr;
+      r = r < rows ? r : rows - 1u;
+      dma16(rs_x, r * row_bytes + lane_piece_off, soff, i < P::PX ? dst + i * 1024 : dump);
     }
   };
-  // filter fragments of the SPS taps of group g of line j, half h -> ring slot wb (contiguous CH * NT KiB per tap)
-  auto stage_w = [&](const Sub& u, int g, int wb) {
-    char* dst = L + P::OFF_W + wb * P::WS;
+  // filter fragments of the SPS taps of group g of plane j, pass h -> ring slot ws: exactly NWS requests per wave
+  auto stage_w = [&](const Sub& u, int g, int ws) {
+    char* dst = L + P::OFF_W + ws * P::WS;
     constexpr int PER_TAP = P::CH * NT;   // KiB per tap
-    for (int i = w; i < SPS * PER_TAP; i += NW) {
+#pragma unroll
+    for (int t = 0; t < P::NWS; ++t) {
+      const int i0 = w + t * NW;
+      const int i = i0 < P::PW ? i0 : P::PW - 1;
       const int s = i / PER_TAP, e = i - s * PER_TAP;
       const int k = u.j * TAPS + g * SPS + s;
-      const char* src = (const char*)a.wimg + ((size_t)(k * P::CPB + u.h * P::CH) * NT + e) * 1024;
-      glds16(src + lane * 16, dst + i * 1024);
+      dma16(rs_w, (unsigned)lane * 16u, (unsigned)(((k * P::CPB + u.h * P::CH) * NT + e) * 1024), i0 < P::PW ? dst + i * 1024 : dump);
+    }
+  };
+  // all but the newest requests named here have landed
+  auto wait_for = [&](int n_w, bool keep_x) {   // n_w in 0..WD steps of filter requests still allowed in flight
+    if (keep_x) {
+      if (n_w >= 2) wait_dma<P::NX + 2 * P::NWS>();
+      else if (n_w == 1) wait_dma<P::NX + P::NWS>();
+      else wait_dma<P::NX>();
+    } else {
+      if (n_w >= 2) wait_dma<2 * P::NWS>();
+      else if (n_w == 1) wait_dma<P::NWS>();
+      else wait_dma<0>();
     }
   };
 
   WT wt;
   wt.init(a, blk * P::BM + w * 16 * MT, m, nullptr, (u32x4*)(L + P::OFF_X) + w * EpiScratch<NT>::U4);
 
-  // multiply the SPS taps of group g of piece `u` from X buffer xb and ring slot wb
-  auto multiply = [&](const Sub& u, int g, int xb, int wb) {
+  // multiply the SPS taps of group g of piece `u` from X buffer xb and ring slot ws.  The reduction is a flat list of
+  // SPS * CH units (tap, 32-channel chunk); the fragments of unit i+1 (NT filter + MT row fragments, all ds_read_b128) are
+  // requested BEFORE the MT*NT MFMAs of unit i are issued (two register sets, sched_barrier keeps hipcc from re-serialising
+  // them behind one s_waitcnt): the LDS round trip of one unit hides under the MFMAs of the previous one.
+  auto multiply = [&](const Sub& u, int g, int xb, int ws) {
     const char* X = L + P::OFF_X + xb * P::XB;
-    const u32x4* Wl = (const u32x4*)(L + P::OFF_W + wb * P::WS);
+    const u32x4* Wl = (const u32x4*)(L + P::OFF_W + ws * P::WS);
     const unsigned pbase = (unsigned)(u.q * CAP);
-    const unsigned plive = (unsigned)line_cnt(u.j) - pbase;
+    const unsigned plive = (unsigned)plane_cnt(u.j) - pbase;
     const unsigned prow = plive < (unsigned)CAP ? plive : (unsigned)CAP;   // rows of this piece
+    constexpr int U = SPS * P::CH;
+    const uint16_t* sl = slot + (u.j * TAPS + g * SPS) * P::BM + w * 16 * MT + c;
+    unsigned xo[SPS][MT];   // byte address of piece 0 of the row | swizzle in the top bits
 #pragma unroll
-    for (int s = 0; s < SPS; ++s) {
-      const int k = u.j * TAPS + g * SPS + s;
-      unsigned xo[MT], xs[MT];
+    for (int s = 0; s < SPS; ++s)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        unsigned e = (unsigned)slot[k * P::BM + w * 16 * MT + mt * 16 + c] - pbase;   // NO_SLOT - pbase stays >= prow
-        e = e < prow ? e : (unsigned)CAP;                                             // outside the piece: the zero row
-        xo[mt] = e * P::RB;
-        xs[mt] = RowSwz<KC>::of(e);
+        unsigned e = (unsigned)sl[s * P::BM + mt * 16] - pbase;   // NO_SLOT - pbase stays >= prow
+        e = e < prow ? e : (unsigned)CAP;                         // outside the piece: the zero row
+        xo[s][mt] = e * P::RB + (RowSwz<KC>::of(e) << 20);
       }
+    auto fetch = [&](int i, u32x4 (&b)[NT], u32x4 (&x)[MT]) {
+      const int s = i / P::CH, cc = i % P::CH;
 #pragma unroll
-      for (int cc = 0; cc < P::CH; ++cc) {
-        u32x4 b[NT], x[MT];
+      for (int nt = 0; nt < NT; ++nt) b[nt] = Wl[(i * NT + nt) * 64 + lane];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = Wl[((s * P::CH + cc) * NT + nt) * 64 + lane];
+      for (int mt = 0; mt < MT; ++mt)
+        x[mt] = *(const u32x4*)(X + (xo[s][mt] & 0xFFFFFu) + (((unsigned)(cc * 4 + g4)) ^ (xo[s][mt] >> 20)) * 16);
+    };
+    auto mma = [&](const u32x4 (&b)[NT], const u32x4 (&x)[MT]) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          x[mt] = *(const u32x4*)(X + xo[mt] + (((unsigned)(cc * 4 + g4)) ^ xs[mt]) * 16);
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mt = 0; mt < MT; ++mt) wt.acc[mt][nt] = mfma<DT>(b[nt], x[mt], wt.acc[mt][nt]);
+    };
+    u32x4 b0[NT], x0[MT], b1[NT], x1[MT];
+    fetch(0, b0, x0);
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wt.acc[mt][nt] = mfma<DT>(b[nt], x[mt], wt.acc[mt][nt]);
+    for (int i = 0; i < U; i += 2) {
+      if (i + 1 < U) fetch(i + 1, b1, x1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(b0, x0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < U) {
+        if (i + 2 < U) fetch(i + 2, b0, x0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(b1, x1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
 
-  Sub cur{0, next_line(0), 0, false};   // the centre line always has rows in a live block
-  Sub nxt = next_sub(cur);
-  stage_x(cur, 0);
-  stage_w(cur, 0, 0);
-  int xb = 0, wb = 0;
-  __syncthreads();   // (hipcc drains the DMA queue — vmcnt(0) — in front of the barrier; also publishes the slot table)
+  // Pipeline.  Steps are numbered t = 0, 1, ...; step t reads filter ring slot t % WR and the X buffer of its piece.
+  // While step t multiplies, the filter of step t+WD and (at the first step of a piece) the rows of the piece DX planes ahead
+  // are in flight; each wave's requests complete in issue order and every wave issues the same fixed number per step, so
+  // "everything step t+1 needs has landed" is a COUNTED wait at the end of step t, never a full drain.
+  Sub sub[3];   // this piece, the next, the one after
+  sub[0] = Sub{0, next_plane(0), 0, false};   // the centre plane always has rows in a live block
+  sub[1] = next_sub(sub[0]);
+  sub[2] = next_sub(sub[1]);
+  auto step_after = [&](int g, int d, int& off, int& g2) { const int gg = g + d; off = gg / P::GROUPS; g2 = gg % P::GROUPS; };
+  stage_x(sub[0], 0);
+  if (P::DX == 2 && !sub[1].done) stage_x(sub[1], 1);
+#pragma unroll
+  for (int d = 0; d < P::WD; ++d) {
+    int off, gd;
+    step_after(0, d, off, gd);
+    if (!sub[off].done) stage_w(sub[off], gd, d);
+  }
+  wait_dma<0>();
+  __syncthreads();   // also publishes the slot table and the zero rows
+  int xb = 0, ws = 0;
+  bool x_prev = false;
   for (;;) {
 #pragma unroll
     for (int g = 0; g < P::GROUPS; ++g) {
-      // requests for the next step go out first: the filter of the next group (or of the next piece's first group), and —
-      // at the first group of a piece — the rows of the next piece; they land while this step multiplies
-      if (g + 1 < P::GROUPS) stage_w(cur, g + 1, wb ^ 1);
-      else if (!nxt.done) stage_w(nxt, 0, wb ^ 1);
-      if (g == 0 && !nxt.done) stage_x(nxt, xb ^ 1);
-      multiply(cur, g, xb, wb);
-      __syncthreads();   // the requests landed (vmcnt(0) in front of the barrier); everyone is done with xb / wb
-      wb ^= 1;
+      // requests: the filter of step t + WD, then (first step of a piece) the rows of the piece DX planes ahead
+      int off, gd;
+      step_after(g, P::WD, off, gd);
+      const bool w_new = !sub[off].done;
+      if (w_new) stage_w(sub[off], gd, (ws + P::WD) % WR);
+      const bool x_now = g == 0 && !sub[P::DX].done;
+      if (x_now) stage_x(sub[P::DX], (xb + P::DX) % P::NXB);
+      multiply(sub[0], g, xb, ws);
+      // Needed by step t+1: its filter and, if it opens a piece, that piece's rows — both requested before the filter of
+      // step t+2 was.  Newer than those (may stay in flight): the filters of steps t+2 .. t+WD and the rows requested during
+      // this step, or — when a piece spans several steps — during the previous one.
+      int n_w = 0;
+#pragma unroll
+      for (int d = 2; d <= P::WD; ++d) {
+        int o2, g2;
+        step_after(g, d, o2, g2);
+        n_w += !sub[o2].done;
+      }
+      const bool keep_x = P::GROUPS >= 2 ? (x_now || (P::WD >= 2 && x_prev)) : (P::DX == 2 && x_now);
+      wait_for(n_w, keep_x);
+      barrier_keep_dma();
+      x_prev = x_now;
+      ws = ws + 1 == WR ? 0 : ws + 1;
     }
-    if (nxt.done) break;
-    cur = nxt;
-    nxt = next_sub(cur);
-    xb ^= 1;
+    if (sub[1].done) break;
+    sub[0] = sub[1];
+    sub[1] = sub[2];
+    sub[2] = next_sub(sub[2]);
+    xb = xb + 1 == P::NXB ? 0 : xb + 1;
   }
   wt.store(a);   // epilogue scratch aliases the X buffers: every wave passed the last barrier, nobody reads X any more
 }

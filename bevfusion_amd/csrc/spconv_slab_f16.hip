@@ -28,17 +28,17 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
   return n;
 }
 
-/* 1 if a voxel set on a [batch, X, Y, Z] grid whose rows are in ascending linear index can use the slab kernels: a line's
- * input range is at most block_rows + (Y + 1) * Z + 2 rows, which must fit the 16-bit slots. */
+/* 1 if a voxel set on a [batch, X, Y, Z] grid whose rows are in ascending linear index can use the slab kernels: the input
+ * range of a kernel plane is at most block_rows + (Y + 2) * Z + 2 rows, which must fit the 16-bit slots. */
 int bevamd_spconv_slab_grid_ok(const int* shape, int block_rows) {
   if (!shape || block_rows <= 0) return 0;
-  const long long bound = (long long)block_rows + ((long long)shape[1] + 1) * shape[2] + 2;
+  const long long bound = (long long)block_rows + ((long long)shape[1] + 2) * shape[2] + 2;
   return bound < 0xFFFE;
 }
 
 size_t bevamd_spconv_slab_hdr_bytes(int m_cap, int block_rows) {
   if (m_cap <= 0 || block_rows <= 0) return 0;
-  return (size_t)((m_cap + block_rows - 1) / block_rows) * slab::LINES * sizeof(int2);
+  return (size_t)((m_cap + block_rows - 1) / block_rows) * slab::PLANES * sizeof(int2);
 }
 size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows) {
   if (m_cap <= 0 || block_rows <= 0) return 0;
@@ -46,8 +46,8 @@ size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows) {
 }
 
 /* Block metadata of a 3x3x3 SubM neighbour table nbr [27, nbr_stride] over m rows (m = *m_dev clamped to m_cap, or m_cap):
- * per block of block_rows (128 | 256) rows and kernel line (kx, ky): hdr = (first input row, row count) of the range its
- * three kz taps read, slots = the table as 16-bit offsets into that range (0xFFFF = no neighbour).  Built once per voxel
+ * per block of block_rows (128 | 256) rows and kernel plane kx: hdr = (first input row, row count) of the range its nine
+ * (ky, kz) taps read, slots = the table as 16-bit offsets into that range (0xFFFF = no neighbour).  Built once per voxel
  * set, shared by every SubM convolution over it.  status (optional int32, device): bit 0 is set if a range exceeded the
  * 16-bit slots (rows not in linear-index order on a grid bevamd_spconv_slab_grid_ok rejects). */
 int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const int* m_dev, int block_rows, void* hdr,
@@ -100,6 +100,7 @@ int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_st
                    (!bias || ((uintptr_t)bias & 15) == 0) && (!bn_scale || (((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0);
   sa.hdr = (const int2*)hdr;
   sa.slots = (const uint16_t*)slots;
+  sa.wimg_bytes = (unsigned)(tile::image_elems(27, cin, cout / 16) * 2);
   return dtype == tile::T_F16 ? slab::launch_f16(sa, cin, cout / 16, variant, stream)
                               : slab::launch_bf16(sa, cin, cout / 16, variant, stream);
 }

@@ -5,15 +5,16 @@
 namespace bevamd {
 namespace slab {
 
-// variant = KC*1000 + MT*100 + (NW/4)*10 + SPS   (KC: channels staged per row, 32 | 64; SPS: kernel taps per barrier, 1 | 3)
-struct Shape { int kc, mt, nw, sps, cap; };
+// variant = KC*10000 + MT*1000 + (NW/4)*100 + SPS*10 + WR
+//   KC: channels staged per row (32 | 64)   MT: 16-row tiles per wave   NW: waves per workgroup
+//   SPS: kernel taps per barrier (1 | 3 | 9)   WR: filter ring slots (2 | 3)
+struct Shape { int kc, mt, nw, sps, wr, cap; };
 
-template <int DT, int KC, int CIN, int NT, int MT, int NW, int SPS, int CAP>
+template <int DT, int KC, int CIN, int NT, int MT, int NW, int SPS, int WR, int CAP>
 static int run(const SlabArgs& sa, hipStream_t stream) {
-  typedef Plan<KC, CIN, NT, MT, NW, SPS, CAP> P;
-  static_assert((CAP + 1) * P::RB < 65536, "row offsets are packed into 16 bits");
+  typedef Plan<KC, CIN, NT, MT, NW, SPS, WR, CAP> P;
   static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
-  auto kern = &spconv_slab_kernel<DT, KC, CIN, NT, MT, NW, SPS, CAP>;
+  auto kern = &spconv_slab_kernel<DT, KC, CIN, NT, MT, NW, SPS, WR, CAP>;
   if (P::BYTES > 65536) {
     static bool raised = false;
     if (!raised) {
@@ -29,19 +30,30 @@ static int run(const SlabArgs& sa, hipStream_t stream) {
   return BEVAMD_OK;
 }
 
-// the built configurations per input width (first entry = default)
+// the built configurations per input width (first entry = default); X(...) expands once per configuration
+// MI355X, 8 flagship frames per launch, fp16 (profiles/r02_slab_sweep_b8.txt; gather kernel in brackets):
+//   32->32 2.08 M rows: 322113 218 us [292]   64->64 788 k rows: 642113 206 us / 642232 204 us [246]
+//   128->128 192 k rows: 642213 167 us / 322232 166 us [193];  one frame: 30 [41], 34 [35], 42-61 [38] -> the 128-channel layers
+//   keep the gather kernel below 4 frames (spconv/fused.py).  64 rows per wave (MT = 4) was measured too: 274-389 us, one
+//   workgroup per CU is too little latency hiding.
+#define BEVAMD_SLAB_SHAPES_32(X) X(32, 2, 4, 1, 3, 192) X(32, 2, 4, 3, 3, 192) X(32, 2, 4, 9, 2, 192)
+#define BEVAMD_SLAB_SHAPES_64(X) X(64, 2, 4, 1, 3, 184) X(64, 2, 8, 1, 3, 320) X(64, 2, 8, 3, 2, 320) X(32, 2, 4, 1, 3, 192)
+#define BEVAMD_SLAB_SHAPES_128(X) X(64, 2, 8, 1, 3, 320) X(64, 1, 8, 1, 3, 192) X(32, 2, 8, 1, 3, 384) X(32, 2, 8, 3, 2, 384)
+
 static inline const Shape* shapes_of(int cin, int* n) {
-  static const Shape s32[] = {{32, 2, 4, 3, 192}, {32, 4, 4, 3, 384}, {32, 2, 4, 1, 192}};
-  static const Shape s64[] = {{64, 2, 4, 1, 192}, {64, 2, 8, 1, 320}, {32, 2, 4, 1, 192}, {32, 2, 4, 3, 192}};
-  static const Shape s128[] = {{64, 2, 4, 1, 144}, {32, 2, 4, 1, 192}, {64, 1, 8, 1, 160}};
+#define BEVAMD_ROW(KC, MT, NW, SPS, WR, CAP) {KC, MT, NW, SPS, WR, CAP},
+  static const Shape s32[] = {BEVAMD_SLAB_SHAPES_32(BEVAMD_ROW)};
+  static const Shape s64[] = {BEVAMD_SLAB_SHAPES_64(BEVAMD_ROW)};
+  static const Shape s128[] = {BEVAMD_SLAB_SHAPES_128(BEVAMD_ROW)};
+#undef BEVAMD_ROW
   switch (cin) {
-    case 32: *n = 3; return s32;
-    case 64: *n = 4; return s64;
-    case 128: *n = 3; return s128;
+    case 32: *n = (int)(sizeof(s32) / sizeof(Shape)); return s32;
+    case 64: *n = (int)(sizeof(s64) / sizeof(Shape)); return s64;
+    case 128: *n = (int)(sizeof(s128) / sizeof(Shape)); return s128;
     default: *n = 0; return nullptr;
   }
 }
-static inline int variant_code(const Shape& s) { return s.kc * 1000 + s.mt * 100 + (s.nw / 4) * 10 + s.sps; }
+static inline int variant_code(const Shape& s) { return s.kc * 10000 + s.mt * 1000 + (s.nw / 4) * 100 + s.sps * 10 + s.wr; }
 static inline const Shape* find_shape(int cin, int variant) {
   int n = 0;
   const Shape* s = shapes_of(cin, &n);
@@ -60,19 +72,18 @@ int launch_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t st
     return BEVAMD_ERR_UNSUPPORTED;
   }
   const int code = variant_code(*s);
-#define BEVAMD_SLAB(CIN, KC, MT, NW, SPS, CAP) \
-  if (cin == CIN && code == KC * 1000 + MT * 100 + (NW / 4) * 10 + SPS) return run<DT, KC, CIN, CIN / 16, MT, NW, SPS, CAP>(sa, stream)
-  BEVAMD_SLAB(32, 32, 2, 4, 3, 192);
-  BEVAMD_SLAB(32, 32, 4, 4, 3, 384);
-  BEVAMD_SLAB(32, 32, 2, 4, 1, 192);
-  BEVAMD_SLAB(64, 64, 2, 4, 1, 192);
-  BEVAMD_SLAB(64, 64, 2, 8, 1, 320);
-  BEVAMD_SLAB(64, 32, 2, 4, 1, 192);
-  BEVAMD_SLAB(64, 32, 2, 4, 3, 192);
-  BEVAMD_SLAB(128, 64, 2, 4, 1, 144);
-  BEVAMD_SLAB(128, 32, 2, 4, 1, 192);
-  BEVAMD_SLAB(128, 64, 1, 8, 1, 160);
-#undef BEVAMD_SLAB
+#define BEVAMD_CASE32(KC, MT, NW, SPS, WR, CAP) \
+  if (cin == 32 && code == KC * 10000 + MT * 1000 + (NW / 4) * 100 + SPS * 10 + WR) return run<DT, KC, 32, 2, MT, NW, SPS, WR, CAP>(sa, stream);
+#define BEVAMD_CASE64(KC, MT, NW, SPS, WR, CAP) \
+  if (cin == 64 && code == KC * 10000 + MT * 1000 + (NW / 4) * 100 + SPS * 10 + WR) return run<DT, KC, 64, 4, MT, NW, SPS, WR, CAP>(sa, stream);
+#define BEVAMD_CASE128(KC, MT, NW, SPS, WR, CAP) \
+  if (cin == 128 && code == KC * 10000 + MT * 1000 + (NW / 4) * 100 + SPS * 10 + WR) return run<DT, KC, 128, 8, MT, NW, SPS, WR, CAP>(sa, stream);
+  BEVAMD_SLAB_SHAPES_32(BEVAMD_CASE32)
+  BEVAMD_SLAB_SHAPES_64(BEVAMD_CASE64)
+  BEVAMD_SLAB_SHAPES_128(BEVAMD_CASE128)
+#undef BEVAMD_CASE32
+#undef BEVAMD_CASE64
+#undef BEVAMD_CASE128
   set_error("spconv slab: variant %d is listed but not built for cin=%d", code, cin);
   return BEVAMD_ERR_UNSUPPORTED;
 }

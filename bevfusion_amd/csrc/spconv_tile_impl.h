@@ -64,8 +64,10 @@ constexpr bool resident_built() {
   return CINP <= 32 && NT <= 2 && 2 * MT * CPO * 4 + MT * NT * 4 <= 160;
 }
 
-// profiling only: variant 9000 + mask launches the shipped stream configuration of the 64->64 / 128->128 layers with parts
-// of the kernel compiled out (see WaveTile's ABL) — tools/sweep_spconv.py --ablate
+// profiling builds only (-DBEVAMD_PROFILING, `python -m bevfusion_amd.build --profiling`): variant 9000 + mask launches the
+// shipped stream configuration of the 64->64 / 128->128 layers with parts of the kernel compiled out (see WaveTile's ABL;
+// results are wrong by construction) — tools/sweep_spconv.py --ablate.  The shipped library does not contain them.
+#ifdef BEVAMD_PROFILING
 template <int DT, int CINP, int NT, int MT, int NW, int SPS, int ABL>
 static int run_ablation(const Args& a, hipStream_t stream) {
   constexpr int CPO = SPS * Chunks<CINP>::CPB;
@@ -79,10 +81,12 @@ static int run_ablation(const Args& a, hipStream_t stream) {
   BEVAMD_LAUNCH_CHECK("spconv_stream(ablation)");
   return BEVAMD_OK;
 }
+#endif
 
 template <int DT, int CINP, int NT>
 static int run_shape(const Args& a, int variant, hipStream_t stream) {
   if (variant >= 9000) {
+#ifdef BEVAMD_PROFILING
     if constexpr (DT == T_F16 && ((CINP == 64 && NT == 4) || (CINP == 128 && NT == 8))) {
       constexpr int MT = CINP == 64 ? 2 : 1, NW = CINP == 64 ? 4 : 8;
       switch (variant - 9000) {
@@ -94,7 +98,8 @@ static int run_shape(const Args& a, int variant, hipStream_t stream) {
         default: break;
       }
     }
-    set_error("spconv tiled: ablation variant %d is not built for this shape", variant);
+#endif
+    set_error("spconv tiled: ablation variant %d needs a -DBEVAMD_PROFILING build of the library (and the 64->64 / 128->128 fp16 shapes)", variant);
     return BEVAMD_ERR_UNSUPPORTED;
   }
   if (variant == 0) {

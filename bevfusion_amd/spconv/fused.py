@@ -74,6 +74,8 @@ class Level:
         self.ready = None           # event behind the kernels that produced indices / n_dev / index (None: already ordered)
         self._subm = {}
         self._down = {}
+        self._slab = {}
+        self.linear_order = False   # rows in ascending linear index (every set a strided convolution produced)
 
     @property
     def device(self):
@@ -138,6 +140,18 @@ class Level:
             self._await(ev)
         return nbr
 
+    def subm_slab(self, block_rows, wait=True):
+        """Slab metadata (ops.SlabMeta) of the 3x3x3 SubM neighbour table, for `block_rows`-row blocks: built once, on the
+        geometry stream, behind the table it rewrites."""
+        if block_rows not in self._slab:
+            nbr = self.subm_neighbors((3, 3, 3), wait=False)
+            meta = ops.slab_build(nbr, self.n_cap, self.n_dev, block_rows, stream_ptr=self._stream_ptr())
+            self._slab[block_rows] = (meta, self._mark())
+        meta, ev = self._slab[block_rows]
+        if wait:
+            self._await(ev)
+        return meta
+
     def downsample(self, ksize, stride, padding, wait=True):
         """(output Level with its rank index, nbr [K, cap_out]) of a strided convolution over this set."""
         key = (tuple(ksize), tuple(stride), tuple(padding))
@@ -171,6 +185,7 @@ class Level:
         _capi.check(rc, "spconv_downsample")
         out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream)
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
+        out.linear_order = True
         out.ready = self._mark()    # behind the downsample: indices, count, rank index and this conv's nbr are final
         self._down[key] = (out, nbr)
         if wait:
@@ -238,6 +253,12 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
         out_lvl, nbr = lvl.downsample(conv.kernel_size, conv.stride, conv.padding)
     K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
     out = torch.empty((out_lvl.n_cap, cout), dtype=dtype, device=x.features.device)
+    slab_variant = _slab_variant_for(conv, lvl, cin, cout)
+    if slab_variant is not None:
+        meta = lvl.subm_slab(ops.slab_block_rows(cin, slab_variant))
+        ops.sparse_conv_slab(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
+                             residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out, variant=slab_variant)
+        return FusedTensor(out, out_lvl)
     ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                           residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
                           variant=_variant_for(lvl.batch, K, cin, cout))
@@ -251,6 +272,38 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
 # (A/B on one box, 8 frames: LiDAR branch 6.11-6.18 -> 5.91-5.94 ms; entries for the 5->16 and 16->32 layers, 10-16 % faster
 # in isolation, changed nothing inside the graph and were left out).
 _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 2211, (128, 128): 2221}
+
+
+# Slab (staged-rows) kernels for the 3x3x3 SubM layers of the sorted levels (csrc/spconv_slab.h): BEVAMD_SPCONV_SLAB=0 keeps
+# the gather kernels; BEVAMD_SPCONV_SLAB_VARIANTS="32:322133,64:642232" overrides the per-width variant (tuning).
+# Measured (tools/sweep_spconv.py --slab, profiles/r02_slab_sweep_*.txt): 8 frames 218 / 206 / 167 us against 292 / 246 / 193 us
+# of the gather kernels for 32 / 64 / 128 channels; one frame 30 / 34 us against 41 / 35 us, but 42+ against 38 us at 128
+# channels (188 blocks on 256 CUs) -> the 128-channel layers switch over from 4 frames per step.
+_SLAB_DEFAULT = {32: 0, 64: 0, 128: 0}     # 0 = the library's first-listed variant
+_SLAB_MIN_BATCH = {128: 4}
+
+
+def _slab_overrides():
+    spec = os.environ.get("BEVAMD_SPCONV_SLAB_VARIANTS", "")
+    out = {}
+    for item in filter(None, spec.split(",")):
+        c, v = item.split(":")
+        out[int(c)] = int(v)
+    return out
+
+
+def _slab_variant_for(conv, lvl, cin, cout):
+    if os.environ.get("BEVAMD_SPCONV_SLAB", "1") == "0":
+        return None
+    if not (conv.subm and tuple(conv.kernel_size) == (3, 3, 3) and lvl.linear_order and cin == cout):
+        return None
+    if cin not in _SLAB_DEFAULT or lvl.batch < _SLAB_MIN_BATCH.get(cin, 1):
+        return None
+    variant = _slab_overrides().get(cin, _SLAB_DEFAULT[cin])
+    rows = ops.slab_block_rows(cin, variant)
+    if rows == 0 or not ops.slab_grid_ok(lvl.shape, rows):
+        return None
+    return variant
 
 
 def _variant_for(batch, K, cin, cout):
@@ -384,5 +437,8 @@ def prefetch_geometry(enc, lvl):
             continue
         if m.subm:
             cur.subm_neighbors(m.kernel_size, wait=False)
+            v = _slab_variant_for(m, cur, m.in_channels, m.out_channels)
+            if v is not None:
+                cur.subm_slab(ops.slab_block_rows(m.in_channels, v), wait=False)
         else:
             cur, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False)

@@ -302,6 +302,70 @@ def sparse_conv_tiled(features, image, nbr, num_out, kernel_volume, cin, cout, b
     return out
 
 
+# ---- slab (staged-rows) SubM convolution: csrc/spconv_slab.h ------------------------------------------------------------
+def slab_block_rows(cin, variant=0):
+    """Rows per block of slab variant `variant` (0 = default) for a cin -> cin 3x3x3 SubM convolution; 0 = not built."""
+    return int(_capi.load().bevamd_spconv_slab_block_rows(int(cin), int(variant)))
+
+
+def slab_variants(cin):
+    lib = _capi.load()
+    codes = (_capi.c_int * 16)()
+    n = lib.bevamd_spconv_slab_variants(int(cin), codes, 16)
+    return [int(codes[i]) for i in range(min(n, 16))]
+
+
+def slab_grid_ok(shape, block_rows):
+    return bool(_capi.load().bevamd_spconv_slab_grid_ok(_capi.ints(shape), int(block_rows)))
+
+
+class SlabMeta:
+    """Block metadata of a 3x3x3 SubM neighbour table over rows in ascending linear index (bevamd_spconv_slab_build)."""
+
+    def __init__(self, hdr, slots, block_rows, status):
+        self.hdr, self.slots, self.block_rows, self.status = hdr, slots, block_rows, status
+
+
+def slab_build(nbr, m_cap, m_dev, block_rows, stream_ptr=None):
+    lib = _capi.load()
+    dev = nbr.device
+    assert nbr.shape[0] == 27 and nbr.dtype == torch.int32
+    with torch.cuda.device(dev):
+        hdr = torch.empty(max(lib.bevamd_spconv_slab_hdr_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
+        slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.bevamd_spconv_slab_build(_capi.ptr(nbr), nbr.stride(0), int(m_cap), _capi.ptr(m_dev), int(block_rows),
+                                          _capi.ptr(hdr), _capi.ptr(slots), _capi.ptr(status),
+                                          stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
+    _capi.check(rc, "spconv_slab_build")
+    return SlabMeta(hdr, slots, int(block_rows), status)
+
+
+def sparse_conv_slab(features, image, meta, num_out, cin, cout, bias=None, bn_scale=None, bn_shift=None, residual=None,
+                     relu=False, num_out_dev=None, out=None, variant=0):
+    """`sparse_conv_tiled` for a 3x3x3 SubM convolution over linear-index-ordered rows, through the slab kernels."""
+    lib = _capi.load()
+    _require_cuda(features, "features")
+    if features.stride(1) != 1:
+        features = features.contiguous()
+    dt = _dtype_code(features)
+    if out is None:
+        out = torch.empty((num_out, cout), dtype=features.dtype, device=features.device)
+    if num_out == 0:
+        return out
+    if residual is not None and residual.stride(1) != 1:
+        residual = residual.contiguous()
+    with torch.cuda.device(features.device):
+        rc = lib.bevamd_spconv_conv_forward_slab(
+            _capi.ptr(features), dt, features.stride(0), features.shape[0], _capi.ptr(image), _capi.ptr(meta.hdr),
+            _capi.ptr(meta.slots), meta.block_rows, int(num_out), _capi.ptr(num_out_dev), int(cin), int(cout), _capi.ptr(out),
+            out.stride(0), _capi.ptr(bias), _capi.ptr(bn_scale), _capi.ptr(bn_shift), _capi.ptr(residual),
+            residual.stride(0) if residual is not None else 0, int(bool(relu)), int(variant),
+            _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_conv_forward_slab")
+    return out
+
+
 def _pad_channels(features, pitch):
     if features.shape[1] == pitch:
         return features

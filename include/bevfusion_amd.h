@@ -411,6 +411,34 @@ int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_s
                                      const float* bn_shift, const void* residual, int residual_stride,
                                      int relu, int variant, void* stream);
 
+/* Slab (staged-rows) forward for 3x3x3 SUBMANIFOLD convolutions over voxel sets whose rows are in ascending linear index
+ * ((b*X + x)*Y + y)*Z + z — every set a strided convolution produced (the reference's CUDA row order, spconv_ops.h:130).
+ * Same operator, epilogue and results as bevamd_spconv_conv_forward_tiled (sparse_conv_ext.indice_conv_half, all.cc:30-33 ->
+ * spconv_ops.h:260-361 with subM = 1), cin == cout in {32, 64, 128}; bit-identical to it for cin <= 64.  Instead of gathering
+ * 19-27 neighbour rows per output row through the texture path, a workgroup copies the ~9 contiguous input ranges its block
+ * of rows reads (one per kernel line (kx, ky)) into LDS and feeds the MFMAs from there (csrc/spconv_slab.h).
+ *   bevamd_spconv_slab_block_rows(cin, variant)   rows per block of a variant (0 = default variant; returns 0 if not built)
+ *   bevamd_spconv_slab_variants(cin, codes, n)     the variant codes built for cin (tuning sweeps)
+ *   bevamd_spconv_slab_grid_ok(shape, block_rows)  1 if ranges on this [X, Y, Z] grid always fit the 16-bit slots
+ *   bevamd_spconv_slab_{hdr,slot}_bytes            metadata sizes for m_cap rows
+ *   bevamd_spconv_slab_build                       nbr [27, nbr_stride] (bevamd_spconv_neighbors, subm = 1) -> per block and
+ *                                                  kernel line (first input row, row count) + 16-bit slot table; once per
+ *                                                  voxel set, shared by every SubM convolution over it; status (optional
+ *                                                  device int32): bit 0 set if a range overflowed (unsorted rows)
+ *   bevamd_spconv_conv_forward_slab                the convolution; `image` as for the tiled entry point */
+int bevamd_spconv_slab_block_rows(int cin, int variant);
+int bevamd_spconv_slab_variants(int cin, int* codes, int max_n);
+int bevamd_spconv_slab_grid_ok(const int* shape, int block_rows);
+size_t bevamd_spconv_slab_hdr_bytes(int m_cap, int block_rows);
+size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows);
+int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const int* m_dev, int block_rows, void* hdr,
+                             void* slots, int* status, void* stream);
+int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_stride, int num_in, const void* image,
+                                    const void* hdr, const void* slots, int block_rows, int num_out,
+                                    const int* num_out_dev, int cin, int cout, void* out, int out_stride,
+                                    const void* bias, const float* bn_scale, const float* bn_shift,
+                                    const void* residual, int residual_stride, int relu, int variant, void* stream);
+
 /* Filter-gradient half of sparse_conv_ext.indice_conv_backward_{fp32,half} (spconv_ops.h:363-456):
  *   filter_grad[k] = sum over pairs of features[i]^T @ out_grad[o]   (fp32 accumulation).
  * The input-gradient half is bevamd_spconv_conv_forward on (out_grad, prepared W^T, nbr_t). */

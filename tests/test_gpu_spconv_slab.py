@@ -1,0 +1,189 @@
+"""GPU parity of the slab (staged-rows) submanifold convolution (csrc/spconv_slab.h, through the C ABI): against the CPU
+oracle (oracle.indice_conv, float64 accumulate) and against the gather kernel it replaces (bevamd_spconv_conv_forward_tiled).
+
+Bars: |err| <= tol * (1 + max|ref|), tol = 2e-3 (fp16) / 1.6e-2 (bf16); BIT-IDENTICAL to the gather kernel for the variants
+that stage whole rows (same summation order), within 2 ulps (of the largest magnitude) of it for the ones that run the channels in 32- / 64-wide passes
+(pass-major order: Cin = 128 always, Cin = 64 with 32-channel rows); every built variant; ranges longer than the
+staging buffer (pieces), empty kernel lines, ragged last block, device-side row count, fused epilogue; block metadata
+(hdr / slots, per kernel plane) equal to a numpy restatement."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from bevfusion_amd import spconv
+from bevfusion_amd.spconv import ops as sops
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+
+
+def sorted_indices(rng, B, shape, n, dense_planes=()):
+    """Active voxels of B samples in ascending linear index; `dense_planes`: x-planes filled completely (long ranges)."""
+    vol = int(np.prod(shape))
+    out = []
+    for b in range(B):
+        lin = set(rng.choice(vol, size=min(n, vol), replace=False).tolist())
+        for x in dense_planes:
+            lin.update(range(x * shape[1] * shape[2], (x + 1) * shape[1] * shape[2]))
+        lin = np.array(sorted(lin))
+        out.append(np.concatenate([np.full((len(lin), 1), b), np.stack(np.unravel_index(lin, shape), 1)], 1))
+    return np.concatenate(out).astype(np.int32)
+
+
+def make_case(rng, dev, c, dtype, B=2, shape=(24, 20, 9), n=1500, dense_planes=()):
+    indices = sorted_indices(rng, B, shape, n, dense_planes)
+    oi, opairs, onum, _ = oracle.get_indice_pairs(indices, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
+    assert np.array_equal(oi, indices)
+    w = (rng.standard_normal((3, 3, 3, c, c)) / np.sqrt(c * 27 / 4)).astype(np.float32)
+    f = torch.from_numpy(rng.standard_normal((indices.shape[0], c)).astype(np.float32)).to(dtype)
+    w = torch.from_numpy(w).to(dtype)
+    ref = oracle.indice_conv(f.float().numpy(), w.float().numpy(), opairs, onum, oi.shape[0])
+    rb = spconv.build_rulebook(torch.from_numpy(indices).to(dev), B, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, True)
+    return f.to(dev), w.to(dev), rb, ref
+
+
+def run_slab(f, w, rb, variant=0, m_dev=None, **kw):
+    c = w.shape[-1]
+    meta = sops.slab_build(rb.nbr, rb.num_out, m_dev, sops.slab_block_rows(c, variant))
+    out = sops.sparse_conv_slab(f, sops.make_filter_image(w), meta, rb.num_out, c, c, variant=variant, num_out_dev=m_dev, **kw)
+    assert int(meta.status.item()) == 0
+    return out, meta
+
+
+def run_gather(f, w, rb, **kw):
+    c = w.shape[-1]
+    return sops.sparse_conv_tiled(f, sops.make_filter_image(w), rb.nbr, rb.num_out, 27, c, c, **kw)
+
+
+def same_order(c, variant):
+    """Variant code = KC*10000 + ...: rows staged whole (KC == Cin) keep the gather kernels' summation order."""
+    kc = (variant or sops.slab_variants(c)[0]) // 10000
+    return kc == c
+
+
+def assert_same(out, base, c, variant):
+    if same_order(c, variant):
+        assert torch.equal(out, base), f"variant {variant} is not bit-identical to the gather kernel"
+    else:
+        assert ulp_close(out, base, 2), f"variant {variant}"
+
+
+def assert_close(out, ref, dtype):
+    err = np.max(np.abs(out.float().cpu().numpy().astype(np.float64) - ref))
+    assert err <= TOL[dtype] * (1.0 + np.max(np.abs(ref))), err
+
+
+def ulp_close(a, b, ulps):
+    """Within `ulps` units in the last place of the LARGEST magnitude (pass-major summation moves the fp32 sum by a few of
+    its own ulps before the single 16-bit rounding; near zero that is many ulps of the small value)."""
+    scale = float(torch.maximum(a.float().abs().max(), b.float().abs().max()))
+    eps = 2.0 ** -10 if a.dtype == torch.float16 else 2.0 ** -7
+    return float((a.float() - b.float()).abs().max()) <= ulps * eps * max(scale, 1.0)
+
+
+def test_block_metadata_matches_numpy(dev):
+    rng = np.random.default_rng(5)
+    f, w, rb, _ = make_case(rng, dev, 32, torch.float16, n=900)
+    nbr = rb.nbr.cpu().numpy()[:, : rb.num_out]
+    for bm in (128, 256):
+        meta = sops.slab_build(rb.nbr, rb.num_out, None, bm)
+        nblk = (rb.num_out + bm - 1) // bm
+        hdr = meta.hdr.cpu().numpy().view(np.int32).reshape(-1)[: nblk * 6].reshape(nblk, 3, 2)
+        slots = meta.slots.cpu().numpy().view(np.uint16)[: nblk * 27 * bm].reshape(nblk, 27, bm)
+        for b in range(nblk):
+            rows = slice(b * bm, min((b + 1) * bm, rb.num_out))
+            for j in range(3):                                     # kernel plane kx = j: its nine (ky, kz) taps share one range
+                v = nbr[9 * j: 9 * j + 9, rows]
+                if (v >= 0).any():
+                    lo, hi = v[v >= 0].min(), v[v >= 0].max()
+                    assert tuple(hdr[b, j]) == (lo, hi - lo + 1)
+                else:
+                    lo = 0
+                    assert hdr[b, j, 1] == 0
+                want = np.where(v >= 0, v - lo, 0xFFFF).astype(np.uint16)
+                got = slots[b, 9 * j: 9 * j + 9, : want.shape[1]]
+                assert np.array_equal(got, want)
+                assert (slots[b, 9 * j: 9 * j + 9, want.shape[1]:] == 0xFFFF).all()      # rows past the live count
+        # rows in linear-index order: a plane's range is about one block long
+        assert np.median(hdr[:, :, 1][hdr[:, :, 1] > 0]) <= 1.5 * bm
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("c", [32, 64, 128])
+def test_every_variant_vs_oracle_and_gather(dev, c, dtype):
+    rng = np.random.default_rng(c)
+    f, w, rb, ref = make_case(rng, dev, c, dtype, n=1700)      # 3400 rows: ragged last block for 128- and 256-row blocks
+    base = run_gather(f, w, rb)
+    assert_close(base, ref, dtype)
+    variants = sops.slab_variants(c)
+    assert variants and sops.slab_block_rows(c, 0) == sops.slab_block_rows(c, variants[0])
+    for v in variants:
+        out, _ = run_slab(f, w, rb, variant=v)
+        assert_close(out, ref, dtype)
+        assert_same(out, base, c, v)
+        again, _ = run_slab(f, w, rb, variant=v)
+        assert torch.equal(out, again)                         # bit-reproducible
+
+
+@pytest.mark.parametrize("c", [32, 64, 128])
+def test_long_ranges_take_the_piece_loop(dev, c):
+    """Two completely filled x-planes next to sparse ones: the kernel planes that look into them span up to Y*Z = 360 extra rows
+    (> the 192 / 384-row staging buffers) and are processed in pieces."""
+    rng = np.random.default_rng(100 + c)
+    f, w, rb, ref = make_case(rng, dev, c, torch.float16, B=1, shape=(12, 40, 9), n=400, dense_planes=(4, 5))
+    base = run_gather(f, w, rb)
+    for v in sops.slab_variants(c):
+        out, meta = run_slab(f, w, rb, variant=v)
+        bm = meta.block_rows
+        nblk = (rb.num_out + bm - 1) // bm
+        cnt = meta.hdr.cpu().numpy().view(np.int32).reshape(-1)[: nblk * 6].reshape(nblk, 3, 2)[:, :, 1]
+        assert cnt.max() > 1.5 * bm, "the case must exercise multi-piece ranges"
+        assert_close(out, ref, torch.float16)
+        assert_same(out, base, c, v)
+
+
+def test_isolated_voxels_empty_lines_and_tiny_sets(dev):
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 130):                                         # far apart: only the centre plane has rows
+        shape = (40, 40, 20)
+        lin = np.sort(rng.choice(np.arange(0, 40 * 40 * 20, 97), size=n, replace=False))
+        ind = np.concatenate([np.zeros((n, 1), np.int64), np.stack(np.unravel_index(lin, shape), 1)], 1).astype(np.int32)
+        oi, opairs, onum, _ = oracle.get_indice_pairs(ind, 1, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
+        w = torch.from_numpy((rng.standard_normal((3, 3, 3, 64, 64)) * 0.05).astype(np.float32)).half()
+        f = torch.from_numpy(rng.standard_normal((n, 64)).astype(np.float32)).half()
+        ref = oracle.indice_conv(f.float().numpy(), w.float().numpy(), opairs, onum, n)
+        rb = spconv.build_rulebook(torch.from_numpy(ind).to(dev), 1, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, True)
+        out, _ = run_slab(f.to(dev), w.to(dev), rb)
+        assert_close(out, ref, torch.float16)
+
+
+@pytest.mark.parametrize("c", [32, 128])
+def test_epilogue_and_device_row_count(dev, c):
+    rng = np.random.default_rng(11 + c)
+    dtype = torch.float16
+    f, w, rb, ref = make_case(rng, dev, c, dtype, n=1000)
+    m = rb.num_out
+    bias = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).to(dev).to(dtype)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(dev)
+    shift = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).to(dev)
+    res = torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32)).to(dev).to(dtype)
+    kw = dict(bias=bias, bn_scale=scale, bn_shift=shift, residual=res, relu=True)
+    base = run_gather(f, w, rb, **kw)
+    out, _ = run_slab(f, w, rb, **kw)
+    assert_same(out, base, c, 0)
+    y = (torch.from_numpy(ref).to(dev).to(dtype).float() + bias.float()).to(dtype).float()
+    y = (y * scale + shift).to(dtype).float()
+    y = torch.relu((y + res.float()).to(dtype).float())
+    assert float((out.float() - y).abs().max()) <= 4 * TOL[dtype] * (1 + float(y.abs().max()))
+    # live row count on the device, launch bounded by the capacity: rows past it stay untouched
+    live = m - 77
+    m_dev = torch.tensor([live], dtype=torch.int32, device=dev)
+    sentinel = torch.full((m, c), 7.0, dtype=dtype, device=dev)
+    rb_live_nbr = rb.nbr.clone()
+    rb_live_nbr[rb_live_nbr >= live] = -1                         # a table built for the live rows only
+    meta = sops.slab_build(rb_live_nbr, m, m_dev, sops.slab_block_rows(c, 0))
+    got = sops.sparse_conv_slab(f, sops.make_filter_image(w), meta, m, c, c, num_out_dev=m_dev, out=sentinel.clone())
+    want = sops.sparse_conv_tiled(f, sops.make_filter_image(w), rb_live_nbr, m, 27, c, c, num_out_dev=m_dev, out=sentinel.clone())
+    assert torch.equal(got[live:], sentinel[live:])
+    assert_same(got[:live], want[:live], c, 0)

@@ -46,7 +46,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1, help="frames in the batch (row counts scale with it)")
     ap.add_argument("--small", action="store_true", help="only the layers with < 32 input channels (and no round-0 kernel)")
     ap.add_argument("--quick", action="store_true", help="skip the round-0 kernel and the layers with < 32 input channels")
-    ap.add_argument("--ablate", action="store_true", help="time the 64->64 / 128->128 SubM layers with parts of the kernel compiled out")
+    ap.add_argument("--slab", action="store_true", help="SubM layers of the sorted levels: every slab variant next to the shipped gather variant")
+    ap.add_argument("--ablate", action="store_true", help="time the 64->64 / 128->128 SubM layers with parts of the kernel compiled out (needs `python -m bevfusion_amd.build --profiling`)")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     dev = torch.device("cuda", 0)
@@ -81,6 +82,29 @@ def main():
         gflop = 2.0 * pairs * cin * cout / 1e9
         print(f"{name:38s} rows_in={n_in:7d} rows_out={rb.num_out:7d} pairs={pairs:8d} ({gflop:6.2f} GFLOP)")
         img_bytes = img.numel() * 2
+        if args.slab:
+            if not (name.startswith("subm") and cin == cout and cin >= 32):
+                continue
+            from bevfusion_amd.spconv.fused import _variant_for
+            gv = _variant_for(NB, K, cin, cout)
+            med, _ = timeit(lambda: sops.sparse_conv_tiled(f, img, rb.nbr, rb.num_out, K, cin, cout, variant=gv))
+            base = sops.sparse_conv_tiled(f, img, rb.nbr, rb.num_out, K, cin, cout, variant=gv)
+            print(f"    gather variant {gv:5d}: {med:8.1f} us  {gflop / med * 1e3:8.1f} TFLOP/s eff")
+            for bm in (128, 256):
+                t, _ = timeit(lambda: sops.slab_build(rb.nbr, rb.num_out, None, bm))
+                print(f"    slab_build (BM={bm}): {t:8.1f} us (once per level)")
+            for v in sops.slab_variants(cin):
+                meta = sops.slab_build(rb.nbr, rb.num_out, None, sops.slab_block_rows(cin, v))
+                try:
+                    med, _ = timeit(lambda: sops.sparse_conv_slab(f, img, meta, rb.num_out, cin, cout, variant=v))
+                except RuntimeError as e:
+                    print(f"    slab variant {v}: {e}")
+                    continue
+                out = sops.sparse_conv_slab(f, img, meta, rb.num_out, cin, cout, variant=v)
+                same = bool(torch.equal(out, base))
+                md = float((out.float() - base.float()).abs().max())
+                print(f"    slab variant {v:5d}: {med:8.1f} us  {gflop / med * 1e3:8.1f} TFLOP/s eff   identical={same} max|diff|={md:.3g}")
+            continue
         if args.ablate:
             if (cin, cout) not in ((64, 64), (128, 128)) or K != 27:
                 continue
