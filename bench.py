@@ -9,10 +9,11 @@
 stub on the host and the backend for gloo: the whole N>1 control flow (spawn, rendezvous, frame sharding, barriers,
 max-over-ranks timing, the JSON line) runs in a container without GPUs (tests/test_bench_launch.py).
 
-A "step" is ONE pass of the hot path over ONE synthetic frame per GPU at the C+L flagship sizes
-(SURVEY.md §8d), inputs already resident in HBM:
-    camera branch : bev_pool interval reduction of the [6*118*32*88, 80] frustum feature volume into the
-                    360x360 BEV grid (rank/sort/CSR precompute cached: calibration is static at inference)
+A "step" is ONE pass of the hot path over one batch of synthetic frames per GPU (--batch, default 8) at the C+L flagship
+sizes, inputs already resident in HBM:
+    camera branch : LiDAR -> per-camera depth images (depth raster), fused depth (x) context -> BEV pooling, and the API-level
+                    bev_pool interval reduction of the [6*118*32*88, 80] frustum feature volume into the 360x360 BEV grid
+                    (geometry + rank/sort/CSR plan cached: calibration is static at inference; uncached cost reported)
     LiDAR branch  : hard voxelization + mean of ~310k points (0.075 m voxels, 160k cap)
                     -> SparseEncoder (VoxelNet: 17 SubM + 4 strided sparse convs) -> [1, 256, 180, 180]
 One process per GPU; for N>1 the driver launches this file under torch.distributed.run and ranks meet only in
@@ -44,13 +45,17 @@ def parse():
     ap.add_argument("--feat-dtype", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--spconv-dtype", choices=["fp16", "fp32", "bf16"], default="fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=None,
                     help="frames per step per GPU (default 8: BASELINE.json's C+L inference config is quoted at batch 8 on one GPU; "
                          "--batch 1 = single-frame latency)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed number of frames per step for the WHOLE job, split over the ranks with sharding.frames_for_rank "
                          "(strong scaling); default 0 = --batch frames on every GPU (weak scaling)")
     ap.add_argument("--no-graph", action="store_true", help="launch the LiDAR branch kernel by kernel instead of replaying a HIP graph")
+    ap.add_argument("--mode", choices=["infer", "train-step"], default="infer",
+                    help="infer (default): the inference hot path of BASELINE configs[3]; train-step: forward + backward + optimizer "
+                         "step of the same path in fp32 (BASELINE configs[4]: 4 frames per GPU unless --batch / --global-batch says "
+                         "otherwise, gradients all-reduced over RCCL when --gpus > 1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: a host stub stands in for the hot path and gloo for RCCL, everything else (launch, sharding, "
                          "barriers, timing, JSON) is the real code path")
@@ -220,8 +225,113 @@ def cpu_baseline(inp, pts, cfg, B, D, H, W):
                 sample="one frame, stage by stage: " + "; ".join(parts), seconds_per_frame=total)
 
 
+def train_step(args, rank, world, frame_ids, dev):
+    """`--mode train-step`: one optimisation step of the hot path's trainable part per timed step — BASELINE configs[4].
+    camera: bev_pool forward + backward on the materialised [N', 80] volume (the API-level op; backward = 622.5 MB per frame,
+    SURVEY.md §8d) and the fused depth (x) context pooling forward + backward (what DepthLSSTransform runs);
+    LiDAR: hard voxelization (no gradient) + SparseEncoder forward / backward in fp32 training mode (module path, autograd:
+    dgrad through the forward kernel on the transposed table, MFMA filter gradient), gradient all-reduce by
+    DistributedDataParallel over RCCL when world > 1, clip_grad_norm 35 + AdamW(lr 2e-4) step (configs/default.yaml)."""
+    import torch.distributed as dist
+
+    from bevfusion_amd import synth
+    from bevfusion_amd.bev_pool import BevPoolPlan
+    from bevfusion_amd.sharding import barrier, max_over_ranks, sum_over_ranks
+    from bevfusion_amd.voxel import voxelize_batch
+
+    cfg = synth.CL_CONFIG
+    B = len(frame_ids)
+    inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank, with_feats=False)
+    H, W, D = (int(v) for v in inp["nx"])
+    C = inp["channels"]
+    geom = torch.from_numpy(inp["geom"]).to(dev)
+    plan = BevPoolPlan.from_geometry(geom, B, inp["origin"], inp["dx"], inp["nx"], want_intervals=True)
+    n_kept = plan.n_kept()
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+    feats = torch.randn((geom.shape[0], C), generator=gen, device=dev).requires_grad_(True)
+    fh, fw = cfg["feature_size"]
+    n_cam = cfg["num_cameras"]
+    dbins = geom.shape[0] // (B * n_cam * fh * fw)
+    depth = torch.softmax(torch.randn((B * n_cam, dbins, fh, fw), generator=gen, device=dev), 1).requires_grad_(True)
+    ctx = torch.randn((B * n_cam * fh * fw, C), generator=gen, device=dev).requires_grad_(True)
+    gout = torch.randn((B, D, H, W, C), generator=gen, device=dev)
+    pts = [torch.from_numpy(synth.lidar_points(seed=f)).to(dev) for f in frame_ids]
+    enc = make_encoder(cfg, dev, torch.float32).train()
+    model = enc
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(enc, device_ids=[dev.index])
+    opt = torch.optim.AdamW(enc.parameters(), lr=2e-4, weight_decay=0.01)
+    names = ["bev_pool_fwd", "bev_pool_bwd", "fused_pool_fwd", "fused_pool_bwd", "voxelize", "encoder_fwd", "encoder_bwd+allreduce",
+             "clip+adamw"]
+
+    def step(ev=None):
+        mark = (lambda i: ev[i].record()) if ev else (lambda i: None)
+        mark(0)
+        out = plan.forward(feats)
+        mark(1)
+        out.backward(gout)
+        mark(2)
+        outf = plan.fused(depth, ctx, dbins, fh, fw)
+        mark(3)
+        outf.backward(gout)
+        mark(4)
+        vf, vc, _ = voxelize_batch(pts, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][0])
+        mark(5)
+        y = model(vf, vc, B)
+        mark(6)
+        y.square().mean().backward()
+        mark(7)
+        torch.nn.utils.clip_grad_norm_(enc.parameters(), 35.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        feats.grad = depth.grad = ctx.grad = None
+        mark(8)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(evs[i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local, device=dev)
+    frames_per_step = int(sum_over_ranks(B, device=dev))
+    stage = {n: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i, n in enumerate(names)}
+    if rank == 0:
+        bwd_bytes = B * D * H * W * C * 4 + n_kept * C * 4          # cell gradients read + row gradients written (SURVEY.md §8d)
+        achieved = bwd_bytes / (stage["bev_pool_bwd"] * 1e-3) / 1e9
+        nparam = sum(p.numel() for p in enc.parameters())
+        print(json.dumps({
+            "metric": "train-step frames/sec of the BEVFusion C+L hot path (fwd + bwd + optimizer step of bev_pool / fused pooling / "
+                      "voxelize / SparseEncoder), fp32",
+            "value": frames_per_step * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"training step of the hot path, {B} frame(s)/GPU (BASELINE configs[4]: 4 per GPU): bev_pool "
+                                   f"N'={geom.shape[0]} ({n_kept} kept) x C={C} fwd+bwd, fused depth x context pooling fwd+bwd, hard "
+                                   f"voxelize {sum(p.shape[0] for p in pts)} points (cap {cfg['max_voxels'][0]}), SparseEncoder fp32 "
+                                   f"train mode ({nparam} parameters) fwd+bwd, clip_grad_norm 35, AdamW",
+                       "frames_per_step_per_gpu": B, "frames_per_step": frames_per_step, "stage_ms": stage,
+                       "gradient_allreduce": (f"DistributedDataParallel over torch.distributed nccl (= RCCL), world {world}, "
+                                              f"{nparam * 4 / 1e6:.1f} MB per step") if world > 1 else "single rank: none"},
+            "roofline": {"kernel": "bev_pool_bwd_rows_vec_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bwd_bytes, "kernel_ms": stage["bev_pool_bwd"],
+                         "note": "stage time by HIP events around the autograd call (one kernel + the grad buffer allocation)"},
+            "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.batch is None:
+        args.batch = 4 if args.mode == "train-step" else 8
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_under_launcher(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -258,6 +368,8 @@ def main():
         raise SystemExit(f"rank {rank}: no frames to process (--global-batch {args.global_batch} < {world} ranks)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if args.mode == "train-step":
+        return train_step(args, rank, world, frame_ids, dev)
 
     from bevfusion_amd import synth
     from bevfusion_amd.bev_pool import BevPoolPlan
@@ -345,39 +457,79 @@ def main():
         with torch.cuda.graph(graph):
             state["lidar_bev"], state["n_voxels_dev"], _ = lidar_branch()
 
-    # side figure (NOT part of `value`): the fused depth (x) context -> BEV op on the same plan, i.e. the
-    # camera branch without the 638 MB feature volume.  Different byte denominator than bev_pool: reported on its own.
+    # ---- camera branch as the product runs it: the step starts from what the dense network hands over ----
+    # depth distribution [B*6, 118, 32, 88] (softmax output of depthnet), context [B*6*32*88, 80] (channels-last), the LiDAR
+    # points and the calibration matrices:
+    #   depth raster  (base.py:283-329, a3)  points -> [B, 6, 1, 256, 704] scalar depth images (input of dtransform, which is
+    #                                        dense torch.nn and out of scope; its output stands in as the random `depth_prob`)
+    #   fused pooling (depth_lss.py:92-97 + base.py:141-176, a4-a8)  out[cell] = sum depth * ctx, the [N', 80] volume never built
+    # The geometry / pooling plan is static per calibration at inference (cached; its uncached cost is reported next to it).
+    # The materialised-volume bev_pool kernel stays a stage of the step as well: it is the API-level op BASELINE.json's
+    # "bev_pool HBM GB/s" is defined on — the camera reduction is therefore paid twice in `value`.
+    from bevfusion_amd.vtransforms import DepthLSSTransform
+
     fh, fw = cfg["feature_size"]
-    dbins = geom.shape[0] // (B * cfg["num_cameras"] * fh * fw)  # noqa
-    g = torch.Generator(device="cpu").manual_seed(7)
-    depth_prob = torch.softmax(torch.randn((B * cfg["num_cameras"], dbins, fh, fw), generator=g), 1).to(dev)
-    ctx_cl = torch.randn((B * cfg["num_cameras"] * fh * fw, C), generator=g).to(dev)
+    n_cam = cfg["num_cameras"]
+    dbins = geom.shape[0] // (B * n_cam * fh * fw)
+    vt = DepthLSSTransform(256, C, cfg["image_size"], cfg["feature_size"], cfg["xbound"], cfg["ybound"], cfg["zbound"],
+                           cfg["dbound"], downsample=2).to(dev).eval()
+    rig = synth.camera_rig(n_cam)
+    mats = {}
+    for name, (rot, trans) in dict(c2l=(rig["camera2lidar_rots"], rig["camera2lidar_trans"]),
+                                   K=(rig["intrins"], np.zeros((n_cam, 3), np.float32)),
+                                   ia=(rig["post_rots"], rig["post_trans"])).items():
+        m4 = np.tile(np.eye(4, dtype=np.float32), (B, n_cam, 1, 1))
+        m4[:, :, :3, :3], m4[:, :, :3, 3] = rot, trans
+        mats[name] = m4
+    l2i = (mats["K"].astype(np.float64) @ np.linalg.inv(mats["c2l"].astype(np.float64))).astype(np.float32)
+    t_l2i, t_ia = torch.from_numpy(l2i).to(dev), torch.from_numpy(mats["ia"]).to(dev)
+    t_la = torch.eye(4, device=dev).repeat(B, 1, 1)
+    t_c2l, t_K = torch.from_numpy(mats["c2l"]).to(dev), torch.from_numpy(mats["K"]).to(dev)
+    img_stub = torch.zeros(B, n_cam, 1, 1, 1, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    depth_prob = torch.softmax(torch.randn((B * n_cam, dbins, fh, fw), generator=g, device=dev), 1)
+    ctx_cl = torch.randn((B * n_cam * fh * fw, C), generator=g, device=dev)
     fused_out = torch.empty_like(bev)
-    for _ in range(3):
-        plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
-    fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    fe[0].record()
-    for _ in range(10):
-        plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
-    fe[1].record()
-    fe[1].synchronize()
-    fused_ms = fe[0].elapsed_time(fe[1]) / 10
     fused_bytes = n_kept * 4 + ctx_cl.numel() * 4 + B * D * H * W * C * 4
 
-    NSTAGE = 2
+    def camera_geometry_uncached():
+        """what a NEW calibration costs: device-side 3x3 inverses + frustum geometry + rank/sort/CSR plan (no host sync)"""
+        with torch.no_grad():
+            gm = vt.get_geometry(t_c2l[..., :3, :3], t_c2l[..., :3, 3], t_K[..., :3, :3], t_ia[..., :3, :3], t_ia[..., :3, 3],
+                                 extra_rots=t_la[:, :3, :3], extra_trans=t_la[:, :3, 3])
+            return vt.make_plan(gm, B)
+
+    for _ in range(2):
+        camera_geometry_uncached()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        camera_geometry_uncached()
+    torch.cuda.synchronize()
+    geometry_plan_ms = (time.perf_counter() - t0) / 5 * 1e3
+
+    STAGES = ["depth_raster", "fused_depth_context_pool", "bev_pool_forward_cells", "voxelize_mean + sparse_encoder"]
+    NSTAGE = len(STAGES)
 
     def step(ev=None):
         if ev:
             ev[0].record()
-        plan.launch_forward(feats, bev)                                   # camera: bev_pool (one kernel)
+        with torch.no_grad():
+            state["depth_img"] = vt.depth_raster(img_stub, pts_list, t_l2i, t_ia, t_la)   # camera: LiDAR -> depth images
         if ev:
             ev[1].record()
+        plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)      # camera: depth (x) context -> BEV
+        if ev:
+            ev[2].record()
+        plan.launch_forward(feats, bev)                                   # the API-level bev_pool op (one kernel; roofline)
+        if ev:
+            ev[3].record()
         if graph is not None:
             graph.replay()                                                # LiDAR: voxelize + sparse encoder
         else:
             state["lidar_bev"], state["n_voxels_dev"], _ = lidar_branch()
         if ev:
-            ev[2].record()
+            ev[4].record()
 
     for _ in range(args.warmup):
         step()
@@ -394,7 +546,8 @@ def main():
     stage_ms = [float(np.mean([e[s].elapsed_time(e[s + 1]) for e in evs])) for s in range(NSTAGE)]
     state["n_voxels"] = int(state["n_voxels_dev"].reshape(-1)[0])
     assert tuple(state["lidar_bev"].shape) == (B, 256, 180, 180)
-    kern_ms = stage_ms[0]  # the bev_pool stage is exactly one kernel launch
+    kern_ms = stage_ms[2]  # the bev_pool stage is exactly one kernel launch
+    fused_ms = stage_ms[1]
 
     elapsed_local = elapsed
     elapsed = max_over_ranks(elapsed, device=dev)  # slowest rank defines the step time
@@ -449,14 +602,23 @@ def main():
                 "parallelism": f"frames sharded over {world} rank(s), one process per GPU, no data-path collective"
                                + (f"; torch.distributed backend nccl (= RCCL) world size {world}" if world > 1 else ""),
                 "per_rank": per_rank,
-                "stages": ["bev_pool_forward_cells", "voxelize_mean + sparse_encoder"],
-                "stage_ms": dict(zip(["bev_pool", "lidar_branch"], stage_ms)),
+                "stages": STAGES,
+                "stage_ms": dict(zip(["depth_raster", "fused_depth_context_pool", "bev_pool", "lidar_branch"], stage_ms)),
+                "camera_branch": {
+                    "starts_from": "depth distribution [B*6,118,32,88] + context [B*6*32*88,80] + LiDAR points + calibration",
+                    "depth_raster_ms": stage_ms[0], "fused_pool_ms": stage_ms[1],
+                    "geometry_and_plan_ms_uncached": geometry_plan_ms,
+                    "note": "geometry + pooling plan are cached per calibration at inference and are NOT in the step; the "
+                            "materialised-volume bev_pool stage is the API-level op of the HBM GB/s metric and is in the step "
+                            "too, so the camera reduction is counted twice in `value`"},
                 "lidar_branch_eager_ms": {"voxelize": eager_vox_ms, "sparse_encoder": eager_enc_ms},
                 "hip_graph": graph is not None,
                 "fused_depth_context_bev": {"ms": fused_ms, "algorithmic_bytes": fused_bytes,
-                                            "note": "side figure, not in `value`: out[cell] = sum depth*ctx straight from depth "
+                                            "gbs_on_own_bytes": fused_bytes / (fused_ms * 1e-3) / 1e9,
+                                            "note": "stage of the step: out[cell] = sum depth*ctx straight from depth "
                                                     "[6,118,32,88] + context [6*32*88,80] (the [N',80] volume never exists); "
-                                                    "L2-bound, own byte denominator (SURVEY.md 8d/8f)"},
+                                                    "L2-bound, own byte denominator (SURVEY.md 8d/8f), not comparable with the "
+                                                    "bev_pool roofline figure"},
                 "bev_pool_precompute_ms_uncached": precompute_ms,
                 "bev_pool_precompute_first_call_ms": t_first * 1e3,
             },
@@ -468,6 +630,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": "profiles/bev_pool_traffic.json (FETCH_SIZE x2 + WRITE_SIZE from two separate rocprofv3 --pmc "
+                                  "passes of tools/pmc_bev_pool.sh, per frame x frames per launch) — not measured inside this run",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kern_ms,
             },

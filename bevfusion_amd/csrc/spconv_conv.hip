@@ -205,68 +205,99 @@ __global__ __launch_bounds__(256) void spconv_prepare_filters_kernel(const typen
 }
 
 // ---------------------------------------------------------------------------
-// filter gradient: gW[k][ci][co] = sum over pairs (i,o) of offset k of feat[i][ci] * gout[o][co]
-// One workgroup per (offset, slab of output rows); threads own (ci, co) entries, rows staged in LDS;
-// partial sums land with fp32 atomics (order of arrival varies: the only non-bit-reproducible kernel
-// of the op, as is the reference's GEMM-with-split-K on GPUs).
+// filter gradient (spconv_ops.h:363-456, the `filtersGrad[i] = buf^T * gradbuf` GEMM of every offset):
+//   gW[k][ci][co] = sum over output rows o with i = nbr[k][o] >= 0 of feat[i][ci] * gout[o][co]
+// — the rulebook-gathered GEMM of the backward pass, on MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products and sums for every
+// feature dtype; 16-bit inputs are widened while they are staged), deterministic, without atomics:
+//   pass 1  grid (row slab s, kernel offset k, 64-wide output-channel group z): a workgroup stages 32 rows at a time —
+//           feat[nbr[k][o]] (zeros where the offset has no neighbour) and gout[o] — into LDS as fp32 and accumulates
+//           X^T * gY for its slab: wave w owns output-channel tile w of the group and every input-channel tile
+//           (A = X^T: lane (ci, r) <- fa[r][ci]; B = gY: lane (r, co) <- fb[r][co]; one ds_read_b32 each, row pitch padded by
+//           16 floats so that the two 32-lane halves of a read hit disjoint banks); the slab's partial goes to
+//           part[s][k][ci][co] (fp32) — every entry written exactly once, no memset;
+//   pass 2  gW[k][ci][co] = sum_s part[s][k][ci][co], s ascending (fixed order -> bit-reproducible), cast to the filter dtype.
+// Any cin, cout <= 128 (padded to multiples of 16 inside the kernel).
 // ---------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void spconv_wgrad_kernel(const typename Elem<DT>::T* __restrict__ feat,
-                                                           const typename Elem<DT>::T* __restrict__ gout,
-                                                           const int* __restrict__ nbr, int nbr_stride, int m, int K,
-                                                           int cin, int cout, int rows_per_block,
-                                                           float* __restrict__ gw) {
-  extern __shared__ float lds[];  // [ROWS][cin] then [ROWS][cout]
-  constexpr int ROWS = 32;
-  float* fa = lds;
-  float* fb = lds + ROWS * cin;
-  const int k = blockIdx.y;
-  const int rbeg = blockIdx.x * rows_per_block;
-  const int rend = rbeg + rows_per_block < m ? rbeg + rows_per_block : m;
-  const int nent = cin * cout;
-  constexpr int MAXE = 64;  // entries per thread: supports cin*cout <= 16384
-  float acc[MAXE];
+constexpr int WG_ROWS = 32;      // rows staged per iteration
+constexpr int WG_COG = 64;       // output channels per workgroup (4 waves x one 16-wide tile)
+constexpr int WG_MAX_SLABS = 32;
+
+template <int DT, int CIT>   // CIT = input-channel tiles (cin_pad / 16): 1, 2, 4 or 8
+__global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const typename Elem<DT>::T* __restrict__ feat,
+                                                                const typename Elem<DT>::T* __restrict__ gout,
+                                                                const int* __restrict__ nbr, int nbr_stride, int m, int K,
+                                                                int cin, int cout, int cout_pad, int rows_per_slab,
+                                                                float* __restrict__ part) {
+  constexpr int CINP = CIT * 16;
+  constexpr int LDA = CINP + 16, LDB = WG_COG + 16;
+  __shared__ float fa[WG_ROWS * LDA];
+  __shared__ float fb[WG_ROWS * LDB];
+  __shared__ int rowmap[WG_ROWS];
+  const int s = blockIdx.x, k = blockIdx.y, co0 = blockIdx.z * WG_COG;
+  const int rbeg = s * rows_per_slab;
+  const int rend = rbeg + rows_per_slab < m ? rbeg + rows_per_slab : m;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  f32x4 acc[CIT];
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) acc[e] = 0.f;
-  for (int r0 = rbeg; r0 < rend; r0 += ROWS) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < ROWS * cin; t += 256) {
-      int rr = t / cin, c = t - rr * cin;
-      int o = r0 + rr;
-      int i = o < rend ? nbr[(size_t)k * nbr_stride + o] : -1;
-      fa[t] = i >= 0 ? Elem<DT>::to_f32(feat[(size_t)i * cin + c]) : 0.f;
-    }
-    for (int t = threadIdx.x; t < ROWS * cout; t += 256) {
-      int rr = t / cout, c = t - rr * cout;
-      int o = r0 + rr;
-      int i = o < rend ? nbr[(size_t)k * nbr_stride + o] : -1;
-      fb[t] = i >= 0 ? Elem<DT>::to_f32(gout[(size_t)o * cout + c]) : 0.f;
+  for (int t = 0; t < CIT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool wave_live = co0 + w * 16 < cout_pad;   // a narrow layer leaves the upper waves of the group without a tile
+  for (int r0 = rbeg; r0 < rend; r0 += WG_ROWS) {
+    __syncthreads();   // previous chunk fully consumed
+    if (threadIdx.x < WG_ROWS) {
+      const int o = r0 + (int)threadIdx.x;
+      rowmap[threadIdx.x] = o < rend ? nbr[(size_t)k * nbr_stride + o] : -1;
     }
     __syncthreads();
+    for (int t = threadIdx.x; t < WG_ROWS * CINP; t += 256) {
+      const int rr = t / CINP, c = t - rr * CINP;
+      const int i = rowmap[rr];
+      fa[rr * LDA + c] = (i >= 0 && c < cin) ? Elem<DT>::to_f32(feat[(size_t)i * cin + c]) : 0.f;
+    }
+    for (int t = threadIdx.x; t < WG_ROWS * WG_COG; t += 256) {
+      const int rr = t / WG_COG, c = t - rr * WG_COG;
+      const int o = r0 + rr, co = co0 + c;
+      fb[rr * LDB + c] = (rowmap[rr] >= 0 && co < cout) ? Elem<DT>::to_f32(gout[(size_t)o * cout + co]) : 0.f;
+    }
+    __syncthreads();
+    if (wave_live) {
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      int idx = threadIdx.x + e * 256;
-      if (idx < nent) {
-        int ci = idx / cout, co = idx - ci * cout;
-        float s = 0.f;
-#pragma unroll 8
-        for (int rr = 0; rr < ROWS; ++rr) s += fa[rr * cin + ci] * fb[rr * cout + co];
-        acc[e] += s;
+      for (int q = 0; q < WG_ROWS / 4; ++q) {
+        const int r = q * 4 + l4;
+        const float b = fb[r * LDB + w * 16 + l15];
+#pragma unroll
+        for (int t = 0; t < CIT; ++t) {
+          const float a = fa[r * LDA + t * 16 + l15];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        }
       }
     }
   }
+  if (!wave_live) return;
+  // D[i = ci][j = co]: lane holds column co = l15, rows ci = l4 * 4 + e of tile t
+  const int co = co0 + w * 16 + l15;
+  float* dst = part + ((size_t)s * K + k) * CINP * cout_pad;
 #pragma unroll
-  for (int e = 0; e < MAXE; ++e) {
-    int idx = threadIdx.x + e * 256;
-    if (idx < nent && acc[e] != 0.f) atomicAdd(&gw[(size_t)k * nent + idx], acc[e]);
-  }
+  for (int t = 0; t < CIT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[(size_t)(t * 16 + l4 * 4 + e) * cout_pad + co] = acc[t][e];
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, size_t n,
-                                                            typename Elem<DT>::T* __restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    dst[i] = Elem<DT>::from_f32(src[i]);
+__global__ __launch_bounds__(256) void spconv_wgrad_reduce_kernel(const float* __restrict__ part, int nslabs, int K, int cin,
+                                                                  int cout, int cin_pad, int cout_pad,
+                                                                  typename Elem<DT>::T* __restrict__ gw) {
+  const size_t total = (size_t)K * cin * cout;
+  const size_t slab = (size_t)K * cin_pad * cout_pad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int co = (int)(i % cout);
+    const size_t t = i / cout;
+    const int ci = (int)(t % cin), k = (int)(t / cin);
+    const size_t off = ((size_t)k * cin_pad + ci) * cout_pad + co;
+    float v = 0.f;
+    for (int s = 0; s < nslabs; ++s) v += part[s * slab + off];   // fixed order
+    gw[i] = Elem<DT>::from_f32(v);
+  }
 }
 
 static int round_up(int x, int a) { return (x + a - 1) / a * a; }
@@ -362,10 +393,14 @@ int bevamd_spconv_conv_forward(const void* features, int dtype, const void* prep
   }
 }
 
-/* filter_grad [K, cin, cout] (same dtype as features) = sum over the rulebook of features^T @ out_grad.
- * nbr is the FORWARD table (nbr[k][o] = input row).  ws: K*cin*cout fp32 accumulators. */
+/* filter_grad [K, cin, cout] (same dtype as features) = sum over the rulebook of features^T @ out_grad
+ * (sparse_conv_ext.indice_conv_backward_*'s filter half, spconv_ops.h:363-456).  nbr is the FORWARD table (nbr[k][o] = input
+ * row).  MFMA (exact fp32), no atomics, bit-reproducible.  ws: WG_MAX_SLABS * K * cin_pad * cout_pad fp32 slab partials. */
 size_t bevamd_spconv_wgrad_workspace_bytes(int kernel_volume, int cin, int cout) {
-  return align_up((size_t)kernel_volume * cin * cout * sizeof(float), 256);
+  if (kernel_volume <= 0 || cin <= 0 || cout <= 0 || cin > 128 || cout > 128) return 0;
+  const int cit = (cin + 15) / 16, cinp = (cit <= 1 ? 1 : cit <= 2 ? 2 : cit <= 4 ? 4 : 8) * 16;
+  const int coutp = (cout + 15) / 16 * 16;
+  return align_up((size_t)WG_MAX_SLABS * kernel_volume * cinp * coutp * sizeof(float), 256);
 }
 
 int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dtype, const int* nbr, int nbr_stride,
@@ -374,37 +409,48 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
   hipStream_t stream = (hipStream_t)stream_;
   BEVAMD_REQUIRE(dtype >= 0 && dtype <= 2, "spconv_conv_wgrad: bad dtype %d", dtype);
   BEVAMD_REQUIRE(kernel_volume > 0 && cin > 0 && cout > 0 && num_out >= 0, "spconv_conv_wgrad: bad sizes");
+  BEVAMD_REQUIRE(cin <= 128 && cout <= 128, "spconv_conv_wgrad: %d -> %d channels (<= 128 supported)", cin, cout);
   BEVAMD_REQUIRE(filter_grad != nullptr, "spconv_conv_wgrad: filter_grad is null");
-  BEVAMD_REQUIRE((long long)cin * cout <= 16384, "spconv_conv_wgrad: cin*cout=%d > 16384 unsupported", cin * cout);
   const size_t nw = (size_t)kernel_volume * cin * cout;
-  float* acc = dtype == DT_F32 ? (float*)filter_grad : (float*)ws;
-  if (dtype != DT_F32) {
-    if (!ws || ws_bytes < bevamd_spconv_wgrad_workspace_bytes(kernel_volume, cin, cout)) {
-      set_error("spconv_conv_wgrad: workspace too small");
-      return BEVAMD_ERR_WORKSPACE;
-    }
+  if (num_out == 0) {
+    BEVAMD_HIP_CHECK(hipMemsetAsync(filter_grad, 0, nw * elem_size(dtype), stream));
+    return BEVAMD_OK;
   }
-  BEVAMD_HIP_CHECK(hipMemsetAsync(acc, 0, nw * sizeof(float), stream));
-  if (num_out > 0) {
-    BEVAMD_REQUIRE(features && out_grad && nbr, "spconv_conv_wgrad: null input");
-    // slabs of output rows: enough workgroups to fill 256 CUs, each amortising its atomics
-    int rows_per_block = 32 * ((num_out + 32 * 64 - 1) / (32 * 64));
-    if (rows_per_block < 32) rows_per_block = 32;
-    dim3 grid(cdiv(num_out, rows_per_block), kernel_volume), block(256);
-    size_t lds = (size_t)32 * (cin + cout) * sizeof(float);
-    switch (dtype) {
-      case DT_F32: spconv_wgrad_kernel<DT_F32><<<grid, block, lds, stream>>>((const float*)features, (const float*)out_grad, nbr, nbr_stride, num_out, kernel_volume, cin, cout, rows_per_block, acc); break;
-      case DT_F16: spconv_wgrad_kernel<DT_F16><<<grid, block, lds, stream>>>((const _Float16*)features, (const _Float16*)out_grad, nbr, nbr_stride, num_out, kernel_volume, cin, cout, rows_per_block, acc); break;
-      default:     spconv_wgrad_kernel<DT_BF16><<<grid, block, lds, stream>>>((const uint16_t*)features, (const uint16_t*)out_grad, nbr, nbr_stride, num_out, kernel_volume, cin, cout, rows_per_block, acc); break;
-    }
-    BEVAMD_LAUNCH_CHECK("spconv_wgrad");
+  BEVAMD_REQUIRE(features && out_grad && nbr, "spconv_conv_wgrad: null input");
+  if (!ws || ws_bytes < bevamd_spconv_wgrad_workspace_bytes(kernel_volume, cin, cout)) {
+    set_error("spconv_conv_wgrad: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
   }
-  if (dtype != DT_F32) {
-    dim3 grid((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), block(256);
-    if (dtype == DT_F16) cast_from_f32_kernel<DT_F16><<<grid, block, 0, stream>>>(acc, nw, (_Float16*)filter_grad);
-    else cast_from_f32_kernel<DT_BF16><<<grid, block, 0, stream>>>(acc, nw, (uint16_t*)filter_grad);
-    BEVAMD_LAUNCH_CHECK("spconv_wgrad_cast");
-  }
+  const int cit0 = (cin + 15) / 16, cit = cit0 <= 1 ? 1 : cit0 <= 2 ? 2 : cit0 <= 4 ? 4 : 8;
+  const int cinp = cit * 16, coutp = (cout + 15) / 16 * 16;
+  // row slabs: enough workgroups to fill 256 CUs (x K offsets x channel groups), at most WG_MAX_SLABS partials to reduce
+  int nslabs = (num_out + 2047) / 2048;
+  if (nslabs < 1) nslabs = 1;
+  if (nslabs > WG_MAX_SLABS) nslabs = WG_MAX_SLABS;
+  int rows_per_slab = (num_out + nslabs - 1) / nslabs;
+  rows_per_slab = (rows_per_slab + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+  nslabs = (num_out + rows_per_slab - 1) / rows_per_slab;
+  float* part = (float*)ws;
+  dim3 grid(nslabs, kernel_volume, (coutp + WG_COG - 1) / WG_COG), block(256);
+#define BEVAMD_WGRAD(DT, T, CIT) \
+  spconv_wgrad_mfma_kernel<DT, CIT><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
+                                                                kernel_volume, cin, cout, coutp, rows_per_slab, part)
+#define BEVAMD_WGRAD_DT(DT, T)                                                          \
+  do {                                                                                  \
+    if (cit == 1) BEVAMD_WGRAD(DT, T, 1); else if (cit == 2) BEVAMD_WGRAD(DT, T, 2);    \
+    else if (cit == 4) BEVAMD_WGRAD(DT, T, 4); else BEVAMD_WGRAD(DT, T, 8);             \
+  } while (0)
+  if (dtype == DT_F32) BEVAMD_WGRAD_DT(DT_F32, float);
+  else if (dtype == DT_F16) BEVAMD_WGRAD_DT(DT_F16, _Float16);
+  else BEVAMD_WGRAD_DT(DT_BF16, uint16_t);
+#undef BEVAMD_WGRAD_DT
+#undef BEVAMD_WGRAD
+  BEVAMD_LAUNCH_CHECK("spconv_wgrad_mfma");
+  dim3 rgrid((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048));
+  if (dtype == DT_F32) spconv_wgrad_reduce_kernel<DT_F32><<<rgrid, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, cinp, coutp, (float*)filter_grad);
+  else if (dtype == DT_F16) spconv_wgrad_reduce_kernel<DT_F16><<<rgrid, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, cinp, coutp, (_Float16*)filter_grad);
+  else spconv_wgrad_reduce_kernel<DT_BF16><<<rgrid, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, cinp, coutp, (uint16_t*)filter_grad);
+  BEVAMD_LAUNCH_CHECK("spconv_wgrad_reduce");
   return BEVAMD_OK;
 }
 

@@ -116,6 +116,7 @@ def test_fused_encoder_eight_frames_vs_module_path_and_oracle_levels(dev):
     pts = [torch.from_numpy(p).to(dev) for p in pts_np]
     vs, pr, mp, mv = CFG["voxel_size"], CFG["point_cloud_range"], CFG["max_num_points"], CFG["max_voxels"][1]
     f, c, _, tot = voxelize_batch_device(pts, vs, pr, mp, mv)
+    f = f.half()          # what @auto_fp16 hands the module path; the fused path takes either
     enc = flagship_encoder(dev)
     assert fused._variant_for(B8, 27, 64, 64) != 0                   # the batched tilings are the ones under test
     with torch.no_grad():
@@ -170,7 +171,8 @@ def test_flagship_frame_stage_by_stage_vs_oracle(dev):
                                         num_out_dev=lvl.n_dev, variant=variant)[:n]
         else:
             got = sops.sparse_conv_tiled(x, img, lvl.subm_neighbors((3, 3, 3)), lvl.n_cap, 27, cw, cw, num_out_dev=lvl.n_dev)[:n]
-        assert (variant is not None) == (stage >= 1)                 # level 1 rows are in first-appearance order
+        # level 1 rows are in first-appearance order (gather kernel); the 128-channel level keeps it below 4 frames per step
+        assert (variant is not None) == (stage in (1, 2))
         _, sp, sn, _ = oracle.get_indice_pairs(ind, 1, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
         ref = oracle.indice_conv(x[:n].float().cpu().numpy(), w.float().cpu().numpy(), sp, sn, n)
         err = float(np.max(np.abs(got.float().cpu().numpy() - ref)))

@@ -198,6 +198,36 @@ def test_autograd_backward_vs_oracle(dev, subm, dtype):
     assert np.max(np.abs(conv.weight.grad.float().cpu().numpy() - gw_ref)) <= tol_w * (1 + np.abs(gw_ref).max())
 
 
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 32), (32, 32), (64, 128), (128, 128), (7, 100), (128, 9)])
+def test_filter_gradient_mfma_any_width_deterministic(dev, cin, cout):
+    """bevamd_spconv_conv_wgrad (MFMA, slab partials + fixed-order reduce): every channel count up to 128 (the old
+    kernel refused cin*cout > 16384 only at backward time), fp32 within 2e-4 of the float64 oracle, bit-identical run to run
+    (no atomics), several row slabs."""
+    rng = np.random.default_rng(cin * 131 + cout)
+    B, shape = 2, (24, 20, 9)
+    indices = _random_indices(rng, B, shape, 2300)       # 4600 rows -> 3 row slabs
+    oi, opairs, onum, _ = oracle.get_indice_pairs(indices, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
+    f, w = _conv_case(rng, indices.shape[0], cin, cout, (3, 3, 3), torch.float32)
+    og = rng.standard_normal((oi.shape[0], cout)).astype(np.float32)
+    _, gw_ref = oracle.indice_conv_backward(f, w, og, opairs, onum)
+    rb = spconv.build_rulebook(torch.from_numpy(indices).to(dev), B, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, True)
+    from bevfusion_amd.spconv import ops as sops
+
+    x, wt, g = torch.from_numpy(f).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(og).to(dev)
+    nbr, nbr_t = rb.conv_tables()
+    outs = [sops.sparse_conv_backward(x, wt, g, nbr, nbr_t, x.shape[0])[1] for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    got = outs[0].cpu().numpy()
+    assert got.shape == gw_ref.shape
+    assert np.max(np.abs(got - gw_ref)) <= 2e-4 * (1 + np.abs(gw_ref).max())
+    # 16-bit features: same kernel, products of the widened values (exact), one rounding of the result
+    gh = sops.sparse_conv_backward(x.half(), wt.half(), g.half(), nbr, nbr_t, x.shape[0])[1]
+    _, gw_h = oracle.indice_conv_backward(x.half().float().cpu().numpy(), wt.half().float().cpu().numpy(),
+                                          g.half().float().cpu().numpy(), opairs, onum)
+    assert gh.dtype == torch.float16
+    assert np.max(np.abs(gh.float().cpu().numpy() - gw_h)) <= 2e-3 * (1 + np.abs(gw_h).max())
+
+
 def test_empty_tensor(dev):
     conv = spconv.SubMConv3d(4, 8, 3, padding=1, bias=False).to(dev)
     sp = spconv.SparseConvTensor(torch.zeros(0, 4, device=dev), torch.zeros(0, 4, dtype=torch.int32, device=dev), [8, 8, 8], 1)
