@@ -37,6 +37,7 @@ _SIGNATURES = {
     # view-transform glue
     "bevamd_depth_raster_workspace_bytes": (Z, [I, I, I]),
     "bevamd_depth_raster": (I, [P, I, I, P, P, P, P, I, I, I, P, P, Z, P]),
+    "bevamd_depth_raster_batch": (I, [P, P, I, I, P, P, I, P, P, I, I, I, P, P, Z, P]),
     "bevamd_lss_geometry": (I, [P, I, P, P, P, P, P, P, I, I, P, P]),
     "bevamd_mat3_inverse": (I, [P, LL, LL, I, P, P]),
     "bevamd_lss_camera_matrices": (I, [P, P, P, LL, LL, I, P, P, P]),

@@ -120,6 +120,58 @@ __global__ __launch_bounds__(256) void depth_raster_write_kernel(RasterArgs a, c
   }
 }
 
+// ---- batched raster: up to RASTER_MAX_BATCH samples per launch pair (pointers by value in the kernel argument) ---------------
+constexpr int RASTER_MAX_BATCH = 16;
+struct RasterBatch {
+  const float* points[RASTER_MAX_BATCH];
+  int n[RASTER_MAX_BATCH];
+  int start[RASTER_MAX_BATCH + 1];   // exclusive prefix of n[] (thread -> sample by a short scan)
+  const float* aug_inv_rot;          // [B, 3, 3]
+  const float* aug_trans;            // [B, 3] (row b at b * trans_stride)
+  const float* lidar2image;          // [B, ncam, 4, 4]
+  const float* img_aug;              // [B, ncam, 4, 4]
+  int batch, nfeat, ncam, ih, iw, trans_stride;
+};
+
+__device__ __forceinline__ bool raster_batch_locate(const RasterBatch& rb, long long t, RasterArgs& a, int& b, int& i, int& c) {
+  const long long pt = t / rb.ncam;
+  c = (int)(t - pt * rb.ncam);
+  if (pt >= rb.start[rb.batch]) return false;
+  b = 0;
+#pragma unroll 1
+  while (b + 1 < rb.batch && pt >= rb.start[b + 1]) ++b;
+  i = (int)(pt - rb.start[b]);
+  a.points = rb.points[b];
+  a.aug_inv_rot = rb.aug_inv_rot + (size_t)b * 9;
+  a.aug_trans = rb.aug_trans + (size_t)b * rb.trans_stride;
+  a.lidar2image = rb.lidar2image + (size_t)b * rb.ncam * 16;
+  a.img_aug = rb.img_aug + (size_t)b * rb.ncam * 16;
+  a.n = rb.n[b]; a.nfeat = rb.nfeat; a.ncam = rb.ncam; a.ih = rb.ih; a.iw = rb.iw;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void depth_raster_batch_winner_kernel(RasterBatch rb, int* __restrict__ winner) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  RasterArgs a;
+  int b, i, c, row, col;
+  float dist;
+  if (!raster_batch_locate(rb, t, a, b, i, c)) return;
+  if (project(a, i, c, row, col, dist)) atomicMax(&winner[(((size_t)b * a.ncam + c) * a.ih + row) * a.iw + col], i);
+}
+
+__global__ __launch_bounds__(256) void depth_raster_batch_write_kernel(RasterBatch rb, const int* __restrict__ winner,
+                                                                       float* __restrict__ depth) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  RasterArgs a;
+  int b, i, c, row, col;
+  float dist;
+  if (!raster_batch_locate(rb, t, a, b, i, c)) return;
+  if (project(a, i, c, row, col, dist)) {
+    const size_t pix = (((size_t)b * a.ncam + c) * a.ih + row) * a.iw + col;
+    if (winner[pix] == i) depth[pix] = dist;
+  }
+}
+
 struct GeomArgs {
   const float* frustum;        // [D*fH*fW, 3] (u, v, d)
   const float* post_rot_inv;   // [ncam_total, 3, 3]  inverse(img_aug[:3,:3])
@@ -244,6 +296,56 @@ int bevamd_depth_raster(const float* points, int num_points, int num_features, c
   BEVAMD_LAUNCH_CHECK("depth_raster_winner");
   depth_raster_write_kernel<<<grid, block, 0, stream>>>(a, winner, depth);
   BEVAMD_LAUNCH_CHECK("depth_raster_write");
+  return BEVAMD_OK;
+}
+
+/* bevamd_depth_raster for a whole batch in one launch pair (2 fills + 2 kernels per <= 16 samples instead of 4 launches per
+ * sample): points[b] DEVICE pointers (host array), num_points[b] host ints; lidar_aug_inv_rot [B,3,3], lidar_aug_trans rows at
+ * lidar_aug_trans + b * trans_stride floats (trans_stride 3 for a packed [B,3], 16 for column 3 of a [B,4,4] starting at
+ * element 3 with row stride 4 is NOT contiguous -> pass a packed copy), lidar2image / img_aug [B,ncam,4,4]; depth [B,ncam,1,ih,iw];
+ * ws: batch * bevamd_depth_raster_workspace_bytes(ncam, ih, iw).  Same arithmetic and collision rule per sample. */
+int bevamd_depth_raster_batch(const float* const* points, const int* num_points, int batch, int num_features,
+                              const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
+                              const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth, void* ws,
+                              size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(batch > 0 && num_features >= 3 && ncam > 0 && ih > 0 && iw > 0 && trans_stride >= 3, "depth_raster_batch: bad sizes");
+  BEVAMD_REQUIRE(points && num_points && depth && lidar_aug_inv_rot && lidar_aug_trans && lidar2image && img_aug,
+                 "depth_raster_batch: null buffer");
+  const size_t per = (size_t)ncam * ih * iw;
+  int rc = device_fill_u32((uint32_t*)depth, per * batch, 0u, stream);  // reference: torch.zeros
+  if (rc) return rc;
+  if (!ws || ws_bytes < (size_t)batch * bevamd_depth_raster_workspace_bytes(ncam, ih, iw)) {
+    set_error("depth_raster_batch: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  int* winner = (int*)ws;
+  rc = device_fill_u32((uint32_t*)winner, per * batch, 0xFFFFFFFFu, stream);
+  if (rc) return rc;
+  for (int b0 = 0; b0 < batch; b0 += RASTER_MAX_BATCH) {
+    RasterBatch rb;
+    rb.batch = batch - b0 < RASTER_MAX_BATCH ? batch - b0 : RASTER_MAX_BATCH;
+    rb.start[0] = 0;
+    for (int j = 0; j < rb.batch; ++j) {
+      BEVAMD_REQUIRE(num_points[b0 + j] >= 0 && (num_points[b0 + j] == 0 || points[b0 + j]), "depth_raster_batch: bad sample %d", b0 + j);
+      rb.points[j] = points[b0 + j];
+      rb.n[j] = num_points[b0 + j];
+      rb.start[j + 1] = rb.start[j] + rb.n[j];
+    }
+    for (int j = rb.batch; j < RASTER_MAX_BATCH; ++j) { rb.points[j] = nullptr; rb.n[j] = 0; rb.start[j + 1] = rb.start[rb.batch]; }
+    rb.aug_inv_rot = lidar_aug_inv_rot + (size_t)b0 * 9;
+    rb.aug_trans = lidar_aug_trans + (size_t)b0 * trans_stride;
+    rb.lidar2image = lidar2image + (size_t)b0 * ncam * 16;
+    rb.img_aug = img_aug + (size_t)b0 * ncam * 16;
+    rb.nfeat = num_features; rb.ncam = ncam; rb.ih = ih; rb.iw = iw; rb.trans_stride = trans_stride;
+    const long long total = (long long)rb.start[rb.batch] * ncam;
+    if (total == 0) continue;
+    dim3 grid(cdiv(total, 256)), block(256);
+    depth_raster_batch_winner_kernel<<<grid, block, 0, stream>>>(rb, winner + (size_t)b0 * per);
+    BEVAMD_LAUNCH_CHECK("depth_raster_batch_winner");
+    depth_raster_batch_write_kernel<<<grid, block, 0, stream>>>(rb, winner + (size_t)b0 * per, depth + (size_t)b0 * per);
+    BEVAMD_LAUNCH_CHECK("depth_raster_batch_write");
+  }
   return BEVAMD_OK;
 }
 

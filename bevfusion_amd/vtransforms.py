@@ -15,6 +15,7 @@ What changed underneath (`BaseTransform.bev_pool`, base.py:141-176):
 Reference defects handled as SURVEY.md lists them: D2 (`get_cam_feats` arity) and D3 (DepthLSSTransform gets
 scalar 1-channel depth, no height expansion — the semantics the released checkpoint's `Conv2d(1, 8, 1)` needs).
 """
+import ctypes
 from typing import Tuple
 
 import torch
@@ -321,7 +322,7 @@ class BaseDepthTransform(BaseTransform):
         return depth
 
     def _depth_raster_native(self, points, n_cam, lidar2image, img_aug_matrix, lidar_aug_matrix):
-        """csrc/vtransform.hip: one (winner, write) kernel pair per sample, all cameras at once, no host sync; a pixel hit
+        """csrc/vtransform.hip: one (winner, write) kernel pair for the whole batch, all cameras at once, no host sync; a pixel hit
         by several points keeps the LAST one in input order (the reference's assignment order on CPU; its GPU
         index_put is unordered)."""
         lib = _capi.load()
@@ -340,17 +341,19 @@ class BaseDepthTransform(BaseTransform):
                             "mat3_inverse")
         l2i = lidar2image.float().contiguous()
         ia = img_aug_matrix.float().contiguous()
+        pts = [p if (p.dtype == torch.float32 and p.is_contiguous()) else p.float().contiguous() for p in points]
+        nfeat = pts[0].shape[1]
+        if any(p.shape[1] != nfeat for p in pts):
+            raise RuntimeError("depth_raster: every sample must have the same number of point features")
+        ptrs = (ctypes.c_void_p * B)(*[p.data_ptr() for p in pts])
+        counts = (ctypes.c_int * B)(*[int(p.shape[0]) for p in pts])
         with torch.cuda.device(dev):
-            wsb = lib.bevamd_depth_raster_workspace_bytes(n_cam, iH, iW)
+            wsb = lib.bevamd_depth_raster_workspace_bytes(n_cam, iH, iW) * B
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            for b in range(B):
-                p = points[b]
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    p = p.float().contiguous()
-                rc = lib.bevamd_depth_raster(_capi.ptr(p), p.shape[0], p.shape[1], _capi.ptr(inv_rot[b]), _capi.ptr(trans[b]),
-                                             _capi.ptr(l2i[b]), _capi.ptr(ia[b]), n_cam, iH, iW, _capi.ptr(depth[b]),
-                                             _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
-                _capi.check(rc, "depth_raster")
+            rc = lib.bevamd_depth_raster_batch(ptrs, counts, B, nfeat, _capi.ptr(inv_rot), _capi.ptr(trans), 3, _capi.ptr(l2i),
+                                               _capi.ptr(ia), n_cam, iH, iW, _capi.ptr(depth), _capi.ptr(ws), wsb,
+                                               _capi.stream_ptr(dev))
+        _capi.check(rc, "depth_raster_batch")
         return depth
 
     def forward(self, img, points, radar, sensor2ego, lidar2ego, lidar2camera, lidar2image, cam_intrinsic,

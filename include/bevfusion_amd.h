@@ -173,6 +173,16 @@ int bevamd_depth_raster(const float* points, int num_points, int num_features, c
                         const float* lidar_aug_trans, const float* lidar2image, const float* img_aug, int ncam,
                         int ih, int iw, float* depth, void* ws, size_t ws_bytes, void* stream);
 
+/* The per-sample loop of BaseDepthTransform.forward (base.py:283-329) in ONE launch pair for the whole batch: points[b] are
+ * DEVICE pointers in a HOST array, num_points[b] host ints; lidar_aug_inv_rot [batch,3,3]; lidar_aug_trans: row b at
+ * lidar_aug_trans + b*trans_stride floats (3 for a packed [batch,3]); lidar2image / img_aug [batch,ncam,4,4];
+ * depth [batch,ncam,1,ih,iw]; ws: batch * bevamd_depth_raster_workspace_bytes(ncam, ih, iw).  Per sample identical to
+ * bevamd_depth_raster (same arithmetic, last point in input order wins). */
+int bevamd_depth_raster_batch(const float* const* points, const int* num_points, int batch, int num_features,
+                              const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
+                              const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth,
+                              void* ws, size_t ws_bytes, void* stream);
+
 /* Replaces BaseTransform.get_geometry (base.py:92-135): frustum [frustum_points, 3] (u, v, d) -> geom
  * [batch*cams, frustum_points, 3] in the lidar frame.  post_rot_inv [batch*cams,3,3] = inverse(img_aug[:3,:3]),
  * post_trans [batch*cams,3], combine [batch*cams,3,3] = camera2lidar_rot @ inverse(intrinsics), camera2lidar_trans

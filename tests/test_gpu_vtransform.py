@@ -183,3 +183,33 @@ def test_depth_raster_module_last_point_wins_and_empty(dev):
     # no points at all
     d0 = vt.depth_raster(img, [torch.zeros((0, 5), device=dev)], g(l2i), g(ia), g(la))
     assert float(d0.abs().max()) == 0.0
+
+
+def test_batched_raster_equals_the_per_sample_entry_point(dev, gold):
+    """`bevamd_depth_raster_batch` (one launch pair for the whole batch — what the module calls) == `bevamd_depth_raster` sample by
+    sample on the same device-computed inverse: identical bits, including collision winners; 17 samples cross the 16-per-launch
+    argument limit."""
+    c = case(gold, "small")
+    lib = _capi.load()
+    pts = points_of(c)
+    reps = 9                                                             # 18 samples from the fixture's two
+    B = len(pts) * reps - 1
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    tile = lambda a: np.concatenate([a] * reps)[:B]                      # noqa: E731
+    pl = [g(pts[b % 2][: 4000 + 37 * b]) for b in range(B)]
+    l2i, ia, la = g(tile(c["l2i"])), g(tile(c["ia"])), g(tile(c["la"]))
+    vt = make_vt(SMALL_CFG, dev)
+    got = vt.depth_raster(torch.zeros(B, 6, 1, 1, 1, device=dev), pl, l2i, ia, la)
+    inv = torch.empty((B, 3, 3), device=dev)
+    _capi.check(lib.bevamd_mat3_inverse(_capi.ptr(la), 16, 4, B, _capi.ptr(inv), _capi.stream_ptr(dev)), "mat3_inverse")
+    iH, iW = SMALL_CFG["image_size"]
+    wsb = lib.bevamd_depth_raster_workspace_bytes(6, iH, iW)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    for b in range(B):
+        one = torch.empty((6, 1, iH, iW), device=dev)
+        tr = la[b, :3, 3].contiguous()
+        _capi.check(lib.bevamd_depth_raster(_capi.ptr(pl[b]), pl[b].shape[0], pl[b].shape[1], _capi.ptr(inv[b]), _capi.ptr(tr),
+                                            _capi.ptr(l2i[b]), _capi.ptr(ia[b]), 6, iH, iW, _capi.ptr(one), _capi.ptr(ws), wsb,
+                                            _capi.stream_ptr(dev)), "depth_raster")
+        assert torch.equal(got[b], one), b
+    assert int((got != 0).sum()) > 1000 * B // 4
