@@ -24,21 +24,15 @@ from .structure import SparseConvTensor
 
 
 def _calculate_fan_in_and_fan_out_hwio(tensor):
-    dimensions = tensor.ndimension()
-    if dimensions < 2:
+    """(fan_in, fan_out) of a filter stored [k..., Cin, Cout] (conv.py:26-42 of the reference; its weights are HWIO, so the
+    channel axes are the LAST two and everything in front of them is the receptive field)."""
+    if tensor.dim() < 2:
         raise ValueError("fan in and fan out can not be computed for tensor with fewer than 2 dimensions")
-    if dimensions == 2:
-        fan_in = tensor.size(-2)
-        fan_out = tensor.size(-1)
-    else:
-        num_input_fmaps = tensor.size(-2)
-        num_output_fmaps = tensor.size(-1)
-        receptive_field_size = 1
-        if tensor.dim() > 2:
-            receptive_field_size = tensor[..., 0, 0].numel()
-        fan_in = num_input_fmaps * receptive_field_size
-        fan_out = num_output_fmaps * receptive_field_size
-    return fan_in, fan_out
+    *taps, cin, cout = tensor.shape
+    field = 1
+    for t in taps:
+        field *= int(t)
+    return int(cin) * field, int(cout) * field
 
 
 class IndiceData:

@@ -112,21 +112,21 @@ class BaseTransform(nn.Module):
         B, N, _ = camera2lidar_trans.shape
         if camera2lidar_trans.is_cuda and not torch.is_grad_enabled():
             return self._get_geometry_native(camera2lidar_rots, camera2lidar_trans, intrins, post_rots, post_trans, **kwargs)
-        # host tensors / autograd: the reference's own broadcasting formulation
-        # undo post-transformation
-        points = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
-        points = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(points.unsqueeze(-1))
-        # cam_to_lidar
-        points = torch.cat((points[:, :, :, :, :, :2] * points[:, :, :, :, :, 2:3], points[:, :, :, :, :, 2:3]), 5)
-        combine = camera2lidar_rots.matmul(torch.inverse(intrins))
-        points = combine.view(B, N, 1, 1, 1, 3, 3).matmul(points).squeeze(-1)
-        points += camera2lidar_trans.view(B, N, 1, 1, 1, 3)
-        if "extra_rots" in kwargs:
-            extra_rots = _fp32(kwargs["extra_rots"])[0]
-            points = extra_rots.view(B, 1, 1, 1, 1, 3, 3).repeat(1, N, 1, 1, 1, 1, 1).matmul(points.unsqueeze(-1)).squeeze(-1)
+        # host tensors / autograd: the reference's chain of broadcast matmuls, same operations in the same order (torch picks
+        # the same kernels, so the bits match the reference on CPU: tests/test_oracle_vtransform.py)
+        per_cam = (B, N, 1, 1, 1)
+        inv_aug = torch.inverse(post_rots).view(*per_cam, 3, 3)
+        pix = (self.frustum - post_trans.view(*per_cam, 3)).unsqueeze(-1)           # undo the image augmentation ...
+        pix = inv_aug.matmul(pix)
+        cam = torch.cat((pix[..., :2, :] * pix[..., 2:3, :], pix[..., 2:3, :]), 5)   # ... (u*d, v*d, d) ...
+        to_lidar = camera2lidar_rots.matmul(torch.inverse(intrins)).view(*per_cam, 3, 3)
+        points = to_lidar.matmul(cam).squeeze(-1)                                    # ... unproject and move to the lidar frame
+        points += camera2lidar_trans.view(*per_cam, 3)
+        if "extra_rots" in kwargs:                                                   # LiDAR augmentation (base.py:122-133)
+            rot = _fp32(kwargs["extra_rots"])[0].view(B, 1, 1, 1, 1, 3, 3).repeat(1, N, 1, 1, 1, 1, 1)
+            points = rot.matmul(points.unsqueeze(-1)).squeeze(-1)
         if "extra_trans" in kwargs:
-            extra_trans = _fp32(kwargs["extra_trans"])[0]
-            points += extra_trans.view(B, 1, 1, 1, 1, 3).repeat(1, N, 1, 1, 1, 1)
+            points += _fp32(kwargs["extra_trans"])[0].view(B, 1, 1, 1, 1, 3).repeat(1, N, 1, 1, 1, 1)
         return points
 
     def _get_geometry_native(self, c2l_rots, c2l_trans, intrins, post_rots, post_trans, **kwargs):
