@@ -44,6 +44,7 @@ struct SlabArgs {
   const int2* hdr;           // [nblocks][PLANES] (lo, cnt)
   const uint16_t* slots;     // [nblocks][27][BM]
   unsigned wimg_bytes;       // size of the filter image (buffer descriptor bound)
+  unsigned long long* prof;  // -DBEVAMD_PROFILING builds: [4] cycle sums over all waves (issue, multiply, dma wait, barrier) + [4] = waves
 };
 
 // ---- metadata -----------------------------------------------------------------------------------------------------
@@ -128,10 +129,14 @@ struct Plan {
   static constexpr int NXB = DX + 1;                // X buffers
   static constexpr int XB = ((CAP + 1) * RB + 1023) / 1024 * 1024;   // one X buffer incl. the zero row, KiB-aligned
   static constexpr int WS = SPS * CH * NT * 1024;   // filter bytes per sync step
+  // DMA roles: the lower half of the waves requests the filter pieces, the upper half the row pieces.  A wave's requests
+  // complete in issue order, so a row request (far memory, needed a whole plane later) issued in front of a filter request
+  // (L2, needed next step) would have to be waited for first; with separate issuers the rows keep their full lead.
+  static constexpr int NWI = NW / 2;                // issuing waves per role
   static constexpr int PW = SPS * CH * NT;          // 1 KiB DMA pieces of one step's filter
-  static constexpr int NWS = (PW + NW - 1) / NW;    // ... per wave (waves past the end issue a dummy piece)
+  static constexpr int NWS = (PW + NWI - 1) / NWI;  // ... per filter wave (waves past the end issue a dummy piece)
   static constexpr int PX = CAP / RPI;              // 1 KiB DMA pieces of a full X buffer
-  static constexpr int NX = (PX + NW - 1) / NW;     // ... per wave: a FIXED count, so that s_waitcnt can count
+  static constexpr int NX = (PX + NWI - 1) / NWI;   // ... per row wave: a FIXED count, so that s_waitcnt can count
   static constexpr int OFF_X = 0;
   static constexpr int OFF_W = NXB * XB;
   static constexpr int OFF_SLOT = OFF_W + WR * WS;
@@ -140,7 +145,8 @@ struct Plan {
   static_assert(NW * EpiScratch<NT>::U4 * 16 <= NXB * XB, "epilogue scratch must fit the X buffers it aliases");
   static_assert(CAP % RPI == 0, "CAP must be a whole number of DMA instructions");
   static_assert((CAP + 1) * RB < 65536, "row offsets are 16-bit");
-  static_assert(NX + WD * NWS < 60, "vmcnt is a 6-bit counter");
+  static_assert(NW >= 2 && NW % 2 == 0, "two DMA roles");
+  static_assert(DX * NX < 60 && WD * NWS < 60, "vmcnt is a 6-bit counter");
 };
 
 // LDS-DMA, buffer form: 16 bytes per lane from rsrc[voff + soff] to lds + lane*16 (wave-uniform lds / soff)
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
     char* dst = L + P::OFF_X + xb * P::XB;
 #pragma unroll
     for (int t = 0; t < P::NX; ++t) {
-      const int i = w + t * NW;
+      const int i = (w - P::NWI) + t * P::NWI;
       unsigned r = (unsigned)(i * P::RPI) + lr;
       r = r < rows ? r : rows - 1u;
       dma16(rs_x, r * row_bytes + lane_piece_off, soff, i < P::PX ? dst + i * 1024 : dump);
@@ -244,24 +250,25 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
     constexpr int PER_TAP = P::CH * NT;   // KiB per tap
 #pragma unroll
     for (int t = 0; t < P::NWS; ++t) {
-      const int i0 = w + t * NW;
+      const int i0 = w + t * P::NWI;
       const int i = i0 < P::PW ? i0 : P::PW - 1;
       const int s = i / PER_TAP, e = i - s * PER_TAP;
       const int k = u.j * TAPS + g * SPS + s;
       dma16(rs_w, (unsigned)lane * 16u, (unsigned)(((k * P::CPB + u.h * P::CH) * NT + e) * 1024), i0 < P::PW ? dst + i * 1024 : dump);
     }
   };
-  // all but the newest requests named here have landed
-  auto wait_for = [&](int n_w, bool keep_x) {   // n_w in 0..WD steps of filter requests still allowed in flight
-    if (keep_x) {
-      if (n_w >= 2) wait_dma<P::NX + 2 * P::NWS>();
-      else if (n_w == 1) wait_dma<P::NX + P::NWS>();
-      else wait_dma<P::NX>();
-    } else {
-      if (n_w >= 2) wait_dma<2 * P::NWS>();
-      else if (n_w == 1) wait_dma<P::NWS>();
-      else wait_dma<0>();
-    }
+  const bool w_role = w < P::NWI;   // wave-uniform: this wave requests filter pieces (else row pieces)
+  // filter waves: all but the filter requests of the `n_w` newest steps have landed
+  auto wait_w = [&](int n_w) {
+    if (n_w >= 2) wait_dma<2 * P::NWS>();
+    else if (n_w == 1) wait_dma<P::NWS>();
+    else wait_dma<0>();
+  };
+  // row waves: all but the row requests of the `n_x` newest pieces have landed
+  auto wait_x = [&](int n_x) {
+    if (n_x >= 2) wait_dma<2 * P::NX>();
+    else if (n_x == 1) wait_dma<P::NX>();
+    else wait_dma<0>();
   };
 
   WT wt;
@@ -328,43 +335,62 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
   sub[1] = next_sub(sub[0]);
   sub[2] = next_sub(sub[1]);
   auto step_after = [&](int g, int d, int& off, int& g2) { const int gg = g + d; off = gg / P::GROUPS; g2 = gg % P::GROUPS; };
-  stage_x(sub[0], 0);
-  if (P::DX == 2 && !sub[1].done) stage_x(sub[1], 1);
+  if (!w_role) {
+    stage_x(sub[0], 0);
+    if (P::DX == 2 && !sub[1].done) stage_x(sub[1], 1);
+  } else {
 #pragma unroll
-  for (int d = 0; d < P::WD; ++d) {
-    int off, gd;
-    step_after(0, d, off, gd);
-    if (!sub[off].done) stage_w(sub[off], gd, d);
+    for (int d = 0; d < P::WD; ++d) {
+      int off, gd;
+      step_after(0, d, off, gd);
+      if (!sub[off].done) stage_w(sub[off], gd, d);
+    }
   }
   wait_dma<0>();
   __syncthreads();   // also publishes the slot table and the zero rows
   int xb = 0, ws = 0;
-  bool x_prev = false;
+#ifdef BEVAMD_PROFILING
+  unsigned long long t_issue = 0, t_mul = 0, t_wait = 0, t_bar = 0, t0, t1;
+#define BEVAMD_TICK(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+  t0 = __builtin_readcyclecounter();
+#else
+#define BEVAMD_TICK(acc) do { } while (0)
+#endif
   for (;;) {
 #pragma unroll
     for (int g = 0; g < P::GROUPS; ++g) {
-      // requests: the filter of step t + WD, then (first step of a piece) the rows of the piece DX planes ahead
+      // requests: filter waves ask for the filter of step t + WD; row waves ask — at the first step of a piece — for the rows
+      // of the piece DX planes ahead
       int off, gd;
       step_after(g, P::WD, off, gd);
-      const bool w_new = !sub[off].done;
-      if (w_new) stage_w(sub[off], gd, (ws + P::WD) % WR);
-      const bool x_now = g == 0 && !sub[P::DX].done;
-      if (x_now) stage_x(sub[P::DX], (xb + P::DX) % P::NXB);
-      multiply(sub[0], g, xb, ws);
-      // Needed by step t+1: its filter and, if it opens a piece, that piece's rows — both requested before the filter of
-      // step t+2 was.  Newer than those (may stay in flight): the filters of steps t+2 .. t+WD and the rows requested during
-      // this step, or — when a piece spans several steps — during the previous one.
-      int n_w = 0;
-#pragma unroll
-      for (int d = 2; d <= P::WD; ++d) {
-        int o2, g2;
-        step_after(g, d, o2, g2);
-        n_w += !sub[o2].done;
+      if (w_role) {
+        if (!sub[off].done) stage_w(sub[off], gd, (ws + P::WD) % WR);
+      } else if (g == 0 && !sub[P::DX].done) {
+        stage_x(sub[P::DX], (xb + P::DX) % P::NXB);
       }
-      const bool keep_x = P::GROUPS >= 2 ? (x_now || (P::WD >= 2 && x_prev)) : (P::DX == 2 && x_now);
-      wait_for(n_w, keep_x);
+      BEVAMD_TICK(t_issue);
+      multiply(sub[0], g, xb, ws);
+      BEVAMD_TICK(t_mul);
+      // Needed by step t+1: its filter (filter waves: everything but the requests of steps t+2 .. t+WD) and, if step t+1 opens a
+      // piece, that piece's rows (row waves: everything but the requests for the pieces after it).
+      if (w_role) {
+        int n_w = 0;
+#pragma unroll
+        for (int d = 2; d <= P::WD; ++d) {
+          int o2, g2;
+          step_after(g, d, o2, g2);
+          n_w += !sub[o2].done;
+        }
+        wait_w(n_w);
+      } else if (g == P::GROUPS - 1) {
+        int n_x = 0;
+#pragma unroll
+        for (int d = 2; d <= P::DX; ++d) n_x += !sub[d].done;
+        wait_x(n_x);
+      }
+      BEVAMD_TICK(t_wait);
       barrier_keep_dma();
-      x_prev = x_now;
+      BEVAMD_TICK(t_bar);
       ws = ws + 1 == WR ? 0 : ws + 1;
     }
     if (sub[1].done) break;
@@ -373,6 +399,13 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
     sub[2] = next_sub(sub[2]);
     xb = xb + 1 == P::NXB ? 0 : xb + 1;
   }
+#ifdef BEVAMD_PROFILING
+  if (sa.prof && lane == 0) {
+    atomicAdd(sa.prof + 0, t_issue); atomicAdd(sa.prof + 1, t_mul); atomicAdd(sa.prof + 2, t_wait); atomicAdd(sa.prof + 3, t_bar);
+    atomicAdd(sa.prof + 4, 1ull);
+  }
+#endif
+#undef BEVAMD_TICK
   wt.store(a);   // epilogue scratch aliases the X buffers: every wave passed the last barrier, nobody reads X any more
 }
 

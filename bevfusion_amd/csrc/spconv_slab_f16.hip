@@ -11,7 +11,13 @@ int launch_f16(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t str
 
 using namespace bevamd;
 
+static unsigned long long* g_slab_prof = nullptr;   // profiling builds: device buffer the next slab launches add their cycle sums to
+
 extern "C" {
+
+/* -DBEVAMD_PROFILING builds only: device buffer [5] uint64 (issue, multiply, dma-wait, barrier cycle sums over all waves; wave
+ * count) that every following bevamd_spconv_conv_forward_slab launch accumulates into; NULL switches it off. */
+void bevamd_spconv_slab_set_profile_buffer(void* buf) { g_slab_prof = (unsigned long long*)buf; }
 
 /* Rows per block of slab variant `variant` (0 = default) for a cin-channel SubM 3x3x3 convolution, 0 if none is built
  * (cin must be 32, 64 or 128 and cout == cin).  The block size fixes the metadata layout of bevamd_spconv_slab_build. */
@@ -101,6 +107,7 @@ int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_st
   sa.hdr = (const int2*)hdr;
   sa.slots = (const uint16_t*)slots;
   sa.wimg_bytes = (unsigned)(tile::image_elems(27, cin, cout / 16) * 2);
+  sa.prof = g_slab_prof;
   return dtype == tile::T_F16 ? slab::launch_f16(sa, cin, cout / 16, variant, stream)
                               : slab::launch_bf16(sa, cin, cout / 16, variant, stream);
 }
