@@ -76,6 +76,7 @@ _SIGNATURES = {
     "bevamd_spconv_make_filter_image": (I, [P, I, I, I, I, I, P, P]),
     "bevamd_spconv_conv_forward_tiled": (I, [P, I, I, I, P, P, I, I, P, I, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_slab_set_profile_buffer": (None, [P]),
+    "bevamd_spconv_slab_ablation_mask": (I, []),
     "bevamd_spconv_slab_block_rows": (I, [I, I]),
     "bevamd_spconv_slab_variants": (I, [I, P, I]),
     "bevamd_spconv_slab_grid_ok": (I, [P, I]),

@@ -35,6 +35,11 @@ namespace slab {
 
 using namespace tile;
 
+#ifndef BEVAMD_SLAB_ABL
+#define BEVAMD_SLAB_ABL 0   // profiling builds: -DBEVAMD_SLAB_ABL=mask compiles parts of the kernel out (wrong results by design)
+#endif
+constexpr int SLAB_ABL = BEVAMD_SLAB_ABL;   // 1 no filter DMA, 2 no row DMA, 4 no MFMA, 8 no fragment reads, 16 no barrier, 32 no epilogue stores,
+                                            // 64 no slot-table load, 128 no main loop, 256 launch only
 constexpr int PLANES = 3;         // kx planes of the 3x3x3 kernel: the 9 (ky, kz) taps of a plane share one staged range
 constexpr int TAPS = 9;           // taps per plane
 constexpr unsigned NO_SLOT = 0xFFFFu;
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
   const int per = (nblk + 7) >> 3;
   const int blk = xcd * per + bix;
   if (bix >= per || blk >= nblk) return;   // the whole workgroup leaves together
+  if constexpr (SLAB_ABL & 256) return;   // launch + block map only
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to hipcc: without the readfirstlane every
   // LDS-DMA below (uniform LDS base in M0, uniform soffset) is wrapped in a waterfall loop (cdna_hip_programming.md T20)
@@ -194,7 +200,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
   {
     const u32x4* src = (const u32x4*)(sa.slots + (size_t)blk * 27 * P::BM);
     constexpr int N16 = 27 * P::BM * 2 / 16;
-    for (int i = tid; i < N16; i += NW * 64) ((u32x4*)slot)[i] = src[i];
+    if constexpr (SLAB_ABL & 64) { for (int i = tid; i < N16; i += NW * 64) ((u32x4*)slot)[i] = u32x4{0x00010000u, 0x00030002u, 0x00050004u, 0x00070006u}; }
+    else for (int i = tid; i < N16; i += NW * 64) ((u32x4*)slot)[i] = src[i];
     if (tid < P::NXB * P::PPR) {
       const int b = tid / P::PPR, p = tid % P::PPR;
       *(u32x4*)(L + P::OFF_X + b * P::XB + CAP * P::RB + p * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -297,6 +304,13 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
       }
     auto fetch = [&](int i, u32x4 (&b)[NT], u32x4 (&x)[MT]) {
       const int s = i / P::CH, cc = i % P::CH;
+      if constexpr (SLAB_ABL & 8) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = u32x4{(unsigned)(i + nt), 0x3C003C00u, 0x3C003C00u, (unsigned)lane};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x[mt] = u32x4{xo[s][mt], 0x3C003C00u, (unsigned)cc, (unsigned)lane};
+        return;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) b[nt] = Wl[(i * NT + nt) * 64 + lane];
 #pragma unroll
@@ -304,6 +318,13 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
         x[mt] = *(const u32x4*)(X + (xo[s][mt] & 0xFFFFFu) + (((unsigned)(cc * 4 + g4)) ^ (xo[s][mt] >> 20)) * 16);
     };
     auto mma = [&](const u32x4 (&b)[NT], const u32x4 (&x)[MT]) {
+      if constexpr (SLAB_ABL & 4) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) wt.acc[mt][nt][0] += __uint_as_float(b[nt].x ^ x[mt].x);
+        return;
+      }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -351,21 +372,24 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
   int xb = 0, ws = 0;
 #ifdef BEVAMD_PROFILING
   unsigned long long t_issue = 0, t_mul = 0, t_wait = 0, t_bar = 0, t0, t1;
-#define BEVAMD_TICK(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+  const bool timers = sa.prof != nullptr;   // wave-uniform: without a buffer the ablation runs are not perturbed by s_memtime
+#define BEVAMD_TICK(acc) do { if (timers) { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } } while (0)
   t0 = __builtin_readcyclecounter();
 #else
 #define BEVAMD_TICK(acc) do { } while (0)
 #endif
   for (;;) {
+    if constexpr (SLAB_ABL & 128) break;   // prologue + epilogue only
 #pragma unroll
     for (int g = 0; g < P::GROUPS; ++g) {
       // requests: filter waves ask for the filter of step t + WD; row waves ask — at the first step of a piece — for the rows
       // of the piece DX planes ahead
       int off, gd;
       step_after(g, P::WD, off, gd);
+      constexpr bool do_w = !(SLAB_ABL & 1), do_x = !(SLAB_ABL & 2);
       if (w_role) {
-        if (!sub[off].done) stage_w(sub[off], gd, (ws + P::WD) % WR);
-      } else if (g == 0 && !sub[P::DX].done) {
+        if (do_w && !sub[off].done) stage_w(sub[off], gd, (ws + P::WD) % WR);
+      } else if (do_x && g == 0 && !sub[P::DX].done) {
         stage_x(sub[P::DX], (xb + P::DX) % P::NXB);
       }
       BEVAMD_TICK(t_issue);
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
         wait_x(n_x);
       }
       BEVAMD_TICK(t_wait);
-      barrier_keep_dma();
+      if constexpr (!(SLAB_ABL & 16)) barrier_keep_dma();
       BEVAMD_TICK(t_bar);
       ws = ws + 1 == WR ? 0 : ws + 1;
     }
@@ -406,6 +430,15 @@ __global__ __launch_bounds__(NW * 64) void spconv_slab_kernel(SlabArgs sa) {
   }
 #endif
 #undef BEVAMD_TICK
+  if constexpr (SLAB_ABL & 32) {   // keep the accumulators alive with (at most) one store per wave
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) t += wt.acc[mt][nt][0] + wt.acc[mt][nt][1] + wt.acc[mt][nt][2] + wt.acc[mt][nt][3];
+    if (t == 12345.678f) ((float*)a.out)[0] = t;
+    return;
+  }
   wt.store(a);   // epilogue scratch aliases the X buffers: every wave passed the last barrier, nobody reads X any more
 }
 

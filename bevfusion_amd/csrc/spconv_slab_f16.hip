@@ -18,6 +18,8 @@ extern "C" {
 /* -DBEVAMD_PROFILING builds only: device buffer [5] uint64 (issue, multiply, dma-wait, barrier cycle sums over all waves; wave
  * count) that every following bevamd_spconv_conv_forward_slab launch accumulates into; NULL switches it off. */
 void bevamd_spconv_slab_set_profile_buffer(void* buf) { g_slab_prof = (unsigned long long*)buf; }
+/* the ablation mask this library was COMPILED with (-DBEVAMD_SLAB_ABL=mask; 0 in every shipped build) */
+int bevamd_spconv_slab_ablation_mask(void) { return slab::SLAB_ABL; }
 
 /* Rows per block of slab variant `variant` (0 = default) for a cin-channel SubM 3x3x3 convolution, 0 if none is built
  * (cin must be 32, 64 or 128 and cout == cin).  The block size fixes the metadata layout of bevamd_spconv_slab_build. */

@@ -41,6 +41,10 @@ class NotThisCall(Exception):
 
 _GEOM_STREAMS = {}
 
+# Per-layer profile (bench.py's `roofline_spconv`): set to a list and every fused convolution appends a record with HIP events
+# around its launch and, after a sync, its pair count.  None (default) = no overhead.  Only meaningful in eager passes.
+LAYER_PROFILE = None
+
 
 def geometry_stream(device):
     """The side stream rulebook construction runs on (one per device, created on first use); None when disabled."""
@@ -254,15 +258,46 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
     K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
     out = torch.empty((out_lvl.n_cap, cout), dtype=dtype, device=x.features.device)
     slab_variant = _slab_variant_for(conv, lvl, cin, cout)
+    rec = None
+    if LAYER_PROFILE is not None:
+        torch.cuda.synchronize()          # the rulebook chain (geometry stream) is out of the way: the events bracket the kernel
+        rec = dict(cin=cin, cout=cout, K=K, subm=bool(conv.subm), kernel="slab" if slab_variant is not None else "gather",
+                   variant=slab_variant if slab_variant is not None else _variant_for(lvl.batch, K, cin, cout),
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True),
+                   n_in=lvl.n_dev, n_out=out_lvl.n_dev, n_in_cap=lvl.n_cap, n_out_cap=out_lvl.n_cap, nbr=nbr)
+        rec["start"].record()
     if slab_variant is not None:
         meta = lvl.subm_slab(ops.slab_block_rows(cin, slab_variant))
         ops.sparse_conv_slab(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                              residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out, variant=slab_variant)
-        return FusedTensor(out, out_lvl)
-    ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
-                          residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
-                          variant=_variant_for(lvl.batch, K, cin, cout))
+    else:
+        ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
+                              residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
+                              variant=_variant_for(lvl.batch, K, cin, cout))
+    if rec is not None:
+        rec["end"].record()
+        LAYER_PROFILE.append(rec)
     return FusedTensor(out, out_lvl)
+
+
+def summarize_layer_profile(records, elem_bytes=2):
+    """Per-layer figures of a profiled eager pass: FLOP = 2 * pairs * Cin * Cout, ideal bytes =
+    N_in*Cin*s + pairs*8 + K*Cin*Cout*s + N_out*Cout*s, microseconds from the HIP events, fractions of the dense MFMA peak
+    (16-bit: 2.5 PFLOP/s) and of 8 TB/s."""
+    torch.cuda.synchronize()
+    out = []
+    for r in records:
+        n_in = int(r["n_in"].item()) if r["n_in"] is not None else r["n_in_cap"]
+        n_out = int(r["n_out"].item()) if r["n_out"] is not None else r["n_out_cap"]
+        pairs = int((r["nbr"][:, :n_out] >= 0).sum().item())
+        us = r["start"].elapsed_time(r["end"]) * 1e3
+        flop = 2.0 * pairs * r["cin"] * r["cout"]
+        ideal = n_in * r["cin"] * elem_bytes + pairs * 8 + r["K"] * r["cin"] * r["cout"] * elem_bytes + n_out * r["cout"] * elem_bytes
+        out.append(dict(layer=f"{'subm' if r['subm'] else 'conv'} {r['cin']}->{r['cout']} K={r['K']}", kernel=r["kernel"],
+                        variant=r["variant"], rows_in=n_in, rows_out=n_out, pairs=pairs, us=us, gflop=flop / 1e9,
+                        tflops=flop / (us * 1e-6) / 1e12, frac_mfma_peak=flop / (us * 1e-6) / 2.5e15, ideal_mb=ideal / 1e6,
+                        frac_hbm_peak_on_ideal_bytes=ideal / (us * 1e-6) / 8e12))
+    return out
 
 
 # Tiling per layer shape when a step carries several frames.  The library's own choice (variant 0) is tuned on one frame's row
@@ -388,10 +423,54 @@ def encoder_supported(enc, voxel_features):
 
 
 @torch.no_grad()
-def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None):
+def prepare_geometry(enc, coors, batch_size, num_voxels=None):
+    """Everything of `run_encoder` that depends on voxel COORDINATES only — hash index, every level's active set, neighbour
+    tables, slab metadata — issued on the current stream (and finished there: the geometry stream, if any, is joined back).
+    Returns the level-1 `Level` holding the products; pass it to `SparseEncoder.forward(..., geometry=level)` /
+    `run_encoder(..., geometry=level)`.  Lets a caller run the rulebook chain (latency-bound integer kernels) underneath
+    something else — bench.py runs it, with the voxelizer, beside the HBM-bound camera branch — instead of underneath the
+    encoder's own convolutions."""
+    coors = coors.int().contiguous()
+    n = coors.shape[0]
+    if n == 0:
+        raise NotThisCall("empty input")
+    if num_voxels is not None:
+        num_voxels = num_voxels.reshape(-1)[:1].int().contiguous()
+    dev = coors.device
+    g = geometry_stream(dev)
+    main = torch.cuda.current_stream(dev)
+    if g is not None:
+        g.wait_stream(main)
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g)
+    try:
+        prefetch_geometry(enc, lvl)
+    finally:
+        if g is not None:
+            main.wait_stream(g)
+    # the products are complete on `main` from here on: later consumers need no per-product event
+    _drop_events(lvl)
+    return lvl
+
+
+def _drop_events(lvl):
+    seen = set()
+    while lvl is not None and id(lvl) not in seen:
+        seen.add(id(lvl))
+        lvl.ready = None
+        lvl.gstream = None
+        lvl._subm = {k: (v[0], None) for k, v in lvl._subm.items()}
+        lvl._slab = {k: (v[0], None) for k, v in lvl._slab.items()}
+        nxt = None
+        for out, _ in lvl._down.values():
+            nxt = out
+        lvl = nxt
+
+
+def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometry=None):
     """SparseEncoder.forward on the fused path.  voxel_features [N, C_in] (any float dtype), coors [N, 4] int32
     (batch, x, y, z); `num_voxels` (optional int32 device tensor [1]): live row count when the inputs are
-    capacity-padded buffers straight from the voxelizer (`voxelize_batch(..., sync=False)`)."""
+    capacity-padded buffers straight from the voxelizer (`voxelize_batch(..., sync=False)`); `geometry`: the Level returned
+    by `prepare_geometry` for these coordinates (the rulebook chain is then already built and ordered before this call)."""
     dtype = enc.conv_input[0].weight.dtype
     n = voxel_features.shape[0]
     if n == 0:
@@ -400,6 +479,14 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None):
     pitch = ops.padded_channels(cin)
     feats = torch.zeros((n, pitch), dtype=dtype, device=voxel_features.device)
     feats[:, :cin] = voxel_features
+    if geometry is not None:
+        if geometry.n_cap != n or geometry.batch != int(batch_size):
+            raise RuntimeError("run_encoder: `geometry` was prepared for other inputs")
+        x = FusedTensor(feats, geometry)
+        x = _sequential(enc.conv_input, x)
+        x = _sequential(enc.encoder_layers, x)
+        x = _sequential(enc.conv_out, x)
+        return dense_bev(x)
     coors = coors.int().contiguous()
     if num_voxels is not None:
         num_voxels = num_voxels.reshape(-1)[:1].int().contiguous()

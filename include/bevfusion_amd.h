@@ -437,6 +437,7 @@ int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_s
  *                                                  device int32): bit 0 set if a range overflowed (unsorted rows)
  *   bevamd_spconv_conv_forward_slab                the convolution; `image` as for the tiled entry point */
 void bevamd_spconv_slab_set_profile_buffer(void* buf);  /* only meaningful in -DBEVAMD_PROFILING builds */
+int bevamd_spconv_slab_ablation_mask(void);               /* compile-time ablation mask of this build (0 = shipped kernels) */
 int bevamd_spconv_slab_block_rows(int cin, int variant);
 int bevamd_spconv_slab_variants(int cin, int* codes, int max_n);
 int bevamd_spconv_slab_grid_ok(const int* shape, int block_rows);

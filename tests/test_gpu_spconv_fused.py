@@ -204,3 +204,31 @@ def test_empty_frame_goes_through_and_keeps_the_fused_path_enabled(dev):
         cs = torch.full((100, 4), 7, dtype=torch.int32, device=dev)
         out = enc(xs, cs, 2, num_voxels=torch.zeros(1, dtype=torch.int32, device=dev))
         assert tuple(out.shape) == (2, 64, 5, 5) and float(out.abs().max()) == 0.0 and enc.fused_inference
+
+
+def test_prepared_geometry_path_is_bit_identical(dev):
+    """`enc.prepare_geometry(coors, B, num_voxels)` ahead of time + `enc(..., geometry=lvl)` == the one-call fused forward, also with
+    the geometry built on ANOTHER stream than the convolutions (how bench.py overlaps it with the camera branch)."""
+    rng = np.random.default_rng(9)
+    B, shape = 2, (40, 40, 41)
+    coors = _coords(rng, B, shape, 2600)
+    n, cap = coors.shape[0], 6000
+    enc = _small_encoder(dev, torch.float16)
+    xp = torch.zeros((cap, 5), device=dev)
+    xp[:n] = torch.from_numpy(rng.standard_normal((n, 5)).astype(np.float32)).to(dev)
+    cp = torch.full((cap, 4), 77777, dtype=torch.int32, device=dev)
+    cp[:n] = torch.from_numpy(coors).to(dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        want = enc(xp, cp, B, num_voxels=cnt)
+        lvl = enc.prepare_geometry(cp, B, num_voxels=cnt)
+        got = enc(xp, cp, B, num_voxels=cnt, geometry=lvl)
+        assert enc.last_path == "fused" and torch.equal(got, want)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            lvl2 = enc.prepare_geometry(cp, B, num_voxels=cnt)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(enc(xp, cp, B, num_voxels=cnt, geometry=lvl2), want)
+        with pytest.raises(RuntimeError):
+            enc(xp[:100], cp[:100], B, num_voxels=cnt, geometry=lvl)

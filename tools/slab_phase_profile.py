@@ -26,7 +26,7 @@ for cout, ks, st, pd in [(32, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (64, (3, 3, 3), 
     f = torch.randn(ind.shape[0], c, device=dev).half()
     w = (torch.randn(27, c, c, device=dev) / (27 * c) ** 0.5).half()
     img = sops.make_filter_image(w.view(27, 1, 1, c, c))
-    for v in sops.slab_variants(c):
+    for v in (sops.slab_variants(c) if os.environ.get("SLAB_PHASES") == "1" else []):
         meta = sops.slab_build(rb.nbr, rb.num_out, None, sops.slab_block_rows(c, v))
         sops.sparse_conv_slab(f, img, meta, rb.num_out, c, c, variant=v)
         prof = torch.zeros(8, dtype=torch.int64, device=dev)
@@ -42,3 +42,17 @@ for cout, ks, st, pd in [(32, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (64, (3, 3, 3), 
         tot = sum(p[:4])
         print(f"{c:3d}->{c:<3d} variant {v}: {s.elapsed_time(e) * 1e3:7.1f} us (timers on); per wave: issue {p[0] / waves:8.0f}  multiply {p[1] / waves:8.0f}  "
               f"dma-wait {p[2] / waves:8.0f}  barrier {p[3] / waves:8.0f} cycles  ({100 * p[0] / tot:.0f} / {100 * p[1] / tot:.0f} / {100 * p[2] / tot:.0f} / {100 * p[3] / tot:.0f} %)")
+
+    # compile-time ablation (tools/slab_ablation.sh rebuilds the library per mask): time the default variant of this build
+    mask = lib.bevamd_spconv_slab_ablation_mask()
+    v = sops.slab_variants(c)[0]
+    meta = sops.slab_build(rb.nbr, rb.num_out, None, sops.slab_block_rows(c, v))
+    for _ in range(3):
+        sops.sparse_conv_slab(f, img, meta, rb.num_out, c, c, variant=v)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10):
+        sops.sparse_conv_slab(f, img, meta, rb.num_out, c, c, variant=v)
+    e.record()
+    e.synchronize()
+    print(f"ABL mask {mask:3d}  {c}->{c} variant {v}: {s.elapsed_time(e) * 100:7.1f} us")
