@@ -117,6 +117,19 @@ int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_ou
 int radix_sort_pairs_u32_ex(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n,
                             int nbits, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t** result_keys,
                             uint32_t** result_vals);
+// Segmented sort: up to SORT_MAX_SEGS independent arrays laid end to end, each stably sorted on its own by the launches of
+// one sort (a batch of LiDAR sweeps).  The table travels as a kernel argument.
+constexpr int SORT_MAX_SEGS = 64;
+struct SortSegs {
+  int nseg;
+  uint32_t off[SORT_MAX_SEGS + 1];  // element range of segment s: [off[s], off[s+1])
+  uint32_t blk[SORT_MAX_SEGS + 1];  // workgroup range of segment s
+};
+int sort_segs_init(SortSegs& sg, const int* counts, int nseg);
+size_t radix_sort_segmented_workspace_bytes(const SortSegs& sg);
+int radix_sort_pairs_u32_segmented(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
+                                   const SortSegs& sg, int nbits, void* ws, size_t ws_bytes, hipStream_t stream,
+                                   uint32_t** result_keys, uint32_t** result_vals);
 // fill / copy of 32-bit words as ordinary kernels (captured as kernel nodes in HIP graphs)
 int device_fill_u32(uint32_t* p, size_t n, uint32_t v, hipStream_t stream);
 int device_copy_u32(uint32_t* d, const uint32_t* s, size_t n, hipStream_t stream);

@@ -312,34 +312,64 @@ constexpr int RS_MAX_BINS = 1 << RS_MAX_BITS;
 
 // hist element (digit d, workgroup b) lives at d * sd + b * sb: digit-major (sd = nblocks, sb = 1) for the generic
 // flat scan, block-major (sd = 1, sb = nbins) for the single-launch scan (coalesced for every kernel that touches it)
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
-                                                                int shift, int bits, unsigned sd, unsigned sb,
-                                                                uint32_t* __restrict__ hist) {
+//
+// Both kernels are written over one tile [base, end) whose digit counters sit at hcol[d * sd]; the plain sort maps
+// workgroup -> tile by blockIdx.x, the segmented sort (several independent arrays, one launch) through a SortSegs table.
+__device__ __forceinline__ void radix_hist_tile(const uint32_t* __restrict__ keys, size_t base, size_t end, int shift,
+                                                int bits, unsigned sd, uint32_t* __restrict__ hcol) {
   __shared__ unsigned lh[RS_MAX_BINS];
   const unsigned nbins = 1u << bits, mask = nbins - 1u;
   for (unsigned i = threadIdx.x; i < nbins; i += RS_THREADS) lh[i] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * RS_TILE;
 #pragma unroll 4
   for (int i = 0; i < RS_TILE / RS_THREADS; ++i) {
     size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&lh[(keys[idx] >> shift) & mask], 1u);
+    if (idx < end) atomicAdd(&lh[(keys[idx] >> shift) & mask], 1u);
   }
   __syncthreads();
-  for (unsigned i = threadIdx.x; i < nbins; i += RS_THREADS) hist[(size_t)i * sd + (size_t)blockIdx.x * sb] = lh[i];
+  for (unsigned i = threadIdx.x; i < nbins; i += RS_THREADS) hcol[(size_t)i * sd] = lh[i];
 }
 
-__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n,
+                                                                int shift, int bits, unsigned sd, unsigned sb,
+                                                                uint32_t* __restrict__ hist) {
+  radix_hist_tile(keys, (size_t)blockIdx.x * RS_TILE, n, shift, bits, sd, hist + (size_t)blockIdx.x * sb);
+}
+
+// Segment s owns elements [off[s], off[s+1]) and workgroups [blk[s], blk[s+1]); its histogram block starts at
+// blk[s] << bits, digit-major over its own workgroups.  A flat exclusive scan of the concatenated histograms is then
+// the destination of every (segment, digit, workgroup) run in the concatenated output: everything before segment s
+// sums to off[s].
+struct SegTile { size_t base, end; unsigned sd; size_t hcol; };
+__device__ __forceinline__ SegTile seg_tile(const SortSegs& sg, int bits) {
+  int s = 0;
+  while (s + 1 < sg.nseg && blockIdx.x >= sg.blk[s + 1]) ++s;
+  const unsigned lb = blockIdx.x - sg.blk[s];
+  SegTile t;
+  t.base = (size_t)sg.off[s] + (size_t)lb * RS_TILE;
+  t.end = sg.off[s + 1];
+  t.sd = sg.blk[s + 1] - sg.blk[s];
+  t.hcol = ((size_t)sg.blk[s] << bits) + lb;
+  return t;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_seg_kernel(const uint32_t* __restrict__ keys, SortSegs sg,
+                                                                    int shift, int bits, uint32_t* __restrict__ hist) {
+  const SegTile t = seg_tile(sg, bits);
+  radix_hist_tile(keys, t.base, t.end, shift, bits, t.sd, hist + t.hcol);
+}
+
+__device__ __forceinline__ void radix_scatter_tile(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift, int bits,
-    unsigned sd, unsigned sb, const uint32_t* __restrict__ hist_scanned) {
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t tile_base, size_t n, int shift, int bits,
+    unsigned sd, const uint32_t* __restrict__ hcol) {
   __shared__ unsigned cnt[4][RS_MAX_BINS];  // per-wave running digit counters -> later: bases
   const unsigned nbins = 1u << bits, mask = nbins - 1u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (unsigned i = threadIdx.x; i < 4 * RS_MAX_BINS; i += RS_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
 
-  const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)wave * RS_WAVE_CHUNK;
+  const size_t wbase = tile_base + (size_t)wave * RS_WAVE_CHUNK;
   uint32_t k[RS_ROUNDS], v[RS_ROUNDS];
   unsigned short rnk[RS_ROUNDS];
   const unsigned long long lt = lanemask_lt();
@@ -372,7 +402,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   __syncthreads();
   // per-digit exclusive prefix over the 4 waves + global base of (digit, block)
   for (unsigned d = threadIdx.x; d < nbins; d += RS_THREADS) {
-    unsigned g = hist_scanned[(size_t)d * sd + (size_t)blockIdx.x * sb];
+    unsigned g = hcol[(size_t)d * sd];
     unsigned c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d];
     cnt[0][d] = g;
     cnt[1][d] = g + c0;
@@ -390,6 +420,22 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       vals_out[dst] = v[r];
     }
   }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift, int bits,
+    unsigned sd, unsigned sb, const uint32_t* __restrict__ hist_scanned) {
+  radix_scatter_tile(keys_in, vals_in, keys_out, vals_out, (size_t)blockIdx.x * RS_TILE, n, shift, bits, sd,
+                     hist_scanned + (size_t)blockIdx.x * sb);
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_seg_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, SortSegs sg, int shift, int bits,
+    const uint32_t* __restrict__ hist_scanned) {
+  const SegTile t = seg_tile(sg, bits);
+  radix_scatter_tile(keys_in, vals_in, keys_out, vals_out, t.base, t.end, shift, bits, t.sd, hist_scanned + t.hcol);
 }
 
 size_t radix_sort_workspace_bytes(size_t n) {
@@ -488,6 +534,81 @@ int radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_ou
   return rc;
 }
 
+// Segmented variant: sg.nseg independent arrays laid end to end (segment s = elements [off[s], off[s+1])), each sorted
+// on its own — stable, on the low nbits — by the launches of one sort.  Values are whatever the caller stored (local
+// indices, usually).  The result is in (*result_keys, *result_vals) like radix_sort_pairs_u32_ex.
+int sort_segs_init(SortSegs& sg, const int* counts, int nseg) {
+  if (nseg < 1 || nseg > SORT_MAX_SEGS) {
+    set_error("segmented sort: %d segments (1..%d supported)", nseg, SORT_MAX_SEGS);
+    return BEVAMD_ERR_INVALID_ARG;
+  }
+  sg.nseg = nseg;
+  sg.off[0] = 0;
+  sg.blk[0] = 0;
+  unsigned long long tot = 0;
+  for (int s = 0; s < nseg; ++s) {
+    if (counts[s] < 0) {
+      set_error("segmented sort: negative count");
+      return BEVAMD_ERR_INVALID_ARG;
+    }
+    tot += (unsigned long long)counts[s];
+    if (tot >= (1ull << 32)) {
+      set_error("segmented sort: more than 2^32 elements");
+      return BEVAMD_ERR_INVALID_ARG;
+    }
+    sg.off[s + 1] = (uint32_t)tot;
+    sg.blk[s + 1] = sg.blk[s] + (uint32_t)(((size_t)counts[s] + RS_TILE - 1) / RS_TILE);
+  }
+  return BEVAMD_OK;
+}
+
+size_t radix_sort_segmented_workspace_bytes(const SortSegs& sg) {
+  size_t nblocks = sg.blk[sg.nseg] ? sg.blk[sg.nseg] : 1;
+  size_t hist = align_up(nblocks * RS_MAX_BINS * sizeof(uint32_t), 256);
+  return hist + scan_workspace_bytes(nblocks * RS_MAX_BINS);
+}
+
+int radix_sort_pairs_u32_segmented(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
+                                   const SortSegs& sg, int nbits, void* ws, size_t ws_bytes, hipStream_t stream,
+                                   uint32_t** result_keys, uint32_t** result_vals) {
+  *result_keys = keys_a;
+  *result_vals = vals_a;
+  const unsigned nblocks = sg.blk[sg.nseg];
+  if (nblocks == 0) return BEVAMD_OK;
+  if (nbits < 1) nbits = 1;
+  if (nbits > 32) nbits = 32;
+  if (ws == nullptr || ws_bytes < radix_sort_segmented_workspace_bytes(sg)) {
+    set_error("radix_sort_pairs_u32_segmented: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  uint32_t* hist = (uint32_t*)ws;
+  size_t hist_bytes = align_up((size_t)nblocks * RS_MAX_BINS * sizeof(uint32_t), 256);
+  void* scan_ws = (char*)ws + hist_bytes;
+  size_t scan_ws_bytes = ws_bytes - hist_bytes;
+  const int npass = (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  const int bits_per_pass = (nbits + npass - 1) / npass;
+  uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
+  int shift = 0;
+  for (int p = 0; p < npass; ++p) {
+    int bits = bits_per_pass;
+    if (shift + bits > nbits) bits = nbits - shift;
+    if (bits <= 0) bits = 1;
+    radix_hist_seg_kernel<<<nblocks, RS_THREADS, 0, stream>>>(ki, sg, shift, bits, hist);
+    BEVAMD_LAUNCH_CHECK("radix_hist_seg");
+    int rc = exclusive_scan_u32(hist, hist, (size_t)nblocks << bits, nullptr, scan_ws, scan_ws_bytes, stream);
+    if (rc != BEVAMD_OK) return rc;
+    radix_scatter_seg_kernel<<<nblocks, RS_THREADS, 0, stream>>>(ki, vi, ko, vo, sg, shift, bits, hist);
+    BEVAMD_LAUNCH_CHECK("radix_scatter_seg");
+    uint32_t* t;
+    t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+    shift += bits;
+  }
+  *result_keys = ki;
+  *result_vals = vi;
+  return BEVAMD_OK;
+}
+
 }  // namespace bevamd
 
 // ---- C-ABI test hooks for the primitives (used by tests/ only) --------------
@@ -505,5 +626,30 @@ int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* 
                                 void* stream) {
   return bevamd::radix_sort_pairs_u32(keys_in, vals_in, keys_out, vals_out, n, nbits, ws, ws_bytes,
                                       (hipStream_t)stream);
+}
+size_t bevamd_radix_sort_segmented_workspace_bytes(const int* counts, int nseg) {
+  bevamd::SortSegs sg;
+  if (!counts || bevamd::sort_segs_init(sg, counts, nseg) != BEVAMD_OK) return 0;
+  return bevamd::radix_sort_segmented_workspace_bytes(sg);
+}
+int bevamd_radix_sort_pairs_u32_segmented(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                                          const int* counts, int nseg, int nbits, void* ws, size_t ws_bytes, void* stream) {
+  bevamd::SortSegs sg;
+  if (!counts) {
+    bevamd::set_error("radix_sort_pairs_u32_segmented: counts is null (host array)");
+    return BEVAMD_ERR_INVALID_ARG;
+  }
+  int rc = bevamd::sort_segs_init(sg, counts, nseg);
+  if (rc) return rc;
+  uint32_t *rk, *rv;
+  rc = bevamd::radix_sort_pairs_u32_segmented(keys_in, vals_in, keys_out, vals_out, sg, nbits, ws, ws_bytes,
+                                              (hipStream_t)stream, &rk, &rv);
+  if (rc) return rc;
+  if (rk != keys_out) {
+    rc = bevamd::device_copy_u32(keys_out, rk, sg.off[nseg], (hipStream_t)stream);
+    if (rc) return rc;
+    rc = bevamd::device_copy_u32(vals_out, rv, sg.off[nseg], (hipStream_t)stream);
+  }
+  return rc;
 }
 }

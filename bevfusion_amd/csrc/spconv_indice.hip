@@ -25,6 +25,7 @@
 //     order is atomicAdd order, i.e. unspecified).
 // Offset numbering: offset = (kx*Ky + ky)*Kz + kz with k = in - out*stride + pad (geometry.h:67-69).
 #include "common.h"
+#include "spconv_slab_meta.h"
 
 namespace bevamd {
 
@@ -680,6 +681,42 @@ static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const 
   return BEVAMD_OK;
 }
 
+// Slab metadata of the 3x3x3 SubM convolution straight from the index of the voxel set: thread t of block b looks its 27
+// neighbour cells up itself (one 8-byte rank-index load each; the three kz taps of a (kx, ky) line sit in the same or the
+// next word) and the block emits (range, slots) — the int32 table nbr [27, N] (108 B per row written by the neighbour
+// kernel, read back by slab_build_kernel) never exists.
+template <int BM, int KIND>
+__global__ __launch_bounds__(BM) void sp_slab_from_index_kernel(const int* __restrict__ indices, int m_cap,
+                                                                const int* __restrict__ m_dev, ConvGeom g, IndexRef ix,
+                                                                int2* __restrict__ hdr, uint16_t* __restrict__ slots,
+                                                                int* __restrict__ status) {
+  int m = m_dev ? *m_dev : m_cap;
+  if (m > m_cap) m = m_cap;
+  const int blk = blockIdx.x, t = threadIdx.x, row = blk * BM + t;
+  const bool live = row < m;
+  const int4 c = live ? ((const int4*)indices)[row] : make_int4(0, 0, 0, 0);
+  int v[27];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        const int k = (kx * 3 + ky) * 3 + kz;
+        const int x = c.y - 1 + kx, y = c.z - 1 + ky, z = c.w - 1 + kz;
+        int r = -1;
+        if (k == 13) {
+          r = live ? row : -1;
+        } else if (live && x >= 0 && x < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && z >= 0 && z < g.in_shape[2]) {
+          const uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + x) * g.in_shape[1] + y) * g.in_shape[2] + z);
+          r = index_lookup<KIND>(ix, (uint32_t)c.x, key);
+          if (r >= m) r = -1;
+        }
+        v[k] = r;
+      }
+  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+}
+
 }  // namespace bevamd
 
 using namespace bevamd;
@@ -914,6 +951,34 @@ int bevamd_spconv_transpose_nbr(const int* nbr, int nbr_stride, int m, int kerne
   sp_transpose_nbr_kernel<<<dim3(cdiv(m, 256), kernel_volume), dim3(256), 0, stream>>>(nbr, nbr_stride, m, nbr_t,
                                                                                        nbr_t_stride);
   BEVAMD_LAUNCH_CHECK("sp_transpose_nbr");
+  return BEVAMD_OK;
+}
+
+/* Slab metadata (bevamd_spconv_slab_build's hdr / slots, same layout and contents) of the 3x3x3 submanifold convolution
+ * over the voxel set `indices` [m, 4] (b, x, y, z) on grid `shape`, computed from the set's own index (index_kind /
+ * index / index_n_cap as for bevamd_spconv_neighbors) without building the neighbour table.  The caller vouches that the
+ * rows are in ascending linear index (what the slab kernels need anyway). */
+int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int* m_dev, int batch_size, const int* shape,
+                                        int index_kind, const void* index, int index_n_cap, int block_rows, void* hdr,
+                                        void* slots, int* status, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvGeom g;
+  const int k3[3] = {3, 3, 3}, one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+  int rc = make_geom(batch_size, shape, shape, k3, one, zero, nullptr, 1, g);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(block_rows == 128 || block_rows == 256, "spconv_slab_build_from_index: block_rows %d (128 | 256)", block_rows);
+  BEVAMD_REQUIRE(index_kind == INDEX_HASH || index_kind == INDEX_RANK, "spconv_slab_build_from_index: index_kind %d", index_kind);
+  BEVAMD_REQUIRE(m_cap >= 0, "spconv_slab_build_from_index: bad sizes");
+  if (m_cap == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(indices && index && hdr && slots, "spconv_slab_build_from_index: null buffer");
+  const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(index, index_n_cap, batch_size) : rank_ref(index);
+  const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows);
+#define BEVAMD_GO(BM, KIND) \
+  sp_slab_from_index_kernel<BM, KIND><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix, (int2*)hdr, (uint16_t*)slots, status)
+  if (block_rows == 128) { if (index_kind == INDEX_HASH) BEVAMD_GO(128, INDEX_HASH); else BEVAMD_GO(128, INDEX_RANK); }
+  else { if (index_kind == INDEX_HASH) BEVAMD_GO(256, INDEX_HASH); else BEVAMD_GO(256, INDEX_RANK); }
+#undef BEVAMD_GO
+  BEVAMD_LAUNCH_CHECK("sp_slab_from_index");
   return BEVAMD_OK;
 }
 

@@ -29,6 +29,7 @@
 // 9.05 * Cin * 2 B per row (L2 -> LDS), filter traffic 27 * Cin * Cout * 2 B per block.
 #pragma once
 #include "spconv_tile.h"
+#include "spconv_slab_meta.h"
 
 namespace bevamd {
 namespace slab {
@@ -40,9 +41,6 @@ using namespace tile;
 #endif
 constexpr int SLAB_ABL = BEVAMD_SLAB_ABL;   // 1 no filter DMA, 2 no row DMA, 4 no MFMA, 8 no fragment reads, 16 no barrier, 32 no epilogue stores,
                                             // 64 no slot-table load, 128 no main loop, 256 launch only
-constexpr int PLANES = 3;         // kx planes of the 3x3x3 kernel: the 9 (ky, kz) taps of a plane share one staged range
-constexpr int TAPS = 9;           // taps per plane
-constexpr unsigned NO_SLOT = 0xFFFFu;
 
 struct SlabArgs {
   Args a;                    // features, filter image, epilogue operands (nbr is unused)
@@ -51,59 +49,6 @@ struct SlabArgs {
   unsigned wimg_bytes;       // size of the filter image (buffer descriptor bound)
   unsigned long long* prof;  // -DBEVAMD_PROFILING builds: [4] cycle sums over all waves (issue, multiply, dma wait, barrier) + [4] = waves
 };
-
-// ---- metadata -----------------------------------------------------------------------------------------------------
-// One workgroup (BM threads) per block of BM output rows.
-template <int BM>
-__global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ nbr, int nbr_stride, int m_cap,
-                                                        const int* __restrict__ m_dev, int2* __restrict__ hdr,
-                                                        uint16_t* __restrict__ slots, int* __restrict__ status) {
-  __shared__ int s_lo[BM / 64][PLANES], s_hi[BM / 64][PLANES];
-  int m = m_dev ? *m_dev : m_cap;
-  if (m > m_cap) m = m_cap;
-  const int blk = blockIdx.x, t = threadIdx.x, row = blk * BM + t;
-  const bool live = row < m;
-  int v[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) v[k] = live ? nbr[(size_t)k * nbr_stride + row] : -1;
-  const int w = t >> 6;
-#pragma unroll
-  for (int j = 0; j < PLANES; ++j) {
-    int lo = 0x7FFFFFFF, hi = -1;
-#pragma unroll
-    for (int d = 0; d < TAPS; ++d) {
-      const int x = v[j * TAPS + d];
-      if (x >= 0) { lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-      lo = l2 < lo ? l2 : lo;
-      hi = h2 > hi ? h2 : hi;
-    }
-    if ((t & 63) == 0) { s_lo[w][j] = lo; s_hi[w][j] = hi; }
-  }
-  __syncthreads();
-  bool overflow = false;
-#pragma unroll
-  for (int j = 0; j < PLANES; ++j) {
-    int lo = 0x7FFFFFFF, hi = -1;
-#pragma unroll
-    for (int i = 0; i < BM / 64; ++i) { lo = s_lo[i][j] < lo ? s_lo[i][j] : lo; hi = s_hi[i][j] > hi ? s_hi[i][j] : hi; }
-    int cnt = hi >= 0 ? hi - lo + 1 : 0;
-    if (hi < 0) lo = 0;
-    if (cnt > 0xFFFE) { cnt = 0xFFFE; overflow = true; }   // cannot happen for rows in linear-index order on grids the host admits
-    if (t == 0) hdr[(size_t)blk * PLANES + j] = make_int2(lo, cnt);
-#pragma unroll
-    for (int d = 0; d < TAPS; ++d) {
-      const int k = j * TAPS + d, x = v[k];
-      unsigned s = NO_SLOT;
-      if (x >= 0 && x - lo < cnt) s = (unsigned)(x - lo);
-      slots[((size_t)blk * 27 + k) * BM + t] = (uint16_t)s;
-    }
-  }
-  if (overflow && t == 0 && status) atomicOr(status, 1);
-}
 
 // ---- LDS plan ------------------------------------------------------------------------------------------------------
 template <int KC> struct RowSwz;   // XOR applied to the 16-byte piece index of LDS row r (rows are KC*2 bytes)

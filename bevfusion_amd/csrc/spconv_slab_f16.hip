@@ -24,16 +24,17 @@ int bevamd_spconv_slab_ablation_mask(void) { return slab::SLAB_ABL; }
 /* Rows per block of slab variant `variant` (0 = default) for a cin-channel SubM 3x3x3 convolution, 0 if none is built
  * (cin must be 32, 64 or 128 and cout == cin).  The block size fixes the metadata layout of bevamd_spconv_slab_build. */
 int bevamd_spconv_slab_block_rows(int cin, int variant) {
-  const slab::Shape* s = slab::find_shape(cin, variant);
-  return s ? s->nw * 16 * s->mt : 0;
+  return slab::block_rows_of(cin, variant);
 }
 
 /* The variant codes built for `cin` (for sweeps): writes up to max_n codes, returns how many exist. */
 int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
-  int n = 0;
+  int n = 0, nr = 0;
   const slab::Shape* s = slab::shapes_of(cin, &n);
+  const slab::ShapeR* r = slab::shapes_r_of(cin, &nr);
   for (int i = 0; s && i < n && i < max_n; ++i) codes[i] = slab::variant_code(s[i]);
-  return n;
+  for (int i = 0; r && i < nr && n + i < max_n; ++i) codes[n + i] = slab::variant_code(r[i]);
+  return n + nr;
 }
 
 /* 1 if a voxel set on a [batch, X, Y, Z] grid whose rows are in ascending linear index can use the slab kernels: the input

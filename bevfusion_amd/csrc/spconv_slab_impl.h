@@ -1,6 +1,7 @@
 // Per-dtype instantiation of the slab (staged-rows) submanifold convolution (included by spconv_slab_{f16,bf16}.hip).
 #pragma once
 #include "spconv_slab.h"
+#include "spconv_slab_regw.h"
 
 namespace bevamd {
 namespace slab {
@@ -64,8 +65,91 @@ static inline const Shape* find_shape(int cin, int variant) {
   return nullptr;
 }
 
+// ---- register-filter kernels (spconv_slab_regw.h): variant = 1000000 + KC*10000 + MT*1000 + RW*100 + CW*10 + ID ----------
+struct ShapeR { int kc, mt, rw, cw, cap, id; };
+
+template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP>
+static int run_r(const SlabArgs& sa, hipStream_t stream) {
+  typedef PlanR<KC, CIN, NT, MT, RW, CW, CAP> P;
+  static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
+  auto kern = &spconv_slabr_kernel<DT, KC, CIN, NT, MT, RW, CW, CAP>;
+  if (P::BYTES > 65536) {
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+      raised = true;
+    }
+  }
+  const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
+  const long long blocks = (nblk + 7) / 8 * 8;
+  kern<<<dim3((unsigned)blocks), dim3(P::NW * 64), P::BYTES, stream>>>(sa);
+  BEVAMD_LAUNCH_CHECK("spconv_slabr");
+  return BEVAMD_OK;
+}
+
+#define BEVAMD_SLABR_SHAPES_32(X) X(32, 4, 2, 1, 192, 0) X(32, 4, 4, 1, 384, 0) X(32, 2, 4, 1, 192, 0)
+#define BEVAMD_SLABR_SHAPES_64(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 2, 2, 152, 1) X(64, 2, 4, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 1, 152, 0)
+#define BEVAMD_SLABR_SHAPES_128(X) X(64, 4, 2, 2, 184, 0) X(64, 2, 4, 2, 184, 0) X(64, 4, 2, 4, 184, 0) X(64, 4, 4, 2, 320, 0)
+
+static inline const ShapeR* shapes_r_of(int cin, int* n) {
+#define BEVAMD_ROW(KC, MT, RW, CW, CAP, ID) {KC, MT, RW, CW, CAP, ID},
+  static const ShapeR s32[] = {BEVAMD_SLABR_SHAPES_32(BEVAMD_ROW)};
+  static const ShapeR s64[] = {BEVAMD_SLABR_SHAPES_64(BEVAMD_ROW)};
+  static const ShapeR s128[] = {BEVAMD_SLABR_SHAPES_128(BEVAMD_ROW)};
+#undef BEVAMD_ROW
+  switch (cin) {
+    case 32: *n = (int)(sizeof(s32) / sizeof(ShapeR)); return s32;
+    case 64: *n = (int)(sizeof(s64) / sizeof(ShapeR)); return s64;
+    case 128: *n = (int)(sizeof(s128) / sizeof(ShapeR)); return s128;
+    default: *n = 0; return nullptr;
+  }
+}
+constexpr int REGW_BASE = 1000000;
+static inline int variant_code(const ShapeR& s) { return REGW_BASE + s.kc * 10000 + s.mt * 1000 + s.rw * 100 + s.cw * 10 + s.id; }
+static inline const ShapeR* find_shape_r(int cin, int variant) {
+  int n = 0;
+  const ShapeR* s = shapes_r_of(cin, &n);
+  for (int i = 0; s && i < n; ++i)
+    if (variant_code(s[i]) == variant) return s + i;
+  return nullptr;
+}
+// rows per block of any variant code (0 = none built)
+static inline int block_rows_of(int cin, int variant) {
+  if (variant >= REGW_BASE) {
+    const ShapeR* r = find_shape_r(cin, variant);
+    return r ? r->rw * 16 * r->mt : 0;
+  }
+  const Shape* s = find_shape(cin, variant);
+  return s ? s->nw * 16 * s->mt : 0;
+}
+
+template <int DT>
+int launch_r_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t stream) {
+  const ShapeR* s = find_shape_r(cin, variant);
+  if (!s || nt != cin / 16) {
+    set_error("spconv slab: no register-filter kernel for cin=%d, cout tiles=%d, variant=%d", cin, nt, variant);
+    return BEVAMD_ERR_UNSUPPORTED;
+  }
+#define BEVAMD_CASE32(KC, MT, RW, CW, CAP, ID) \
+  if (cin == 32 && variant == REGW_BASE + KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID) return run_r<DT, KC, 32, 2, MT, RW, CW, CAP>(sa, stream);
+#define BEVAMD_CASE64(KC, MT, RW, CW, CAP, ID) \
+  if (cin == 64 && variant == REGW_BASE + KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID) return run_r<DT, KC, 64, 4, MT, RW, CW, CAP>(sa, stream);
+#define BEVAMD_CASE128(KC, MT, RW, CW, CAP, ID) \
+  if (cin == 128 && variant == REGW_BASE + KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID) return run_r<DT, KC, 128, 8, MT, RW, CW, CAP>(sa, stream);
+  BEVAMD_SLABR_SHAPES_32(BEVAMD_CASE32)
+  BEVAMD_SLABR_SHAPES_64(BEVAMD_CASE64)
+  BEVAMD_SLABR_SHAPES_128(BEVAMD_CASE128)
+#undef BEVAMD_CASE32
+#undef BEVAMD_CASE64
+#undef BEVAMD_CASE128
+  set_error("spconv slab: variant %d is listed but not built for cin=%d", variant, cin);
+  return BEVAMD_ERR_UNSUPPORTED;
+}
+
 template <int DT>
 int launch_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t stream) {
+  if (variant >= REGW_BASE) return launch_r_impl<DT>(sa, cin, nt, variant, stream);
   const Shape* s = find_shape(cin, variant);
   if (!s || nt != cin / 16) {
     set_error("spconv slab: no kernel for cin=%d, cout tiles=%d, variant=%d", cin, nt, variant);

@@ -1,0 +1,237 @@
+// Staged-rows submanifold convolution, second cut: filter fragments in REGISTERS, no barrier inside a kernel plane.
+//
+// spconv_slab.h stages the rows of a kernel plane AND the filter of every tap in LDS; each tap then costs a filter DMA, a
+// counted wait and a workgroup barrier, and 8 of a wave's 12 fragment reads per tap are filter fragments.  The compile-time
+// ablation (profiles/r02_slab_ablation.txt) shows a latency-serial kernel: with a barrier every 16 MFMAs nothing overlaps.
+//
+// Here the workgroup's waves form an RW x CW grid: wave (r, c) owns 16*MT rows x (Cout / CW) output channels.  The filter
+// image is already in MFMA-fragment order (1 KiB per (tap, 32-channel chunk, 16 output channels)), so a wave loads ITS
+// fragments of a tap with NTW*CH coalesced 16-byte buffer loads straight into registers, two taps ahead (a three-set register
+// ring, static indices after unrolling the 9 taps of a plane); every filter byte crosses the L1 RW times per block
+// instead of going through LDS.  Only the staged rows live in LDS (same LDS-DMA, same swizzle, same slot table and block
+// headers as spconv_slab.h — slab_build_kernel is shared), so the ONLY workgroup barrier left is the one that switches
+// planes (3 per block, + pieces).  Row fragments are software-pipelined across the taps of a plane: the ds_read_b128 of
+// unit i+1 are issued before the MFMAs of unit i, so one LDS round trip is exposed per plane, not per tap.
+//
+// Summation order per output element is unchanged (kernel offset ascending, then 32-channel chunk): results are
+// bit-identical to spconv_slab.h and, for Cin <= 64, to the gather kernels.
+#pragma once
+#include "spconv_slab.h"
+
+namespace bevamd {
+namespace slab {
+
+// KC  channels staged per row (32 | 64; CIN / KC passes)      MT  16-row tiles per wave
+// RW  wave rows, CW wave columns (block = RW*16*MT rows)       CAP rows of one X buffer
+template <int KC, int CIN, int NT, int MT, int RW, int CW, int CAP>
+struct PlanR {
+  static_assert(KC == 32 || KC == 64, "staged row = 32 or 64 channels");
+  static_assert(CIN % KC == 0 && NT % CW == 0, "bad split");
+  static constexpr int NW = RW * CW;
+  static constexpr int BM = RW * 16 * MT;
+  static constexpr int NTW = NT / CW;               // 16-channel output tiles per wave
+  static constexpr int RB = KC * 2;                 // staged bytes per row
+  static constexpr int PPR = RB / 16;               // 16-byte pieces per row
+  static constexpr int RPI = 64 / PPR;              // rows per DMA instruction (1 KiB)
+  static constexpr int CH = KC / 32;                // 32-channel chunks per staged row
+  static constexpr int CPB = CIN / 32;              // chunks per kernel offset in the filter image
+  static constexpr int NH = CIN / KC;               // channel passes
+  static constexpr int NB = NTW * CH;               // filter fragments (16 B per lane) per tap per wave
+  static constexpr int WD = 2;                      // taps of filter lookahead (ring of WD + 1 register sets; 9 % (WD + 1) == 0)
+  static constexpr int NXB = 2;                     // X buffers: this piece and the next
+  static constexpr int XB = ((CAP + 1) * RB + 1023) / 1024 * 1024;   // one X buffer incl. the zero row, KiB-aligned
+  static constexpr int PX = CAP / RPI;              // 1 KiB DMA pieces of a full X buffer
+  static constexpr int NX = (PX + NW - 1) / NW;     // ... per wave: a FIXED count, so that s_waitcnt can count
+  static constexpr int OFF_X = 0;
+  static constexpr int OFF_SLOT = NXB * XB;
+  static constexpr int OFF_DUMP = OFF_SLOT + 27 * BM * 2;   // landing zone of the dummy pieces
+  static constexpr int BYTES = OFF_DUMP + 1024;
+  static_assert(NW * EpiScratch<NTW>::U4 * 16 <= NXB * XB, "epilogue scratch must fit the X buffers it aliases");
+  static_assert(CAP % RPI == 0, "CAP must be a whole number of DMA instructions");
+  static_assert((CAP + 1) * RB < 65536, "row offsets are 16-bit");
+  static_assert(WD * NB + NX < 60, "vmcnt is a 6-bit counter");
+  static_assert(TAPS % (WD + 1) == 0, "register ring must close over a plane");
+};
+
+template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP>
+__global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa) {
+  typedef PlanR<KC, CIN, NT, MT, RW, CW, CAP> P;
+  typedef WaveTile<DT, (CIN > 64 ? 64 : CIN), P::NTW, MT, (CIN > 64 ? 64 : CIN) / 32> WT;   // accumulators + epilogue only
+  typedef typename Num<DT>::T T;
+  extern __shared__ u32x4 lds[];
+  char* const L = (char*)lds;
+  const Args& a = sa.a;
+  const int m = a.m_dev ? (*a.m_dev < a.m_cap ? *a.m_dev : a.m_cap) : a.m_cap;
+  const int nblk = (m + P::BM - 1) / P::BM;
+  // XCD-aware block map: XCD x walks a contiguous range of blocks (neighbouring blocks share staged rows in its L2)
+  const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
+  const int per = (nblk + 7) >> 3;
+  const int blk = xcd * per + bix;
+  if (bix >= per || blk >= nblk) return;   // the whole workgroup leaves together
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for hipcc too (no waterfall loops around the DMA)
+  const int wr = w / CW, wc = w % CW;
+  const int c = lane & 15, g4 = lane >> 4;
+
+  // ---- slot table -> LDS; zero rows; block header -> one VGPR pair (lane j = plane j) ------------------------------
+  uint16_t* slot = (uint16_t*)(L + P::OFF_SLOT);
+  {
+    const u32x4* src = (const u32x4*)(sa.slots + (size_t)blk * 27 * P::BM);
+    constexpr int N16 = 27 * P::BM * 2 / 16;
+    for (int i = tid; i < N16; i += P::NW * 64) ((u32x4*)slot)[i] = src[i];
+    if (tid < P::NXB * P::PPR) {
+      const int b = tid / P::PPR, p = tid % P::PPR;
+      *(u32x4*)(L + P::OFF_X + b * P::XB + CAP * P::RB + p * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  const int2 hl = sa.hdr[(size_t)blk * PLANES + (lane < PLANES ? lane : 0)];
+  const int vlo = hl.x, vcnt = lane < PLANES ? hl.y : 0;
+  const unsigned live_planes = (unsigned)__builtin_amdgcn_readfirstlane((int)__ballot(vcnt > 0));   // bit j: plane j has rows
+  auto plane_lo = [&](int j) { return __builtin_amdgcn_readlane(vlo, j); };
+  auto plane_cnt = [&](int j) { return __builtin_amdgcn_readlane(vcnt, j); };
+  auto next_plane = [&](int from) {   // first plane >= from with rows, PLANES if none
+    const unsigned rest = from < PLANES ? live_planes >> from : 0u;
+    return rest ? from + (int)__builtin_ctz(rest) : PLANES;
+  };
+  auto next_sub = [&](Sub u) {
+    if (u.done) return u;
+    if ((u.q + 1) * CAP < plane_cnt(u.j)) { ++u.q; return u; }
+    u.q = 0;
+    u.j = next_plane(u.j + 1);
+    if (u.j < PLANES) return u;
+    u.j = next_plane(0);
+    if (++u.h >= P::NH) u.done = true;
+    return u;
+  };
+
+  const unsigned row_bytes = (unsigned)a.feat_stride * 2u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat, 0, (unsigned)a.n_in * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, sa.wimg_bytes, 0x00020000);
+  char* const dump = L + P::OFF_DUMP;
+  const unsigned lr = (unsigned)(lane / P::PPR), sp = (unsigned)(lane % P::PPR);
+  const unsigned lane_piece_off = (sp ^ RowSwz<KC>::of(lr)) * 16u;
+  static_assert(P::RPI % 8 == 0, "swizzle must not depend on the instruction index");
+  // rows of piece (j, q), channel pass h -> X buffer xb: exactly NX 1-KiB requests per wave (pieces past the range re-read
+  // its last row into rows no slot refers to, or into the dump); a finished `u` sends all of them to the dump
+  auto stage_x = [&](const Sub& u, int xb) {
+    const int j = u.done ? next_plane(0) : u.j;
+    const int n = plane_cnt(j) - (u.done ? 0 : u.q * CAP);
+    const unsigned rows = (unsigned)(n < CAP ? n : CAP);
+    const unsigned soff = (unsigned)(plane_lo(j) + (u.done ? 0 : u.q * CAP)) * row_bytes + (unsigned)((u.done ? 0 : u.h) * KC * 2);
+    char* dst = L + P::OFF_X + xb * P::XB;
+#pragma unroll
+    for (int t = 0; t < P::NX; ++t) {
+      const int i = w + t * P::NW;
+      unsigned r = (unsigned)(i * P::RPI) + lr;
+      r = r < rows ? r : rows - 1u;
+      dma16(rs_x, r * row_bytes + lane_piece_off, soff, (i < P::PX && !u.done) ? dst + i * 1024 : dump);
+    }
+  };
+  // this wave's filter fragments of tap d (0..8) of piece u: NB coalesced 16-byte loads
+  auto load_w = [&](const Sub& u, int d, u32x4 (&wf)[P::NB]) {
+    const int k = u.j * TAPS + d;
+#pragma unroll
+    for (int cc = 0; cc < P::CH; ++cc)
+#pragma unroll
+      for (int nt = 0; nt < P::NTW; ++nt)
+        wf[cc * P::NTW + nt] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs_w, (unsigned)lane * 16u, (unsigned)(((k * P::CPB + u.h * P::CH + cc) * NT + wc * P::NTW + nt) * 1024), 0);
+  };
+  // Row addressing is split in two so that no LDS round trip sits in front of an MFMA group: the 16-bit slots of tap d are
+  // READ two taps ahead (raw ring, like the filter), and turned into LDS addresses (byte address of piece 0 | swizzle << 20)
+  // just before the tap's first fragment read, one reduction unit later at the earliest.
+  auto load_slots = [&](const Sub& u, int d, unsigned (&raw)[MT]) {
+    const uint16_t* sl = slot + (u.j * TAPS + d) * P::BM + wr * 16 * MT + c;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) raw[mt] = (unsigned)sl[mt * 16];
+  };
+  auto to_offsets = [&](const Sub& u, const unsigned (&raw)[MT], unsigned (&xo)[MT]) {
+    const unsigned pbase = (unsigned)(u.q * CAP);
+    const unsigned plive = (unsigned)plane_cnt(u.j) - pbase;
+    const unsigned prow = plive < (unsigned)CAP ? plive : (unsigned)CAP;   // rows of this piece
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      unsigned e = raw[mt] - pbase;        // NO_SLOT - pbase stays >= prow
+      e = e < prow ? e : (unsigned)CAP;    // outside the piece: the zero row
+      xo[mt] = e * P::RB + (RowSwz<KC>::of(e) << 20);
+    }
+  };
+
+  // output channels [c0, c0 + 16*NTW) of the rows: the epilogue sees a narrower convolution
+  Args aw = a;
+  const int c0 = wc * P::NTW * 16;
+  aw.out = (void*)((T*)a.out + c0);
+  if (a.bias) aw.bias = (const void*)((const T*)a.bias + c0);
+  if (a.scale) { aw.scale = a.scale + c0; aw.shift = a.shift + c0; }
+  if (a.residual) aw.residual = (const void*)((const T*)a.residual + c0);
+  aw.cout = a.cout - c0;
+  WT wt;
+  wt.init(aw, blk * P::BM + wr * 16 * MT, m, nullptr, (u32x4*)(L + P::OFF_X) + w * EpiScratch<P::NTW>::U4);
+
+  Sub sub[2];   // this piece, the next
+  sub[0] = Sub{0, next_plane(0), 0, false};   // the centre plane always has rows in a live block
+  sub[1] = next_sub(sub[0]);
+  u32x4 wf[P::WD + 1][P::NB];   // filter ring: tap d of a piece lives in set d % 3
+  stage_x(sub[0], 0);
+  load_w(sub[0], 0, wf[0]);
+  load_w(sub[0], 1, wf[1]);
+  wait_dma<0>();
+  __syncthreads();   // rows of the first piece landed; also publishes the slot table and the zero rows
+  int xb = 0;
+  unsigned raw[P::WD + 1][MT];   // slot ring: tap d of a piece lives in set d % 3
+  load_slots(sub[0], 0, raw[0]);
+  load_slots(sub[0], 1, raw[1]);
+  for (;;) {
+    const char* X = L + P::OFF_X + xb * P::XB;
+    constexpr int U = TAPS * P::CH;   // reduction units of a piece: (tap, 32-channel chunk)
+    unsigned xo[2][MT];
+    u32x4 xa[2][MT];
+    auto fetch = [&](int i) {
+      const int d = i / P::CH, cc = i % P::CH;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        xa[i & 1][mt] = *(const u32x4*)(X + (xo[d & 1][mt] & 0xFFFFFu) + (((unsigned)(cc * 4 + g4)) ^ (xo[d & 1][mt] >> 20)) * 16);
+    };
+    to_offsets(sub[0], raw[0], xo[0]);
+    fetch(0);
+#pragma unroll
+    for (int d = 0; d < TAPS; ++d) {
+      // requests: the filter of the tap WD ahead (the next piece's first taps at the end of this one); at the first tap the
+      // rows of the next piece, AFTER the filter request — a filter load issued behind them could not complete before them
+      {
+        const int dn = d + P::WD;
+        const Sub& un = dn < TAPS ? sub[0] : (sub[1].done ? sub[0] : sub[1]);   // past the last piece: a valid, unused load
+        load_w(un, dn % TAPS, wf[dn % (P::WD + 1)]);
+        load_slots(un, dn % TAPS, raw[dn % (P::WD + 1)]);
+      }
+      if (d == 0) stage_x(sub[1], xb ^ 1);
+#pragma unroll
+      for (int cc = 0; cc < P::CH; ++cc) {
+        const int i = d * P::CH + cc;
+        if (i + 1 < U) {
+          if ((i + 1) % P::CH == 0) to_offsets(sub[0], raw[(d + 1) % (P::WD + 1)], xo[(d + 1) & 1]);
+          fetch(i + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < P::NTW; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            wt.acc[mt][nt] = mfma<DT>(wf[d % (P::WD + 1)][cc * P::NTW + nt], xa[i & 1][mt], wt.acc[mt][nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the next piece's rows (requested nine taps ago, in front of all but the two newest filter sets) have landed; every
+    // wave is done reading this piece
+    wait_dma<P::WD * P::NB>();
+    barrier_keep_dma();
+    if (sub[1].done) break;
+    sub[0] = sub[1];
+    sub[1] = next_sub(sub[1]);
+    xb ^= 1;
+  }
+  wt.store(aw);   // epilogue scratch aliases the X buffers: every wave passed the last barrier, nobody reads X any more
+}
+
+}  // namespace slab
+}  // namespace bevamd

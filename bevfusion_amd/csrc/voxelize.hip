@@ -288,6 +288,128 @@ __global__ __launch_bounds__(256) void vox_compact_kernel(const float* __restric
   }
 }
 
+// ---- batched voxelize + mean: every sweep of the batch in the launches of one ----------------------------------------------
+// Sweep b's points occupy [off[b], off[b+1]) of the concatenated key / index arrays (the points themselves stay where they
+// are: one pointer per sweep).  The segmented sort orders each range by cell on its own, so "rank of the voxel's first
+// point among the voxel-opening points of ITS sweep" — the reference's voxel id — is one flat scan of the first-point
+// flags minus the scan value at the sweep's start.  No head / segment arrays: a head row counts its run (<= max_points
+// rows) while it sums it.
+constexpr int VOX_MAX_BATCH = SORT_MAX_SEGS;
+struct VoxBatch {
+  const float* pts[VOX_MAX_BATCH];
+  uint32_t off[VOX_MAX_BATCH + 1];
+  int batch;
+};
+
+__global__ __launch_bounds__(256) void vox_key_batch_kernel(VoxBatch vb, int nfeat, VoxGrid g, uint32_t ncells,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                            uint32_t* __restrict__ first) {
+  const int b = blockIdx.y;
+  const uint32_t n = vb.off[b + 1] - vb.off[b];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int cx, cy, cz;
+  bool ok = voxel_coord(vb.pts[b] + (size_t)i * nfeat, g, cx, cy, cz);
+  keys[vb.off[b] + i] = ok ? (uint32_t)((cx * g.gy + cy) * g.gz + cz) : ncells;
+  vals[vb.off[b] + i] = i;
+  first[vb.off[b] + i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void vox_heads_batch_kernel(VoxBatch vb, const uint32_t* __restrict__ keys,
+                                                              const uint32_t* __restrict__ idx, uint32_t ncells,
+                                                              uint32_t* __restrict__ first /*zeroed, point order*/) {
+  const int b = blockIdx.y;
+  const uint32_t n = vb.off[b + 1] - vb.off[b];
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t J = vb.off[b] + j;
+  const uint32_t k = keys[J];
+  if (k < ncells && (j == 0 || keys[J - 1] != k)) first[vb.off[b] + idx[J]] = 1u;  // stable sort: earliest point
+}
+
+// counts[b] = min(voxels of sweep b, max_voxels); rowbase[b] = first output row of sweep b (packed: running sum of the
+// counts, else b * max_voxels); total = sum of counts.  first_scan is the exclusive scan, *first_total its grand total.
+__global__ void vox_counts_batch_kernel(VoxBatch vb, const uint32_t* __restrict__ first_scan,
+                                        const uint32_t* __restrict__ first_total, int max_voxels, int packed,
+                                        int* __restrict__ counts, uint32_t* __restrict__ rowbase, int* __restrict__ total) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t ntot = vb.off[vb.batch];
+  uint32_t run = 0;
+  for (int b = 0; b < vb.batch; ++b) {
+    const uint32_t lo = vb.off[b] < ntot ? first_scan[vb.off[b]] : *first_total;
+    const uint32_t hi = vb.off[b + 1] < ntot ? first_scan[vb.off[b + 1]] : *first_total;
+    const uint32_t c = hi - lo < (uint32_t)max_voxels ? hi - lo : (uint32_t)max_voxels;
+    counts[b] = (int)c;
+    rowbase[b] = packed ? run : (uint32_t)b * (uint32_t)max_voxels;
+    run += c;
+  }
+  if (total) *total = (int)run;
+}
+
+__global__ __launch_bounds__(256) void vox_mean_batch_kernel(
+    VoxBatch vb, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ first_scan, const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
+    int max_points, int max_voxels, float* __restrict__ feats, int* __restrict__ coords4,
+    int* __restrict__ num_points_per_voxel) {
+  const int b = blockIdx.y;
+  const uint32_t n = vb.off[b + 1] - vb.off[b];
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t J = vb.off[b] + j;
+  const uint32_t k = keys[J];
+  if (k >= ncells || (j != 0 && keys[J - 1] == k)) return;  // head rows only
+  const uint32_t vid = first_scan[vb.off[b] + idx[J]] - first_scan[vb.off[b]];
+  if (vid >= (uint32_t)max_voxels) return;
+  const size_t row = (size_t)rowbase[b] + vid;
+  const float* __restrict__ points = vb.pts[b];
+  const uint32_t room = n - j < (uint32_t)max_points ? n - j : (uint32_t)max_points;
+  int cnt = 0;
+  if (nfeat <= 8) {
+    // point-major walk: one index load per point, all its features accumulated in registers (same per-feature summation
+    // order as the reference's sum over the point slots: r ascending)
+    float acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = 0.f;
+    for (uint32_t r = 0; r < room; ++r) {
+      if (r && keys[J + r] != k) break;
+      const float* p = points + (size_t)idx[J + r] * nfeat;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        if (f < nfeat) acc[f] += p[f];
+      ++cnt;
+    }
+    const float fc = (float)cnt;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f < nfeat) feats[row * nfeat + f] = __fdiv_rn(acc[f], fc);
+  } else {
+    for (uint32_t r = 0; r < room; ++r) {
+      if (r && keys[J + r] != k) break;
+      ++cnt;
+    }
+    const float fc = (float)cnt;
+    for (int f = 0; f < nfeat; ++f) {
+      float s = 0.f;
+      for (int r = 0; r < cnt; ++r) s += points[(size_t)idx[J + r] * nfeat + f];
+      feats[row * nfeat + f] = __fdiv_rn(s, fc);
+    }
+  }
+  if (num_points_per_voxel) num_points_per_voxel[row] = cnt;
+  int cz = (int)(k % (uint32_t)g.gz);
+  uint32_t t = k / (uint32_t)g.gz;
+  int cy = (int)(t % (uint32_t)g.gy);
+  int cx = (int)(t / (uint32_t)g.gy);
+  ((int4*)coords4)[row] = make_int4(b, cx, cy, cz);
+}
+
+static size_t voxelize_batch_ws_bytes(const SortSegs& sg) {
+  const size_t n = sg.off[sg.nseg] ? sg.off[sg.nseg] : 1;
+  size_t a = align_up(n * sizeof(uint32_t), 256);
+  size_t s1 = radix_sort_segmented_workspace_bytes(sg), s2 = scan_workspace_bytes(n);
+  // keys_a, vals_a, keys_b, vals_b, first (scanned in place), rowbase + total
+  return 5 * a + 2 * 256 + align_up(s1 > s2 ? s1 : s2, 256);
+}
+
 }  // namespace bevamd
 
 using namespace bevamd;
@@ -376,6 +498,81 @@ int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* n
   BEVAMD_LAUNCH_CHECK("vox_mean");
   vox_count_kernel<<<1, 1, 0, stream>>>(vb.nseg, max_voxels, voxel_num_dev);
   BEVAMD_LAUNCH_CHECK("vox_count");
+  return BEVAMD_OK;
+}
+
+size_t bevamd_voxelize_mean_batch_workspace_bytes(const int* num_points, int batch_size) {
+  SortSegs sg;
+  if (!num_points || sort_segs_init(sg, num_points, batch_size) != BEVAMD_OK) return 0;
+  return voxelize_batch_ws_bytes(sg);
+}
+
+int bevamd_voxelize_mean_batch(const float* const* points, const int* num_points, int batch_size, int num_features,
+                               const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                               int packed, float* feats, int* coords4, int* num_points_per_voxel, int* counts_dev,
+                               int* total_dev, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(points && num_points, "voxelize_mean_batch: points / num_points are null (host arrays)");
+  BEVAMD_REQUIRE(batch_size >= 1 && batch_size <= VOX_MAX_BATCH, "voxelize_mean_batch: batch_size %d (1..%d supported)",
+                 batch_size, VOX_MAX_BATCH);
+  BEVAMD_REQUIRE(num_features >= 3, "voxelize_mean_batch: need num_features >= 3");
+  BEVAMD_REQUIRE(max_points > 0 && max_voxels > 0, "voxelize_mean_batch: max_points/max_voxels must be > 0");
+  BEVAMD_REQUIRE(counts_dev != nullptr, "voxelize_mean_batch: counts_dev is null");
+  VoxGrid g;
+  int rc = make_grid(voxel_size, coors_range, g);
+  if (rc) return rc;
+  SortSegs sg;
+  rc = sort_segs_init(sg, num_points, batch_size);
+  if (rc) return rc;
+  VoxBatch vbt;
+  vbt.batch = batch_size;
+  int nmax = 0;
+  for (int b = 0; b < batch_size; ++b) {
+    BEVAMD_REQUIRE(num_points[b] == 0 || points[b] != nullptr, "voxelize_mean_batch: points[%d] is null", b);
+    vbt.pts[b] = points[b];
+    vbt.off[b] = sg.off[b];
+    if (num_points[b] > nmax) nmax = num_points[b];
+  }
+  vbt.off[batch_size] = sg.off[batch_size];
+  const size_t n = sg.off[batch_size];
+  if (n == 0) {
+    rc = device_fill_u32((uint32_t*)counts_dev, (size_t)batch_size, 0u, stream);
+    if (rc == BEVAMD_OK && total_dev) rc = device_fill_u32((uint32_t*)total_dev, 1, 0u, stream);
+    return rc;
+  }
+  BEVAMD_REQUIRE(feats && coords4, "voxelize_mean_batch: null output buffer");
+  if (ws == nullptr || ws_bytes < voxelize_batch_ws_bytes(sg)) {
+    set_error("voxelize_mean_batch: workspace too small (%zu < %zu)", ws_bytes, voxelize_batch_ws_bytes(sg));
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  const uint32_t ncells = (uint32_t)((unsigned long long)g.gx * g.gy * g.gz);
+  Carver cv(ws, ws_bytes);
+  uint32_t* keys_a = cv.take<uint32_t>(n);
+  uint32_t* vals_a = cv.take<uint32_t>(n);
+  uint32_t* keys_b = cv.take<uint32_t>(n);
+  uint32_t* vals_b = cv.take<uint32_t>(n);
+  uint32_t* first = cv.take<uint32_t>(n);
+  uint32_t* rowbase = cv.take<uint32_t>(VOX_MAX_BATCH);
+  uint32_t* first_total = cv.take<uint32_t>(1);
+  void* sws = cv.base + cv.off;
+  const size_t sws_bytes = ws_bytes - cv.off;
+
+  const dim3 grid(cdiv(nmax, 256), batch_size), block(256);
+  vox_key_batch_kernel<<<grid, block, 0, stream>>>(vbt, num_features, g, ncells, keys_a, vals_a, first);
+  BEVAMD_LAUNCH_CHECK("vox_key_batch");
+  uint32_t *keys_s, *idx_s;
+  rc = radix_sort_pairs_u32_segmented(keys_a, vals_a, keys_b, vals_b, sg, bits_for((uint64_t)ncells + 1), sws, sws_bytes,
+                                      stream, &keys_s, &idx_s);
+  if (rc) return rc;
+  vox_heads_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, ncells, first);
+  BEVAMD_LAUNCH_CHECK("vox_heads_batch");
+  rc = exclusive_scan_u32(first, first, n, first_total, sws, sws_bytes, stream);
+  if (rc) return rc;
+  vox_counts_batch_kernel<<<1, 64, 0, stream>>>(vbt, first, first_total, max_voxels, packed, counts_dev, rowbase, total_dev);
+  BEVAMD_LAUNCH_CHECK("vox_counts_batch");
+  vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, rowbase, num_features, g, ncells, max_points,
+                                                    max_voxels, feats, coords4, num_points_per_voxel);
+  BEVAMD_LAUNCH_CHECK("vox_mean_batch");
   return BEVAMD_OK;
 }
 

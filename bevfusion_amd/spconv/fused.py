@@ -148,8 +148,13 @@ class Level:
         """Slab metadata (ops.SlabMeta) of the 3x3x3 SubM neighbour table, for `block_rows`-row blocks: built once, on the
         geometry stream, behind the table it rewrites."""
         if block_rows not in self._slab:
-            nbr = self.subm_neighbors((3, 3, 3), wait=False)
-            meta = ops.slab_build(nbr, self.n_cap, self.n_dev, block_rows, stream_ptr=self._stream_ptr())
+            if (3, 3, 3) in self._subm or not _SLAB_DIRECT:
+                nbr = self.subm_neighbors((3, 3, 3), wait=False)
+                meta = ops.slab_build(nbr, self.n_cap, self.n_dev, block_rows, stream_ptr=self._stream_ptr())
+            else:   # nobody asked for the int32 table: every row looks its neighbours up itself, 54 B per row written in all
+                self.ensure_index()
+                meta = ops.slab_build_from_index(self.indices, self.n_cap, self.n_dev, self.batch, self.shape, self.index_kind,
+                                                 self.index, self.index_n_cap, block_rows, stream_ptr=self._stream_ptr())
             self._slab[block_rows] = (meta, self._mark())
         meta, ev = self._slab[block_rows]
         if wait:
@@ -251,13 +256,15 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
         raise Unfusable("feature pitch smaller than the padded channel count")
     image, bias, scale, shift = folded(conv, bn, dtype)
     lvl = x.level
+    slab_variant = _slab_variant_for(conv, lvl, cin, cout)
     if conv.subm:
-        nbr, out_lvl = lvl.subm_neighbors(conv.kernel_size), lvl
+        # the slab kernels read their own metadata: the int32 neighbour table is only built for them when profiling (pair counts)
+        nbr = lvl.subm_neighbors(conv.kernel_size) if slab_variant is None or LAYER_PROFILE is not None else None
+        out_lvl = lvl
     else:
         out_lvl, nbr = lvl.downsample(conv.kernel_size, conv.stride, conv.padding)
     K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
     out = torch.empty((out_lvl.n_cap, cout), dtype=dtype, device=x.features.device)
-    slab_variant = _slab_variant_for(conv, lvl, cin, cout)
     rec = None
     if LAYER_PROFILE is not None:
         torch.cuda.synchronize()          # the rulebook chain (geometry stream) is out of the way: the events bracket the kernel
@@ -314,8 +321,10 @@ _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 
 # Measured (tools/sweep_spconv.py --slab, profiles/r02_slab_sweep_*.txt): 8 frames 218 / 206 / 167 us against 292 / 246 / 193 us
 # of the gather kernels for 32 / 64 / 128 channels; one frame 30 / 34 us against 41 / 35 us, but 42+ against 38 us at 128
 # channels (188 blocks on 256 CUs) -> the 128-channel layers switch over from 4 frames per step.
-_SLAB_DEFAULT = {32: 0, 64: 0, 128: 0}     # 0 = the library's first-listed variant
+_SLAB_DEFAULT = {32: 1322410, 64: 1644221, 128: 1644220}   # register-filter kernels (spconv_slab_regw.h); 0 = the library's first-listed variant
 _SLAB_MIN_BATCH = {128: 4}
+# BEVAMD_SPCONV_SLAB_DIRECT=0: build the slab metadata from the int32 neighbour table instead of straight from the rank index
+_SLAB_DIRECT = os.environ.get("BEVAMD_SPCONV_SLAB_DIRECT", "1") != "0"
 
 
 def _slab_overrides():
@@ -523,9 +532,10 @@ def prefetch_geometry(enc, lvl):
         if any(d != 1 for d in m.dilation):
             continue
         if m.subm:
-            cur.subm_neighbors(m.kernel_size, wait=False)
             v = _slab_variant_for(m, cur, m.in_channels, m.out_channels)
             if v is not None:
                 cur.subm_slab(ops.slab_block_rows(m.in_channels, v), wait=False)
+            else:
+                cur.subm_neighbors(m.kernel_size, wait=False)
         else:
             cur, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False)

@@ -310,9 +310,9 @@ def slab_block_rows(cin, variant=0):
 
 def slab_variants(cin):
     lib = _capi.load()
-    codes = (_capi.c_int * 16)()
-    n = lib.bevamd_spconv_slab_variants(int(cin), codes, 16)
-    return [int(codes[i]) for i in range(min(n, 16))]
+    codes = (_capi.c_int * 32)()
+    n = lib.bevamd_spconv_slab_variants(int(cin), codes, 32)
+    return [int(codes[i]) for i in range(min(n, 32))]
 
 
 def slab_grid_ok(shape, block_rows):
@@ -338,6 +338,22 @@ def slab_build(nbr, m_cap, m_dev, block_rows, stream_ptr=None):
                                           _capi.ptr(hdr), _capi.ptr(slots), _capi.ptr(status),
                                           stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
     _capi.check(rc, "spconv_slab_build")
+    return SlabMeta(hdr, slots, int(block_rows), status)
+
+
+def slab_build_from_index(indices, m_cap, m_dev, batch, shape, index_kind, index, index_n_cap, block_rows, stream_ptr=None):
+    """The same metadata straight from the voxel set's index (bevamd_spconv_slab_build_from_index): no neighbour table."""
+    lib = _capi.load()
+    dev = indices.device
+    with torch.cuda.device(dev):
+        hdr = torch.empty(max(lib.bevamd_spconv_slab_hdr_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
+        slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.bevamd_spconv_slab_build_from_index(_capi.ptr(indices), int(m_cap), _capi.ptr(m_dev), int(batch),
+                                                     _capi.ints(shape), int(index_kind), _capi.ptr(index), int(index_n_cap),
+                                                     int(block_rows), _capi.ptr(hdr), _capi.ptr(slots), _capi.ptr(status),
+                                                     stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
+    _capi.check(rc, "spconv_slab_build_from_index")
     return SlabMeta(hdr, slots, int(block_rows), status)
 
 

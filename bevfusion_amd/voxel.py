@@ -11,6 +11,7 @@ batch with the mean-reduce fused, no `[max_voxels, max_points, F]` intermediate 
 for the whole batch (the reference syncs once per sample).
 """
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -285,6 +286,39 @@ class Voxelization(nn.Module):
         return tmpstr
 
 
+_VOXEL_BATCHED = os.environ.get("BEVAMD_VOXEL_BATCHED", "1") != "0"   # one segmented sort per batch (0 = one per sample)
+_VOXEL_MAX_BATCH = 64
+
+
+def _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, packed):
+    """All samples in the launches of one (`bevamd_voxelize_mean_batch`): returns (feats [B*cap, F], coords [B*cap, 4],
+    sizes [B*cap], counts [B], total [1]); rows packed sample after sample when `packed`, else sample b at row b*cap."""
+    lib = _capi.load()
+    B = len(points_list)
+    dev = points_list[0].device
+    F = points_list[0].shape[1]
+    points_list = [_check_points(p) for p in points_list]
+    for p in points_list:
+        if p.shape[1] != F or p.device != dev:
+            raise ValueError("voxelize_batch: samples must share the device and the feature count")
+    feats = torch.empty((B * max_voxels, F), dtype=torch.float32, device=dev)
+    coords = torch.empty((B * max_voxels, 4), dtype=torch.int32, device=dev)
+    sizes = torch.empty((B * max_voxels,), dtype=torch.int32, device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    ptrs = (ctypes.c_void_p * B)(*[p.data_ptr() if p.shape[0] else None for p in points_list])
+    nums = (ctypes.c_int * B)(*[int(p.shape[0]) for p in points_list])
+    with torch.cuda.device(dev):
+        wsb = lib.bevamd_voxelize_mean_batch_workspace_bytes(nums, B)
+        ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
+        rc = lib.bevamd_voxelize_mean_batch(ptrs, nums, B, F, _capi.floats(voxel_size), _capi.floats(point_cloud_range),
+                                            int(max_num_points), int(max_voxels), 1 if packed else 0, _capi.ptr(feats),
+                                            _capi.ptr(coords), _capi.ptr(sizes), _capi.ptr(counts), _capi.ptr(total),
+                                            _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+    _capi.check(rc, "voxelize_mean_batch")
+    return feats, coords, sizes, counts, total
+
+
 @torch.no_grad()
 def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, sync=True):
     """`BEVFusion.voxelize` (bevfusion.py:169-197, hard voxelization + voxelize_reduce) for a batch.
@@ -293,6 +327,30 @@ def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, m
     coords [M, 4] int32 = (batch_idx, x, y, z), sizes [M] int32).
     With sync=True the outputs are exactly sized (one D2H copy of all counts for the whole batch);
     with sync=False they are (padded buffers, counts_dev) for callers that stay on the device."""
+    lib = _capi.load()
+    B = len(points_list)
+    dev = points_list[0].device
+    F = points_list[0].shape[1]
+    if _VOXEL_BATCHED and B <= _VOXEL_MAX_BATCH:
+        feats, coords, sizes, counts, _ = _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points,
+                                                               max_voxels, packed=False)
+        feats, coords, sizes = feats.view(B, max_voxels, F), coords.view(B, max_voxels, 4), sizes.view(B, max_voxels)
+    else:
+        feats, coords, sizes, counts = _voxelize_mean_lanes(points_list, voxel_size, point_cloud_range, max_num_points,
+                                                            max_voxels)
+    if not sync:
+        return feats, coords, sizes, counts
+
+    cnt = counts.tolist()  # the single host sync of the batch
+    feats = torch.cat([feats[k, : cnt[k]] for k in range(B)], 0)
+    coords = torch.cat([coords[k, : cnt[k]] for k in range(B)], 0)
+    sizes = torch.cat([sizes[k, : cnt[k]] for k in range(B)], 0)
+    return feats, coords, sizes
+
+
+def _voxelize_mean_lanes(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels):
+    """One `bevamd_voxelize_mean` per sample, spread over a few HIP streams (batches beyond the batched entry's 64
+    samples, or BEVAMD_VOXEL_BATCHED=0): padded slabs + device counts."""
     lib = _capi.load()
     B = len(points_list)
     dev = points_list[0].device
@@ -329,14 +387,7 @@ def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, m
             for lane in lanes:
                 if lane is not None:
                     main.wait_stream(lane)
-    if not sync:
-        return feats, coords, sizes, counts
-
-    cnt = counts.tolist()  # the single host sync of the batch
-    feats = torch.cat([feats[k, : cnt[k]] for k in range(B)], 0)
-    coords = torch.cat([coords[k, : cnt[k]] for k in range(B)], 0)
-    sizes = torch.cat([sizes[k, : cnt[k]] for k in range(B)], 0)
-    return feats, coords, sizes
+    return feats, coords, sizes, counts
 
 
 @torch.no_grad()
@@ -345,6 +396,10 @@ def voxelize_batch_device(points_list, voxel_size, point_cloud_range, max_num_po
     sizes [B*max_voxels], total [1] int32 on the device) with the batch packed sample after sample in the first `total`
     rows — what `SparseEncoder(..., num_voxels=total)` consumes on its sync-free path."""
     lib = _capi.load()
+    if _VOXEL_BATCHED and len(points_list) <= _VOXEL_MAX_BATCH:
+        of, oc, osz, _, total = _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
+                                                     packed=True)
+        return of, oc, osz, total
     feats, coords, sizes, counts = voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
                                                   sync=False)
     B, cap, F = feats.shape

@@ -247,6 +247,20 @@ int bevamd_voxelize_mean(const float* points, float* feats, int* coords4, int* n
                          int max_voxels, int num_points, int num_features, int batch_idx,
                          int* voxel_num_dev, void* ws, size_t ws_bytes, void* stream);
 
+/* The same step for a whole batch in the launches of one (bevfusion.py:176-191: the per-sample loop, the F.pad batch
+ * column and the torch.cat): points / num_points are HOST arrays of batch_size device pointers / point counts
+ * (batch_size <= 64).  One segmented radix sort orders every sweep by cell; results are those of batch_size
+ * bevamd_voxelize_mean calls with batch_idx = 0..batch_size-1.
+ *   packed = 0: sample b's rows start at row b * max_voxels (padded slabs, what bevamd_voxel_compact consumes);
+ *   packed = 1: rows are packed sample after sample (the torch.cat) — the buffers still hold batch_size * max_voxels rows.
+ * counts_dev [batch_size] receives min(voxels of the sample, max_voxels), total_dev [1] (optional) their sum.  No host
+ * synchronisation. */
+size_t bevamd_voxelize_mean_batch_workspace_bytes(const int* num_points, int batch_size);
+int bevamd_voxelize_mean_batch(const float* const* points, const int* num_points, int batch_size, int num_features,
+                               const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                               int packed, float* feats, int* coords4, int* num_points_per_voxel, int* counts_dev,
+                               int* total_dev, void* ws, size_t ws_bytes, void* stream);
+
 /* Dynamic scatter.  Replace voxel_layer.dynamic_point_to_voxel_forward / _backward
  *   (voxel/src/voxelization.cpp:6-11 -> voxelization.h:108-140 -> scatter_points_cuda.cu:197-330).
  * bevamd_dynamic_scatter_index: coors [num_points, ndim] int32 (ndim 1..4); rows with a negative entry are dropped.
@@ -445,6 +459,13 @@ size_t bevamd_spconv_slab_hdr_bytes(int m_cap, int block_rows);
 size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows);
 int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const int* m_dev, int block_rows, void* hdr,
                              void* slots, int* status, void* stream);
+
+/* The same metadata without the neighbour table: every row looks its 27 neighbour cells up in the voxel set's own index
+ * (index_kind / index / index_n_cap as for bevamd_spconv_neighbors; indices [m, 4] = (b, x, y, z) on grid `shape`).
+ * Identical hdr / slots to bevamd_spconv_neighbors(subm = 1) + bevamd_spconv_slab_build. */
+int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int* m_dev, int batch_size, const int* shape,
+                                        int index_kind, const void* index, int index_n_cap, int block_rows, void* hdr,
+                                        void* slots, int* status, void* stream);
 int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_stride, int num_in, const void* image,
                                     const void* hdr, const void* slots, int block_rows, int num_out,
                                     const int* num_out_dev, int cin, int cout, void* out, int out_stride,
@@ -470,6 +491,12 @@ size_t bevamd_radix_sort_workspace_bytes(size_t n);
 int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
                                 uint32_t* vals_out, size_t n, int nbits, void* ws, size_t ws_bytes,
                                 void* stream);
+
+/* nseg (<= 64) independent arrays laid end to end — counts is a HOST array of their lengths — each stably sorted on its
+ * own by the launches of one sort */
+size_t bevamd_radix_sort_segmented_workspace_bytes(const int* counts, int nseg);
+int bevamd_radix_sort_pairs_u32_segmented(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                                          const int* counts, int nseg, int nbits, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,3 +70,32 @@ def test_radix_sort_all_equal_and_already_sorted(dev):
     keys = np.arange(n, dtype=np.uint32)
     ko, vo = _sort(keys, keys[::-1].copy(), 19, dev)
     assert np.array_equal(ko, keys) and np.array_equal(vo, keys[::-1])
+
+
+@pytest.mark.parametrize("counts,nbits", [([5000, 0, 1, 1024, 3000], 13), ([1], 8), ([0, 0, 70000], 27),
+                                          ([2048] * 64, 9), ([310000] * 8, 27), ([1023, 1025], 32)])
+def test_segmented_radix_sort_sorts_every_segment_on_its_own(dev, counts, nbits):
+    import ctypes
+
+    lib = _capi.load()
+    rng = np.random.default_rng(len(counts) + nbits)
+    n = sum(counts)
+    keys = rng.integers(0, min((1 << nbits) - 1, 3000) + 1, n).astype(np.uint32)
+    if nbits == 32:
+        keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    vals = np.concatenate([np.arange(c, dtype=np.uint32) for c in counts]) if n else np.zeros(0, np.uint32)
+    k = torch.from_numpy(keys.view(np.int32)).to(dev)
+    v = torch.from_numpy(vals.view(np.int32)).to(dev)
+    ko, vo = torch.empty_like(k), torch.empty_like(v)
+    cn = (ctypes.c_int * len(counts))(*counts)
+    wsb = lib.bevamd_radix_sort_segmented_workspace_bytes(cn, len(counts))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    rc = lib.bevamd_radix_sort_pairs_u32_segmented(_capi.ptr(k), _capi.ptr(v), _capi.ptr(ko), _capi.ptr(vo), cn, len(counts),
+                                                   nbits, _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+    _capi.check(rc, "segmented radix sort")
+    ko, vo = ko.cpu().numpy().view(np.uint32), vo.cpu().numpy().view(np.uint32)
+    for s in range(len(counts)):
+        seg = slice(off[s], off[s + 1])
+        order = np.argsort(keys[seg], kind="stable")
+        assert np.array_equal(ko[seg], keys[seg][order]) and np.array_equal(vo[seg], vals[seg][order])

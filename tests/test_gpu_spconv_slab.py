@@ -58,7 +58,7 @@ def run_gather(f, w, rb, **kw):
 
 def same_order(c, variant):
     """Variant code = KC*10000 + ...: rows staged whole (KC == Cin) keep the gather kernels' summation order."""
-    kc = (variant or sops.slab_variants(c)[0]) // 10000
+    kc = (variant or sops.slab_variants(c)[0]) % 1000000 // 10000   # 1xxxxxx: the register-filter kernels, same KC field
     return kc == c
 
 
@@ -187,3 +187,41 @@ def test_epilogue_and_device_row_count(dev, c):
     want = sops.sparse_conv_tiled(f, sops.make_filter_image(w), rb_live_nbr, m, 27, c, c, num_out_dev=m_dev, out=sentinel.clone())
     assert torch.equal(got[live:], sentinel[live:])
     assert_same(got[:live], want[:live], c, 0)
+
+
+@pytest.mark.parametrize("bm", [128, 256])
+def test_metadata_straight_from_the_index_equals_the_table_route(dev, bm):
+    """bevamd_spconv_slab_build_from_index (27 lookups per row, no int32 table) writes the same (range, slots) as
+    bevamd_spconv_neighbors + bevamd_spconv_slab_build: on a hash-indexed set in linear order, on the rank-indexed output of a
+    strided convolution, with a device row count below the capacity, and on an empty set."""
+    from bevfusion_amd.spconv import fused
+
+    rng = np.random.default_rng(bm)
+    B, shape = 3, (26, 22, 11)
+    ind = torch.from_numpy(sorted_indices(rng, B, shape, 1800, dense_planes=(7,))).to(dev)
+    n = ind.shape[0]
+
+    def both(lvl):
+        direct = sops.slab_build_from_index(lvl.indices, lvl.n_cap, lvl.n_dev, lvl.batch, lvl.shape, lvl.index_kind, lvl.index,
+                                            lvl.index_n_cap, bm)
+        table = sops.slab_build(lvl.subm_neighbors((3, 3, 3)), lvl.n_cap, lvl.n_dev, bm)
+        torch.cuda.synchronize()
+        m = int(lvl.n_dev.item()) if lvl.n_dev is not None else lvl.n_cap
+        nblk = (m + bm - 1) // bm
+        assert int(direct.status.item()) == 0 and int(table.status.item()) == 0
+        assert torch.equal(direct.hdr[: nblk * 24], table.hdr[: nblk * 24])
+        assert torch.equal(direct.slots[: nblk * 27 * bm * 2], table.slots[: nblk * 27 * bm * 2])
+        return nblk
+
+    top = fused.Level(ind, n, None, B, list(shape))
+    top.ensure_index()
+    assert top.index_kind == fused.INDEX_HASH and both(top) > 1
+    low, _ = top.downsample((3, 3, 3), (2, 2, 2), (1, 1, 1))          # rank index, device count < capacity
+    assert low.index_kind == fused.INDEX_RANK and int(low.n_dev.item()) < low.n_cap
+    assert both(low) >= 1
+    short = fused.Level(ind, n, torch.tensor([n // 3], dtype=torch.int32, device=dev), B, list(shape))
+    short.ensure_index()
+    both(short)
+    none = fused.Level(ind, n, torch.zeros(1, dtype=torch.int32, device=dev), B, list(shape))
+    none.ensure_index()
+    both(none)

@@ -131,3 +131,59 @@ def test_batch_packing_without_host_sync(dev):
         n = int(tot)
         assert n == f0.shape[0] and f1.shape[0] == B * 1500
         assert torch.equal(f1[:n], f0) and torch.equal(c1[:n], c0) and torch.equal(s1[:n], s0)
+
+
+def _per_sample_then_cat(pts, vs, pr, mp, mv):
+    """The reference formulation through the one-sample entry: bevfusion.py:176-191."""
+    from bevfusion_amd import voxel as V
+
+    f, c, s, counts = V._voxelize_mean_lanes(pts, vs, pr, mp, mv)
+    cnt = counts.tolist()
+    cat = lambda t: torch.cat([t[k, : cnt[k]] for k in range(len(pts))], 0)
+    return cat(f), cat(c), cat(s), cnt
+
+
+@pytest.mark.parametrize("case", ["ragged", "empty_middle", "all_empty", "capped", "one", "tile_edges"])
+def test_batched_entry_is_bit_identical_to_per_sample_calls(dev, case):
+    """`bevamd_voxelize_mean_batch` (one segmented sort for the batch) == one `bevamd_voxelize_mean` per sample: features,
+    coordinates, counts and the first-appearance voxel order, padded and packed layouts; ragged / empty samples, samples
+    beyond max_voxels, sizes on the sort's 1024-key tile edges."""
+    from bevfusion_amd import voxel as V
+
+    vs, pr, mp = [0.5, 0.5, 0.5], [0.0, 0.0, 0.0, 20.0, 20.0, 4.0], 5
+    sizes = {"ragged": [3000, 1, 4097, 777, 2048], "empty_middle": [500, 0, 0, 900], "all_empty": [0, 0],
+             "capped": [6000, 200, 6000], "one": [2500], "tile_edges": [1024, 1023, 1025, 2048, 1]}[case]
+    mv = 300 if case == "capped" else 1500
+    pts = []
+    for b, n in enumerate(sizes):
+        rng = np.random.default_rng(7 * b + n)
+        p = rng.random((n, 5)).astype(np.float32) * np.array([22, 22, 4.4, 1, 1], np.float32) - 1.0   # some out of range
+        pts.append(torch.from_numpy(p).to(dev))
+    f0, c0, s0, cnt = _per_sample_then_cat(pts, vs, pr, mp, mv)
+    if case == "capped":
+        assert cnt[0] == mv and cnt[1] < mv
+
+    f, c, s, counts, total = V._voxelize_mean_batch(pts, vs, pr, mp, mv, packed=True)
+    assert counts.tolist() == cnt and int(total) == sum(cnt)
+    n = sum(cnt)
+    assert torch.equal(c[:n], c0) and torch.equal(s[:n], s0) and torch.equal(f[:n], f0)
+
+    f, c, s, counts, total = V._voxelize_mean_batch(pts, vs, pr, mp, mv, packed=False)
+    assert counts.tolist() == cnt and int(total) == sum(cnt)
+    row = 0
+    for b, k in enumerate(cnt):
+        sl = slice(b * mv, b * mv + k)
+        assert torch.equal(c[sl], c0[row:row + k]) and torch.equal(s[sl], s0[row:row + k])
+        assert torch.equal(f[sl], f0[row:row + k])
+        row += k
+
+
+def test_batched_entry_rejects_bad_arguments(dev):
+    from bevfusion_amd import voxel as V
+
+    vs, pr = [0.5, 0.5, 0.5], [0.0, 0.0, 0.0, 20.0, 20.0, 4.0]
+    good = torch.zeros((4, 5), device=dev)
+    with pytest.raises(ValueError):
+        V._voxelize_mean_batch([good, torch.zeros((4, 4), device=dev)], vs, pr, 5, 100, packed=True)
+    with pytest.raises(RuntimeError):
+        V._voxelize_mean_batch([good] * 65, vs, pr, 5, 100, packed=True)
