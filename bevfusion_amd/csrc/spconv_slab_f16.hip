@@ -34,7 +34,8 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
   const slab::ShapeR* r = slab::shapes_r_of(cin, &nr);
   for (int i = 0; s && i < n && i < max_n; ++i) codes[i] = slab::variant_code(s[i]);
   for (int i = 0; r && i < nr && n + i < max_n; ++i) codes[n + i] = slab::variant_code(r[i]);
-  return n + nr;
+  for (int i = 0; r && i < nr && n + nr + i < max_n; ++i) codes[n + nr + i] = slab::variant_code(r[i]) + (slab::PERSIST_BASE - slab::REGW_BASE);
+  return n + 2 * nr;
 }
 
 /* 1 if a voxel set on a [batch, X, Y, Z] grid whose rows are in ascending linear index can use the slab kernels: the input

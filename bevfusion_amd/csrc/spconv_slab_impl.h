@@ -2,6 +2,7 @@
 #pragma once
 #include "spconv_slab.h"
 #include "spconv_slab_regw.h"
+#include "spconv_slab_persist.h"
 
 namespace bevamd {
 namespace slab {
@@ -88,9 +89,36 @@ static int run_r(const SlabArgs& sa, hipStream_t stream) {
   return BEVAMD_OK;
 }
 
+// persistent flavour of the same shapes (spconv_slab_persist.h): variant = 2000000 + the same fields
+template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP>
+static int run_p(const SlabArgs& sa, hipStream_t stream) {
+  typedef PlanP<KC, CIN, NT, MT, RW, CW, CAP> P;
+  static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
+  auto kern = &spconv_slabp_kernel<DT, KC, CIN, NT, MT, RW, CW, CAP>;
+  static int wg_per_xcd = 0;   // resident workgroups per XCD (per kernel instantiation; one device type per process)
+  if (wg_per_xcd == 0) {
+    if (P::BYTES > 65536) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+    }
+    int dev = 0, cus = 0, occ = 0;
+    BEVAMD_HIP_CHECK(hipGetDevice(&dev));
+    BEVAMD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    BEVAMD_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, P::NW * 64, P::BYTES));
+    if (occ < 1) occ = 1;
+    wg_per_xcd = (cus + 7) / 8 * occ;
+  }
+  const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
+  long long gx = (nblk + 7) / 8;
+  if (gx > wg_per_xcd) gx = wg_per_xcd;
+  kern<<<dim3((unsigned)(gx * 8)), dim3(P::NW * 64), P::BYTES, stream>>>(sa);
+  BEVAMD_LAUNCH_CHECK("spconv_slabp");
+  return BEVAMD_OK;
+}
+
 #define BEVAMD_SLABR_SHAPES_32(X) X(32, 4, 2, 1, 192, 0) X(32, 4, 4, 1, 384, 0) X(32, 2, 4, 1, 192, 0)
-#define BEVAMD_SLABR_SHAPES_64(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 2, 2, 152, 1) X(64, 2, 4, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 1, 152, 0)
-#define BEVAMD_SLABR_SHAPES_128(X) X(64, 4, 2, 2, 184, 0) X(64, 2, 4, 2, 184, 0) X(64, 4, 2, 4, 184, 0) X(64, 4, 4, 2, 320, 0)
+#define BEVAMD_SLABR_SHAPES_64(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 2, 2, 152, 1) X(64, 2, 4, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 1, 152, 0) X(64, 4, 4, 1, 320, 0) X(64, 4, 2, 2, 168, 2)
+#define BEVAMD_SLABR_SHAPES_128(X) X(64, 4, 2, 2, 184, 0) X(64, 2, 4, 2, 184, 0) X(64, 4, 2, 4, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 2, 152, 1)
 
 static inline const ShapeR* shapes_r_of(int cin, int* n) {
 #define BEVAMD_ROW(KC, MT, RW, CW, CAP, ID) {KC, MT, RW, CW, CAP, ID},
@@ -105,9 +133,10 @@ static inline const ShapeR* shapes_r_of(int cin, int* n) {
     default: *n = 0; return nullptr;
   }
 }
-constexpr int REGW_BASE = 1000000;
+constexpr int REGW_BASE = 1000000, PERSIST_BASE = 2000000;
 static inline int variant_code(const ShapeR& s) { return REGW_BASE + s.kc * 10000 + s.mt * 1000 + s.rw * 100 + s.cw * 10 + s.id; }
 static inline const ShapeR* find_shape_r(int cin, int variant) {
+  if (variant >= PERSIST_BASE) variant -= PERSIST_BASE - REGW_BASE;   // the persistent kernels are built for the same shapes
   int n = 0;
   const ShapeR* s = shapes_r_of(cin, &n);
   for (int i = 0; s && i < n; ++i)
@@ -131,18 +160,23 @@ int launch_r_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t 
     set_error("spconv slab: no register-filter kernel for cin=%d, cout tiles=%d, variant=%d", cin, nt, variant);
     return BEVAMD_ERR_UNSUPPORTED;
   }
-#define BEVAMD_CASE32(KC, MT, RW, CW, CAP, ID) \
-  if (cin == 32 && variant == REGW_BASE + KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID) return run_r<DT, KC, 32, 2, MT, RW, CW, CAP>(sa, stream);
-#define BEVAMD_CASE64(KC, MT, RW, CW, CAP, ID) \
-  if (cin == 64 && variant == REGW_BASE + KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID) return run_r<DT, KC, 64, 4, MT, RW, CW, CAP>(sa, stream);
-#define BEVAMD_CASE128(KC, MT, RW, CW, CAP, ID) \
-  if (cin == 128 && variant == REGW_BASE + KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID) return run_r<DT, KC, 128, 8, MT, RW, CW, CAP>(sa, stream);
+#define BEVAMD_CODE(KC, MT, RW, CW, ID) (KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID)
+#define BEVAMD_CASE32(KC, MT, RW, CW, CAP, ID)                                                                              \
+  if (cin == 32 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 32, 2, MT, RW, CW, CAP>(sa, stream); \
+  if (cin == 32 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 32, 2, MT, RW, CW, CAP>(sa, stream);
+#define BEVAMD_CASE64(KC, MT, RW, CW, CAP, ID)                                                                              \
+  if (cin == 64 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 64, 4, MT, RW, CW, CAP>(sa, stream); \
+  if (cin == 64 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 64, 4, MT, RW, CW, CAP>(sa, stream);
+#define BEVAMD_CASE128(KC, MT, RW, CW, CAP, ID)                                                                               \
+  if (cin == 128 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 128, 8, MT, RW, CW, CAP>(sa, stream); \
+  if (cin == 128 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 128, 8, MT, RW, CW, CAP>(sa, stream);
   BEVAMD_SLABR_SHAPES_32(BEVAMD_CASE32)
   BEVAMD_SLABR_SHAPES_64(BEVAMD_CASE64)
   BEVAMD_SLABR_SHAPES_128(BEVAMD_CASE128)
 #undef BEVAMD_CASE32
 #undef BEVAMD_CASE64
 #undef BEVAMD_CASE128
+#undef BEVAMD_CODE
   set_error("spconv slab: variant %d is listed but not built for cin=%d", variant, cin);
   return BEVAMD_ERR_UNSUPPORTED;
 }

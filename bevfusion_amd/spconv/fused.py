@@ -321,7 +321,7 @@ _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 
 # Measured (tools/sweep_spconv.py --slab, profiles/r02_slab_sweep_*.txt): 8 frames 218 / 206 / 167 us against 292 / 246 / 193 us
 # of the gather kernels for 32 / 64 / 128 channels; one frame 30 / 34 us against 41 / 35 us, but 42+ against 38 us at 128
 # channels (188 blocks on 256 CUs) -> the 128-channel layers switch over from 4 frames per step.
-_SLAB_DEFAULT = {32: 1322410, 64: 1644221, 128: 1644220}   # register-filter kernels (spconv_slab_regw.h); 0 = the library's first-listed variant
+_SLAB_DEFAULT = {32: 2324410, 64: 1644222, 128: 1644220}   # register-filter kernels (spconv_slab_regw.h); 0 = the library's first-listed variant
 _SLAB_MIN_BATCH = {128: 4}
 # BEVAMD_SPCONV_SLAB_DIRECT=0: build the slab metadata from the int32 neighbour table instead of straight from the rank index
 _SLAB_DIRECT = os.environ.get("BEVAMD_SPCONV_SLAB_DIRECT", "1") != "0"

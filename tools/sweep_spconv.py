@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--small", action="store_true", help="only the layers with < 32 input channels (and no round-0 kernel)")
     ap.add_argument("--quick", action="store_true", help="skip the round-0 kernel and the layers with < 32 input channels")
     ap.add_argument("--slab", action="store_true", help="SubM layers of the sorted levels: every slab variant next to the shipped gather variant")
+    ap.add_argument("--cap-factor", type=float, default=0.0, help="with --slab: also time each variant launched for cap-factor x the live rows (device row count), as the sync-free encoder launches it")
     ap.add_argument("--ablate", action="store_true", help="time the 64->64 / 128->128 SubM layers with parts of the kernel compiled out (needs `python -m bevfusion_amd.build --profiling`)")
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
@@ -104,6 +105,16 @@ def main():
                 same = bool(torch.equal(out, base))
                 md = float((out.float() - base.float()).abs().max())
                 print(f"    slab variant {v:5d}: {med:8.1f} us  {gflop / med * 1e3:8.1f} TFLOP/s eff   identical={same} max|diff|={md:.3g}")
+                if args.cap_factor > 1.0:
+                    cap = int(rb.num_out * args.cap_factor)
+                    nbr_pad = torch.full((27, cap), -1, dtype=torch.int32, device=dev)
+                    nbr_pad[:, :rb.num_out] = rb.nbr[:, :rb.num_out]
+                    m_dev = torch.tensor([rb.num_out], dtype=torch.int32, device=dev)
+                    meta_c = sops.slab_build(nbr_pad, cap, m_dev, sops.slab_block_rows(cin, v))
+                    out_c = torch.empty((cap, cout), dtype=dt, device=dev)
+                    med_c, _ = timeit(lambda: sops.sparse_conv_slab(f, img, meta_c, cap, cin, cout, variant=v, num_out_dev=m_dev, out=out_c))
+                    print(f"         launched for {cap} rows (x{args.cap_factor:g}): {med_c:8.1f} us")
+                    del nbr_pad, meta_c, out_c
             continue
         if args.ablate:
             if (cin, cout) not in ((64, 64), (128, 128)) or K != 27:
