@@ -314,48 +314,82 @@ struct WaveTile {
   // 32 bytes per row segment, a quarter of an L2 line each — measured 8 us of a 40 us layer.  The tile is instead
   // rounded to 16 bits (= the reference's stored conv result), transposed through wave-private LDS, and every lane
   // finishes 8 consecutive channels of one row: 16-byte bias / residual loads, 16-byte stores, whole rows contiguous.
-  __device__ __forceinline__ void store_rows(const Args& a) {
+  // the residual pieces this lane adds in store_rows (same lane -> (row, 8 channels) map): callers with registers to spare
+  // request them long before the epilogue (the slab kernels: at the start of a block's last plane) and pass them to store()
+  static constexpr int RES_LPR = NT * 2;
+  static constexpr int RES_RPP = 64 / RES_LPR > 16 ? 16 : 64 / RES_LPR;
+  static constexpr int RES_PASSES = 16 / RES_RPP;
+  struct Residual { u32x4 v[MT][RES_PASSES]; };
+  __device__ __forceinline__ void load_residual(const Args& a, Residual& res) const {
+    typedef typename Num<DT>::T T;
+    const int j = lane % RES_LPR, rsub = lane / RES_LPR, col0 = j * 8;
+    const bool col_ok = rsub < RES_RPP && col0 < a.cout;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int pass = 0; pass < RES_PASSES; ++pass) {
+        const int row = row0 + mt * 16 + pass * RES_RPP + rsub;
+        res.v[mt][pass] = (a.residual && col_ok && row < m) ? *(const u32x4*)((const T*)a.residual + (size_t)row * a.res_stride + col0)
+                                                            : u32x4{0u, 0u, 0u, 0u};
+      }
+  }
+  __device__ __forceinline__ void store_rows(const Args& a, const Residual* pre = nullptr) {
     typedef typename Num<DT>::T T;
     constexpr int RB = NT * 32 + 16;          // padded row pitch in the scratch, bytes
     constexpr int LPR = NT * 2;               // lanes (16-byte pieces) per row
     constexpr int RPP = 64 / LPR > 16 ? 16 : 64 / LPR;
+    constexpr int PASSES = 16 / RPP;
     char* sc = (char*)eps;
+    // A lane finishes the same 8 channels [col0, col0 + 8) of every row it touches: the per-channel operands are loaded once,
+    // and the residual pieces of ALL the wave's rows are requested up front — one memory round trip for the epilogue instead of
+    // one per 16-row tile (measured on the 32-channel slab layers: the residual add cost 40 us of 240).
+    const int j = lane % LPR, rsub = lane / LPR, col0 = j * 8;
+    const bool col_ok = rsub < RPP && col0 < a.cout;
+    Residual res;
+    if (pre) res = *pre;
+    else if (a.residual) load_residual(a, res);
+    float bv[8], sv[8], hv[8];
+    if (a.bias && col_ok) {
+      const u32x4 br = *(const u32x4*)((const T*)a.bias + col0);
+      const T* b = (const T*)&br;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = Num<DT>::to_f32(b[e]);
+    }
+    if (a.scale && col_ok) {
+      const float4 s0 = *(const float4*)(a.scale + col0), s1 = *(const float4*)(a.scale + col0 + 4);
+      const float4 h0 = *(const float4*)(a.shift + col0), h1 = *(const float4*)(a.shift + col0 + 4);
+      sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+      hv[0] = h0.x; hv[1] = h0.y; hv[2] = h0.z; hv[3] = h0.w; hv[4] = h1.x; hv[5] = h1.y; hv[6] = h1.z; hv[7] = h1.w;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         T p[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] = Num<DT>::from_f32(acc[mt][nt][j]);
+        for (int q = 0; q < 4; ++q) p[q] = Num<DT>::from_f32(acc[mt][nt][q]);
         *(uint2*)(sc + c * RB + nt * 32 + g * 8) = *(const uint2*)p;
       }
 #pragma unroll
-      for (int pass = 0; pass < 16 / RPP; ++pass) {
-        const int r = pass * RPP + lane / LPR, j = lane % LPR;
-        const int row = row0 + mt * 16 + r, col0 = j * 8;
-        if (lane / LPR < RPP && row < m && col0 < a.cout) {
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int r = pass * RPP + rsub;
+        const int row = row0 + mt * 16 + r;
+        if (col_ok && row < m) {
           const u32x4 raw = *(const u32x4*)(sc + r * RB + j * 16);
           const T* v = (const T*)&raw;
           float x[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(v[e]);
           if (a.bias) {
-            const u32x4 br = *(const u32x4*)((const T*)a.bias + col0);
-            const T* b = (const T*)&br;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] + Num<DT>::to_f32(b[e])));
+            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] + bv[e]));
           }
           if (a.scale) {
-            const float4 s0 = *(const float4*)(a.scale + col0), s1 = *(const float4*)(a.scale + col0 + 4);
-            const float4 h0 = *(const float4*)(a.shift + col0), h1 = *(const float4*)(a.shift + col0 + 4);
-            const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-            const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] * sv[e] + hv[e]));
           }
           if (a.residual) {
-            const u32x4 rr = *(const u32x4*)((const T*)a.residual + (size_t)row * a.res_stride + col0);
-            const T* rv = (const T*)&rr;
+            const T* rv = (const T*)&res.v[mt][pass];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] + Num<DT>::to_f32(rv[e])));
           }
@@ -367,7 +401,7 @@ struct WaveTile {
       }
     }
   }
-  __device__ __forceinline__ void store(const Args& a) {
+  __device__ __forceinline__ void store(const Args& a, const Residual* pre = nullptr) {
     if constexpr (ABL & 64) {  // profiling: keep the accumulators alive with one store per wave
       float t = 0.f;
 #pragma unroll
@@ -379,7 +413,7 @@ struct WaveTile {
     }
     // NT == 1: a row is 32 bytes and the tile's 16 rows are already one contiguous 512-byte store per instruction
     if (NT >= 2 && a.row_epilogue) {  // wave-uniform
-      store_rows(a);
+      store_rows(a, pre);
       return;
     }
 #pragma unroll
