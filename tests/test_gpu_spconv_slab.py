@@ -154,8 +154,9 @@ def test_isolated_voxels_empty_lines_and_tiny_sets(dev):
         f = torch.from_numpy(rng.standard_normal((n, 64)).astype(np.float32)).half()
         ref = oracle.indice_conv(f.float().numpy(), w.float().numpy(), opairs, onum, n)
         rb = spconv.build_rulebook(torch.from_numpy(ind).to(dev), 1, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, True)
-        out, _ = run_slab(f.to(dev), w.to(dev), rb)
-        assert_close(out, ref, torch.float16)
+        for v in sops.slab_variants(64):
+            out, _ = run_slab(f.to(dev), w.to(dev), rb, variant=v)
+            assert_close(out, ref, torch.float16)
 
 
 @pytest.mark.parametrize("c", [32, 128])
@@ -170,8 +171,9 @@ def test_epilogue_and_device_row_count(dev, c):
     res = torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32)).to(dev).to(dtype)
     kw = dict(bias=bias, bn_scale=scale, bn_shift=shift, residual=res, relu=True)
     base = run_gather(f, w, rb, **kw)
-    out, _ = run_slab(f, w, rb, **kw)
-    assert_same(out, base, c, 0)
+    for v in sops.slab_variants(c):
+        out, _ = run_slab(f, w, rb, variant=v, **kw)
+        assert_same(out, base, c, v)
     y = (torch.from_numpy(ref).to(dev).to(dtype).float() + bias.float()).to(dtype).float()
     y = (y * scale + shift).to(dtype).float()
     y = torch.relu((y + res.float()).to(dtype).float())
@@ -182,11 +184,42 @@ def test_epilogue_and_device_row_count(dev, c):
     sentinel = torch.full((m, c), 7.0, dtype=dtype, device=dev)
     rb_live_nbr = rb.nbr.clone()
     rb_live_nbr[rb_live_nbr >= live] = -1                         # a table built for the live rows only
-    meta = sops.slab_build(rb_live_nbr, m, m_dev, sops.slab_block_rows(c, 0))
-    got = sops.sparse_conv_slab(f, sops.make_filter_image(w), meta, m, c, c, num_out_dev=m_dev, out=sentinel.clone())
     want = sops.sparse_conv_tiled(f, sops.make_filter_image(w), rb_live_nbr, m, 27, c, c, num_out_dev=m_dev, out=sentinel.clone())
-    assert torch.equal(got[live:], sentinel[live:])
-    assert_same(got[:live], want[:live], c, 0)
+    for v in sops.slab_variants(c):
+        meta = sops.slab_build(rb_live_nbr, m, m_dev, sops.slab_block_rows(c, v))
+        got = sops.sparse_conv_slab(f, sops.make_filter_image(w), meta, m, c, c, num_out_dev=m_dev, out=sentinel.clone(), variant=v)
+        assert torch.equal(got[live:], sentinel[live:])
+        assert_same(got[:live], want[:live], c, v)
+
+
+@pytest.mark.parametrize("c,rows", [(32, 420000), (64, 300000)])
+def test_persistent_kernels_walk_several_blocks_per_workgroup(dev, c, rows):
+    """More blocks than the persistent grid has workgroups (768-1024 on an MI355X): every workgroup crosses block boundaries —
+    next block's header, rows and slots prefetched under the last plane, epilogue, accumulators reset — with a residual and a
+    device row count a few blocks short of the capacity.  Bit-identical to the one-block kernels of the same shape."""
+    rng = np.random.default_rng(c)
+    shape = (300, 300, 24)
+    ind = torch.from_numpy(sorted_indices(rng, 1, shape, rows)).to(dev)
+    n = ind.shape[0]
+    rb = spconv.build_rulebook(ind, 1, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, True)
+    f = torch.randn(n, c, device=dev).half()
+    res = torch.randn(n, c, device=dev).half()
+    img = sops.make_filter_image((torch.randn(3, 3, 3, c, c, device=dev) / (27 * c) ** 0.5).half())
+    live = n - 1000
+    m_dev = torch.tensor([live], dtype=torch.int32, device=dev)
+    nbr = rb.nbr.clone()
+    nbr[nbr >= live] = -1
+    persistent = [v for v in sops.slab_variants(c) if v >= 2000000]
+    assert persistent
+    for v in persistent:
+        bm = sops.slab_block_rows(c, v)
+        assert (live + bm - 1) // bm > 1100
+        meta = sops.slab_build(nbr, n, m_dev, bm)
+        kw = dict(residual=res, relu=True, num_out_dev=m_dev)
+        got = sops.sparse_conv_slab(f, img, meta, n, c, c, variant=v, out=torch.zeros_like(f), **kw)
+        twin = sops.sparse_conv_slab(f, img, meta, n, c, c, variant=v - 1000000, out=torch.zeros_like(f), **kw)
+        assert torch.equal(got, twin)
+        assert float(got[:live].float().abs().sum()) > 0 and float(got[live:].float().abs().sum()) == 0
 
 
 @pytest.mark.parametrize("bm", [128, 256])
