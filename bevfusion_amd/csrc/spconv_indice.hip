@@ -693,6 +693,7 @@ __global__ __launch_bounds__(BM) void sp_slab_from_index_kernel(const int* __res
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   const int blk = blockIdx.x, t = threadIdx.x, row = blk * BM + t;
+  if (blk * BM >= m) return;   // launches are sized by capacity (5-14x the live rows at 8 frames): nobody reads a dead block's metadata
   const bool live = row < m;
   const int4 c = live ? ((const int4*)indices)[row] : make_int4(0, 0, 0, 0);
   int v[27];

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ 
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   const int blk = blockIdx.x, t = threadIdx.x, row = blk * BM + t;
+  if (blk * BM >= m) return;   // capacity-sized launch: nobody reads a dead block's metadata
   const bool live = row < m;
   int v[27];
 #pragma unroll
