@@ -346,6 +346,10 @@ __global__ void vox_counts_batch_kernel(VoxBatch vb, const uint32_t* __restrict_
   if (total) *total = (int)run;
 }
 
+// One thread per sorted row; the first row of every run of equal keys (the voxel's earliest point: the sort is stable) sums
+// the run.  The run length comes from the wave's ballot of run boundaries (no dependent walk over the keys), the point indices
+// of the run and then the points themselves are fetched as batches of independent, PREDICATED loads (a lane only requests the
+// rows it owns) before they are added in input order: two memory round trips per voxel instead of two per point.
 __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
     VoxBatch vb, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ first_scan, const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
@@ -354,40 +358,73 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
   const int b = blockIdx.y;
   const uint32_t n = vb.off[b + 1] - vb.off[b];
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t J = vb.off[b] + j;
-  const uint32_t k = keys[J];
-  if (k >= ncells || (j != 0 && keys[J - 1] == k)) return;  // head rows only
-  const uint32_t vid = first_scan[vb.off[b] + idx[J]] - first_scan[vb.off[b]];
+  const bool in = j < n;
+  const uint32_t J = vb.off[b] + (in ? j : 0u);
+  const uint32_t k = in ? keys[J] : 0xFFFFFFFFu;
+  const bool valid = in && k < ncells;
+  const bool head = valid && (j == 0 || keys[J - 1] != k);
+  // rows up to the next boundary (next head, first invalid row, end of the sample): inside the wave from the ballot, past its
+  // last lane by comparing keys (few runs straddle a wave)
+  const unsigned long long bound = __ballot(head || !valid);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long above = lane < 63 ? bound >> (lane + 1) : 0ull;
+  uint32_t len;
+  if (above) {
+    len = (uint32_t)__ffsll((long long)above);
+  } else {
+    len = (uint32_t)(64 - lane);
+    if (head)
+      while (j + len < n && len < (uint32_t)max_points && keys[J + len] == k) ++len;
+  }
+  if (!head) return;
+  const uint32_t i0 = idx[J];
+  const uint32_t vid = first_scan[vb.off[b] + i0] - first_scan[vb.off[b]];
   if (vid >= (uint32_t)max_voxels) return;
   const size_t row = (size_t)rowbase[b] + vid;
   const float* __restrict__ points = vb.pts[b];
-  const uint32_t room = n - j < (uint32_t)max_points ? n - j : (uint32_t)max_points;
-  int cnt = 0;
-  if (nfeat <= 8) {
-    // point-major walk: one index load per point, all its features accumulated in registers (same per-feature summation
-    // order as the reference's sum over the point slots: r ascending)
+  const int cnt = (int)(len < (uint32_t)max_points ? len : (uint32_t)max_points);
+  const float fc = (float)cnt;
+  if (nfeat == 5) {   // the nuScenes layout (x, y, z, intensity, time): one 16-byte + one 4-byte load per point
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < cnt; r0 += 4) {
+      uint32_t pi[4];
+      pi[0] = r0 == 0 ? i0 : idx[J + r0];
+#pragma unroll
+      for (int u = 1; u < 4; ++u)
+        if (r0 + u < cnt) pi[u] = idx[J + r0 + u];
+      float v[4][5];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r0 + u < cnt) {
+          const float* p = points + (size_t)pi[u] * 5;
+          typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+          const f4u q = *(const f4u*)p;
+          v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
+          v[u][4] = p[4];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r0 + u < cnt) {
+#pragma unroll
+          for (int f = 0; f < 5; ++f) acc[f] += v[u][f];   // same per-feature order as the reference's sum over the slots
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 5; ++f) feats[row * 5 + f] = __fdiv_rn(acc[f], fc);
+  } else if (nfeat <= 8) {
     float acc[8];
 #pragma unroll
     for (int f = 0; f < 8; ++f) acc[f] = 0.f;
-    for (uint32_t r = 0; r < room; ++r) {
-      if (r && keys[J + r] != k) break;
+    for (int r = 0; r < cnt; ++r) {
       const float* p = points + (size_t)idx[J + r] * nfeat;
 #pragma unroll
       for (int f = 0; f < 8; ++f)
         if (f < nfeat) acc[f] += p[f];
-      ++cnt;
     }
-    const float fc = (float)cnt;
 #pragma unroll
     for (int f = 0; f < 8; ++f)
       if (f < nfeat) feats[row * nfeat + f] = __fdiv_rn(acc[f], fc);
   } else {
-    for (uint32_t r = 0; r < room; ++r) {
-      if (r && keys[J + r] != k) break;
-      ++cnt;
-    }
-    const float fc = (float)cnt;
     for (int f = 0; f < nfeat; ++f) {
       float s = 0.f;
       for (int r = 0; r < cnt; ++r) s += points[(size_t)idx[J + r] * nfeat + f];
