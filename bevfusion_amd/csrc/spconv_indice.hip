@@ -81,12 +81,27 @@ __device__ __forceinline__ uint32_t hash_home(uint32_t key, uint32_t b, uint32_t
   return (b * region + (hash_u32(key) & (region - 1u))) & mask;
 }
 
+// Rows [lo, hi) of this workgroup when n rows are dealt out as gridDim.x contiguous chunks and XCD x (= blockIdx.x % 8:
+// workgroups go to the XCDs round-robin) takes the x-th eighth of them.  A batch is packed sample after sample, so each XCD
+// then works on about one sample at a time and that sample's slice of the index (a 4 MB hash region, 2.7 MB of rank words) stays in
+// ITS 4 MB L2 — with a grid-stride loop every XCD touched every sample and the probes went to the Infinity Cache.
+__device__ __forceinline__ void xcd_chunk(int n, int& lo, int& hi) {
+  const int nb = (int)gridDim.x;
+  int chunk = (int)blockIdx.x;
+  if ((nb & 7) == 0) chunk = ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
+  const int per = (n + nb - 1) / nb;
+  lo = chunk * per;
+  hi = lo + per < n ? lo + per : n;
+}
+
 __global__ __launch_bounds__(256) void sp_hash_insert_kernel(const int* __restrict__ indices, int n_cap,
                                                              const int* __restrict__ n_dev, ConvGeom g,
                                                              uint2* __restrict__ slots, uint32_t mask, uint32_t region) {
-  int i = blockIdx.x * 256 + threadIdx.x;
   int n = n_dev ? *n_dev : n_cap;
   if (n > n_cap) n = n_cap;
+  int chunk = (int)blockIdx.x;   // XCD x inserts the x-th eighth of the rows (see xcd_chunk)
+  if ((gridDim.x & 7u) == 0) chunk = ((int)blockIdx.x & 7) * (int)(gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  const int i = chunk * 256 + threadIdx.x;
   if (i >= n) return;
   const int4 c = ((const int4*)indices)[i];  // (b, x, y, z)
   uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + c.y) * g.in_shape[1] + c.z) * g.in_shape[2] + c.w);
@@ -160,7 +175,9 @@ __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out
   const int kz = k % g.ksize[2];
   const int ky = (k / g.ksize[2]) % g.ksize[1];
   const int kx = k / (g.ksize[2] * g.ksize[1]);
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) {
+  int lo, hi;
+  xcd_chunk(m, lo, hi);
+  for (int o = lo + threadIdx.x; o < hi; o += 256) {
     const int4 c = ((const int4*)out_indices)[o];
     int ix_, iy, iz;
     int r = -1;
@@ -182,7 +199,9 @@ __global__ __launch_bounds__(256) void sp_nbr_from_inputs_kernel(const int* __re
                                                                  int* __restrict__ nbr, int nbr_stride) {
   int n = n_dev ? *n_dev : n_cap;
   if (n > n_cap) n = n_cap;
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+  int lo, hi;
+  xcd_chunk(n, lo, hi);
+  for (int j = lo + threadIdx.x; j < hi; j += 256) {
     const int4 c = ((const int4*)indices)[j];
     for (int kx = 0; kx < g.ksize[0]; ++kx) {
       int ox, oy, oz;
@@ -230,7 +249,9 @@ __global__ __launch_bounds__(256) void sp_nbr_subm_sym_kernel(const int* __restr
   const int ky = (k / g.ksize[2]) % g.ksize[1];
   const int kx = k / (g.ksize[2] * g.ksize[1]);
   const bool centre = k == g.K / 2;
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < m; o += gridDim.x * 256) {
+  int lo, hi;
+  xcd_chunk(m, lo, hi);
+  for (int o = lo + threadIdx.x; o < hi; o += 256) {
     if (centre) {
       nbr[(size_t)k * nbr_stride + o] = o;
       continue;
@@ -257,7 +278,9 @@ __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restr
                                                               uint8_t* __restrict__ cellmap) {
   int n = n_dev ? *n_dev : n_cap;
   if (n > n_cap) n = n_cap;
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+  int lo, hi;
+  xcd_chunk(n, lo, hi);
+  for (int j = lo + threadIdx.x; j < hi; j += 256) {
     const int4 c = ((const int4*)indices)[j];
     for (int kx = 0; kx < g.ksize[0]; ++kx) {
       int ox, oy, oz;
