@@ -340,12 +340,18 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint32_t* 
 // blk[s] << bits, digit-major over its own workgroups.  A flat exclusive scan of the concatenated histograms is then
 // the destination of every (segment, digit, workgroup) run in the concatenated output: everything before segment s
 // sums to off[s].
-struct SegTile { size_t base, end; unsigned sd; size_t hcol; };
+struct SegTile { size_t base, end; unsigned sd; size_t hcol; bool live; };
 __device__ __forceinline__ SegTile seg_tile(const SortSegs& sg, int bits) {
-  int s = 0;
-  while (s + 1 < sg.nseg && blockIdx.x >= sg.blk[s + 1]) ++s;
-  const unsigned lb = blockIdx.x - sg.blk[s];
+  // workgroup -> tile: XCD x (= blockIdx.x % 8, workgroups go to the XCDs round-robin) takes the x-th contiguous eighth of the
+  // tiles, i.e. about one segment of an 8-sweep batch: a segment's keys, values and digit buckets (2 x 2.4 MB) stay in one L2
+  // (the grid is 8 * ceil(tiles / 8) workgroups; the ones past the last tile leave: SegTile::live)
+  const unsigned tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   SegTile t;
+  t.live = tile < sg.blk[sg.nseg];
+  if (!t.live) return t;
+  int s = 0;
+  while (s + 1 < sg.nseg && tile >= sg.blk[s + 1]) ++s;
+  const unsigned lb = tile - sg.blk[s];
   t.base = (size_t)sg.off[s] + (size_t)lb * RS_TILE;
   t.end = sg.off[s + 1];
   t.sd = sg.blk[s + 1] - sg.blk[s];
@@ -356,6 +362,7 @@ __device__ __forceinline__ SegTile seg_tile(const SortSegs& sg, int bits) {
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_seg_kernel(const uint32_t* __restrict__ keys, SortSegs sg,
                                                                     int shift, int bits, uint32_t* __restrict__ hist) {
   const SegTile t = seg_tile(sg, bits);
+  if (!t.live) return;
   radix_hist_tile(keys, t.base, t.end, shift, bits, t.sd, hist + t.hcol);
 }
 
@@ -435,6 +442,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_seg_kernel(
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, SortSegs sg, int shift, int bits,
     const uint32_t* __restrict__ hist_scanned) {
   const SegTile t = seg_tile(sg, bits);
+  if (!t.live) return;
   radix_scatter_tile(keys_in, vals_in, keys_out, vals_out, t.base, t.end, shift, bits, t.sd, hist_scanned + t.hcol);
 }
 
@@ -593,11 +601,11 @@ int radix_sort_pairs_u32_segmented(uint32_t* keys_a, uint32_t* vals_a, uint32_t*
     int bits = bits_per_pass;
     if (shift + bits > nbits) bits = nbits - shift;
     if (bits <= 0) bits = 1;
-    radix_hist_seg_kernel<<<nblocks, RS_THREADS, 0, stream>>>(ki, sg, shift, bits, hist);
+    radix_hist_seg_kernel<<<(nblocks + 7) / 8 * 8, RS_THREADS, 0, stream>>>(ki, sg, shift, bits, hist);
     BEVAMD_LAUNCH_CHECK("radix_hist_seg");
     int rc = exclusive_scan_u32(hist, hist, (size_t)nblocks << bits, nullptr, scan_ws, scan_ws_bytes, stream);
     if (rc != BEVAMD_OK) return rc;
-    radix_scatter_seg_kernel<<<nblocks, RS_THREADS, 0, stream>>>(ki, vi, ko, vo, sg, shift, bits, hist);
+    radix_scatter_seg_kernel<<<(nblocks + 7) / 8 * 8, RS_THREADS, 0, stream>>>(ki, vi, ko, vo, sg, shift, bits, hist);
     BEVAMD_LAUNCH_CHECK("radix_scatter_seg");
     uint32_t* t;
     t = ki; ki = ko; ko = t;

@@ -301,30 +301,53 @@ struct VoxBatch {
   int batch;
 };
 
+// The batch kernels run one thread per row of the CONCATENATED arrays, in 256-row chunks dealt to the XCDs in contiguous eighths
+// (XCD x = blockIdx.x % 8 takes the x-th eighth): with 8 sweeps per batch every XCD works on one sweep, whose points (6 MB),
+// sort buffers and scan (1.2 MB each) then stay in that XCD's L2 instead of being touched from all eight.  The sweep of a row
+// is found by comparing against the offsets with a UNIFORM loop index (kernel-argument arrays are read with scalar loads).
+struct VoxRow {
+  bool in;        // row exists
+  int b;          // sweep
+  uint32_t J, j;  // position in the concatenated arrays / inside the sweep
+  uint32_t lo, n; // first row and row count of the sweep
+  const float* pts;
+};
+__device__ __forceinline__ VoxRow vox_locate(const VoxBatch& vb) {
+  VoxRow r;
+  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  r.J = chunk * 256u + threadIdx.x;
+  r.in = r.J < vb.off[vb.batch];
+  r.b = 0;
+  r.lo = 0;
+  uint32_t hi = vb.off[1];
+  r.pts = vb.pts[0];
+  for (int q = 1; q < vb.batch; ++q)
+    if (r.J >= vb.off[q]) { r.b = q; r.lo = vb.off[q]; hi = vb.off[q + 1]; r.pts = vb.pts[q]; }
+  r.j = r.J - r.lo;
+  r.n = hi - r.lo;
+  return r;
+}
+static unsigned vox_rows_grid(size_t total) { return (unsigned)(((total + 255) / 256 + 7) / 8 * 8); }
+
 __global__ __launch_bounds__(256) void vox_key_batch_kernel(VoxBatch vb, int nfeat, VoxGrid g, uint32_t ncells,
                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                             uint32_t* __restrict__ first) {
-  const int b = blockIdx.y;
-  const uint32_t n = vb.off[b + 1] - vb.off[b];
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const VoxRow r = vox_locate(vb);
+  if (!r.in) return;
   int cx, cy, cz;
-  bool ok = voxel_coord(vb.pts[b] + (size_t)i * nfeat, g, cx, cy, cz);
-  keys[vb.off[b] + i] = ok ? (uint32_t)((cx * g.gy + cy) * g.gz + cz) : ncells;
-  vals[vb.off[b] + i] = i;
-  first[vb.off[b] + i] = 0u;
+  bool ok = voxel_coord(r.pts + (size_t)r.j * nfeat, g, cx, cy, cz);
+  keys[r.J] = ok ? (uint32_t)((cx * g.gy + cy) * g.gz + cz) : ncells;
+  vals[r.J] = r.j;
+  first[r.J] = 0u;
 }
 
 __global__ __launch_bounds__(256) void vox_heads_batch_kernel(VoxBatch vb, const uint32_t* __restrict__ keys,
                                                               const uint32_t* __restrict__ idx, uint32_t ncells,
                                                               uint32_t* __restrict__ first /*zeroed, point order*/) {
-  const int b = blockIdx.y;
-  const uint32_t n = vb.off[b + 1] - vb.off[b];
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t J = vb.off[b] + j;
-  const uint32_t k = keys[J];
-  if (k < ncells && (j == 0 || keys[J - 1] != k)) first[vb.off[b] + idx[J]] = 1u;  // stable sort: earliest point
+  const VoxRow r = vox_locate(vb);
+  if (!r.in) return;
+  const uint32_t k = keys[r.J];
+  if (k < ncells && (r.j == 0 || keys[r.J - 1] != k)) first[r.lo + idx[r.J]] = 1u;  // stable sort: earliest point
 }
 
 // counts[b] = min(voxels of sweep b, max_voxels); rowbase[b] = first output row of sweep b (packed: running sum of the
@@ -355,11 +378,11 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
     const uint32_t* __restrict__ first_scan, const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
     int max_points, int max_voxels, float* __restrict__ feats, int* __restrict__ coords4,
     int* __restrict__ num_points_per_voxel) {
-  const int b = blockIdx.y;
-  const uint32_t n = vb.off[b + 1] - vb.off[b];
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  const bool in = j < n;
-  const uint32_t J = vb.off[b] + (in ? j : 0u);
+  const VoxRow vr = vox_locate(vb);
+  const int b = vr.b;
+  const uint32_t n = vr.n, j = vr.j;
+  const bool in = vr.in;
+  const uint32_t J = in ? vr.J : 0u;
   const uint32_t k = in ? keys[J] : 0xFFFFFFFFu;
   const bool valid = in && k < ncells;
   const bool head = valid && (j == 0 || keys[J - 1] != k);
@@ -378,10 +401,10 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
   }
   if (!head) return;
   const uint32_t i0 = idx[J];
-  const uint32_t vid = first_scan[vb.off[b] + i0] - first_scan[vb.off[b]];
+  const uint32_t vid = first_scan[vr.lo + i0] - first_scan[vr.lo];
   if (vid >= (uint32_t)max_voxels) return;
   const size_t row = (size_t)rowbase[b] + vid;
-  const float* __restrict__ points = vb.pts[b];
+  const float* __restrict__ points = vr.pts;
   const int cnt = (int)(len < (uint32_t)max_points ? len : (uint32_t)max_points);
   const float fc = (float)cnt;
   if (nfeat == 5) {   // the nuScenes layout (x, y, z, intensity, time): one 16-byte + one 4-byte load per point
@@ -594,7 +617,7 @@ int bevamd_voxelize_mean_batch(const float* const* points, const int* num_points
   void* sws = cv.base + cv.off;
   const size_t sws_bytes = ws_bytes - cv.off;
 
-  const dim3 grid(cdiv(nmax, 256), batch_size), block(256);
+  const dim3 grid(vox_rows_grid(n)), block(256);
   vox_key_batch_kernel<<<grid, block, 0, stream>>>(vbt, num_features, g, ncells, keys_a, vals_a, first);
   BEVAMD_LAUNCH_CHECK("vox_key_batch");
   uint32_t *keys_s, *idx_s;
