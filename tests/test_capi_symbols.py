@@ -60,3 +60,55 @@ def test_product_op_refuses_cpu_tensors():
 
     with pytest.raises(RuntimeError, match="GPU tensor"):
         bev_pool(torch.zeros(4, 8), torch.zeros(4, 4, dtype=torch.long), 1, 1, 2, 2)
+
+
+def test_host_side_tables_of_the_slab_kernels():
+    """Pure host logic of the staged-rows convolution family: variant codes (LDS-filter, 1xxxxxx register-filter, 2xxxxxx
+    persistent), their block sizes, the 16-bit slot bound of a grid, the metadata sizes."""
+    lib = _capi.load()
+    for cin in (32, 64, 128):
+        codes = (ctypes.c_int * 64)()
+        n = lib.bevamd_spconv_slab_variants(cin, codes, 64)
+        got = [codes[i] for i in range(n)]
+        assert n >= 3 and len(set(got)) == n
+        regw = [v for v in got if 1000000 <= v < 2000000]
+        pers = [v for v in got if v >= 2000000]
+        assert regw and sorted(v + 1000000 for v in regw) == sorted(pers)      # every shape is built in both flavours
+        for v in got:
+            rows = lib.bevamd_spconv_slab_block_rows(cin, v)
+            assert rows in (128, 256)
+            if v >= 1000000:                                                   # RW * 16 * MT from the code itself
+                assert rows == (v // 100 % 10) * 16 * (v // 1000 % 10)
+                assert lib.bevamd_spconv_slab_block_rows(cin, v % 1000000 + 2000000) == rows   # the persistent twin: same blocks
+        assert lib.bevamd_spconv_slab_block_rows(cin, 0) == lib.bevamd_spconv_slab_block_rows(cin, got[0])
+        assert lib.bevamd_spconv_slab_block_rows(cin, 1999999) == 0            # not built
+    assert lib.bevamd_spconv_slab_block_rows(48, 0) == 0
+    shape = (ctypes.c_int * 3)(720, 720, 21)
+    assert lib.bevamd_spconv_slab_grid_ok(shape, 256) == 1                     # 256 + 722 * 21 + 2 rows fit 16-bit slots
+    wide = (ctypes.c_int * 3)(720, 4000, 21)
+    assert lib.bevamd_spconv_slab_grid_ok(wide, 128) == 0
+    assert lib.bevamd_spconv_slab_hdr_bytes(1000, 128) == 8 * 3 * 8
+    assert lib.bevamd_spconv_slab_slot_bytes(1000, 128) == 8 * 27 * 128 * 2
+    assert lib.bevamd_spconv_slab_ablation_mask() == 0                         # shipped builds compile nothing out
+
+
+def test_batch_entry_points_validate_their_host_arrays():
+    """Segment tables of the batched voxelizer / segmented sort are host arrays: sizes and limits are checked before any
+    GPU work (workspace queries return 0 for a table they would reject)."""
+    lib = _capi.load()
+    ok = (ctypes.c_int * 3)(1000, 0, 5000)
+    assert lib.bevamd_radix_sort_segmented_workspace_bytes(ok, 3) >= 6 * 512 * 4
+    assert lib.bevamd_voxelize_mean_batch_workspace_bytes(ok, 3) >= 5 * 6000 * 4
+    neg = (ctypes.c_int * 2)(10, -1)
+    assert lib.bevamd_radix_sort_segmented_workspace_bytes(neg, 2) == 0
+    assert lib.bevamd_voxelize_mean_batch_workspace_bytes(neg, 2) == 0
+    many = (ctypes.c_int * 65)(*([1] * 65))
+    assert lib.bevamd_radix_sort_segmented_workspace_bytes(many, 65) == 0      # at most 64 segments per launch
+    assert lib.bevamd_voxelize_mean_batch_workspace_bytes(None, 1) == 0
+    vs, cr = (ctypes.c_float * 3)(0.5, 0.5, 0.5), (ctypes.c_float * 6)(0, 0, 0, 10, 10, 2)
+    rc = lib.bevamd_voxelize_mean_batch(None, None, 1, 5, vs, cr, 10, 100, 1, None, None, None, None, None, None, 0, None)
+    assert rc != 0 and "host arrays" in _capi.last_error()
+    one = (ctypes.c_int * 1)(4)
+    ptrs = (ctypes.c_void_p * 1)(None)
+    rc = lib.bevamd_voxelize_mean_batch(ptrs, one, 1, 2, vs, cr, 10, 100, 1, None, None, None, None, None, None, 0, None)
+    assert rc != 0 and "num_features" in _capi.last_error()
