@@ -6,6 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # sweep_spconv.timeit
 from bevfusion_amd import synth  # noqa: E402
 from bevfusion_amd.spconv import ops as sops  # noqa: E402
 from bevfusion_amd.spconv.fused import _SLAB_DEFAULT  # noqa: E402

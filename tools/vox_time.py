@@ -1,5 +1,7 @@
+"""Time the batched voxelizer (bevamd_voxelize_mean_batch) against one call per sample on 8 flagship sweeps:
+    python tools/vox_time.py"""
 import torch, time, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevfusion_amd import synth
 from bevfusion_amd import voxel as V
 dev = torch.device("cuda:0")
