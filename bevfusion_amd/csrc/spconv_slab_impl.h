@@ -32,12 +32,12 @@ static int run(const SlabArgs& sa, hipStream_t stream) {
   return BEVAMD_OK;
 }
 
-// the built configurations per input width (first entry = default); X(...) expands once per configuration
+// the built configurations per input width (first entry = what variant 0 means); X(...) expands once per configuration
 // MI355X, 8 flagship frames per launch, fp16 (profiles/r02_slab_sweep_b8.txt; gather kernel in brackets):
 //   32->32 2.08 M rows: 322113 218 us [292]   64->64 788 k rows: 642113 206 us / 642232 204 us [246]
-//   128->128 192 k rows: 642213 167 us / 322232 166 us [193];  one frame: 30 [41], 34 [35], 42-61 [38] -> the 128-channel layers
-//   keep the gather kernel below 4 frames (spconv/fused.py).  64 rows per wave (MT = 4) was measured too: 274-389 us, one
-//   workgroup per CU is too little latency hiding.
+//   128->128 192 k rows: 642213 167 us / 322232 166 us [193].  64 rows per wave (MT = 4) was measured too: 274-389 us, one
+//   workgroup per CU is too little latency hiding.  The encoder's defaults are the register-filter / persistent shapes further
+//   down (spconv/fused.py: _SLAB_DEFAULT); these LDS-filter kernels stay built as the reference point of the sweeps.
 #define BEVAMD_SLAB_SHAPES_32(X) X(32, 2, 4, 1, 3, 192) X(32, 2, 4, 3, 3, 192) X(32, 2, 4, 9, 2, 192)
 #define BEVAMD_SLAB_SHAPES_64(X) X(64, 2, 4, 1, 3, 184) X(64, 2, 8, 1, 3, 320) X(64, 2, 8, 3, 2, 320) X(32, 2, 4, 1, 3, 192)
 #define BEVAMD_SLAB_SHAPES_128(X) X(64, 2, 8, 1, 3, 320) X(64, 1, 8, 1, 3, 192) X(32, 2, 8, 1, 3, 384) X(32, 2, 8, 3, 2, 384)

@@ -316,12 +316,15 @@ def summarize_layer_profile(records, elem_bytes=2):
 _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 2211, (128, 128): 2221}
 
 
-# Slab (staged-rows) kernels for the 3x3x3 SubM layers of the sorted levels (csrc/spconv_slab.h): BEVAMD_SPCONV_SLAB=0 keeps
-# the gather kernels; BEVAMD_SPCONV_SLAB_VARIANTS="32:322133,64:642232" overrides the per-width variant (tuning).
-# Measured (tools/sweep_spconv.py --slab, profiles/r02_slab_sweep_*.txt): 8 frames 218 / 206 / 167 us against 292 / 246 / 193 us
-# of the gather kernels for 32 / 64 / 128 channels; one frame 30 / 34 us against 41 / 35 us, but 42+ against 38 us at 128
-# channels (188 blocks on 256 CUs) -> the 128-channel layers switch over from 4 frames per step.
-_SLAB_DEFAULT = {32: 2324410, 64: 1644222, 128: 1644220}   # register-filter kernels (spconv_slab_regw.h); 0 = the library's first-listed variant
+# Slab (staged-rows) kernels for the 3x3x3 SubM layers of the sorted levels (csrc/spconv_slab*.h): BEVAMD_SPCONV_SLAB=0 keeps
+# the gather kernels; BEVAMD_SPCONV_SLAB_VARIANTS="32:322133,64:642232" overrides the per-width variant (tuning).  Codes:
+# xxxxxx = filter staged in LDS (spconv_slab.h), 1xxxxxx = filter fragments in registers (spconv_slab_regw.h), 2xxxxxx = the same,
+# persistent (spconv_slab_persist.h).  Measured (tools/sweep_spconv.py --slab, profiles/r02_slab_sweep_b{1,8}_v3.txt), 8 frames,
+# 32 / 64 / 128 channels: 186 / 183 / 151 us against 290 / 242 / 193 us of the gather kernels (first cut: 211 / 198 / 164); one
+# frame: 26.7 / 30.8 us against 41 / 35.8 us, 128 channels 38.5-40 against 38.8 us (188 blocks on 256 CUs) -> those layers switch
+# over from 4 frames per step.  The persistent 32-channel kernel was only measured at 8 frames: smaller batches keep its one-block twin.
+_SLAB_DEFAULT = {32: 2324410, 64: 1644222, 128: 1644220}
+_SLAB_DEFAULT_SMALL_BATCH = {32: 1322410}   # below 4 frames per step
 _SLAB_MIN_BATCH = {128: 4}
 # BEVAMD_SPCONV_SLAB_DIRECT=0: build the slab metadata from the int32 neighbour table instead of straight from the rank index
 _SLAB_DIRECT = os.environ.get("BEVAMD_SPCONV_SLAB_DIRECT", "1") != "0"
@@ -343,7 +346,8 @@ def _slab_variant_for(conv, lvl, cin, cout):
         return None
     if cin not in _SLAB_DEFAULT or lvl.batch < _SLAB_MIN_BATCH.get(cin, 1):
         return None
-    variant = _slab_overrides().get(cin, _SLAB_DEFAULT[cin])
+    default = _SLAB_DEFAULT_SMALL_BATCH.get(cin, _SLAB_DEFAULT[cin]) if lvl.batch < 4 else _SLAB_DEFAULT[cin]
+    variant = _slab_overrides().get(cin, default)
     rows = ops.slab_block_rows(cin, variant)
     if rows == 0 or not ops.slab_grid_ok(lvl.shape, rows):
         return None
