@@ -59,6 +59,10 @@ def parse():
                          "lidar: the WHOLE LiDAR branch (one HIP graph) runs on a second stream beside the camera stages, which is how the "
                          "two independent branches of the model can be scheduled; stage times then overlap and the bev_pool roofline figure "
                          "is measured WITH that concurrency")
+    ap.add_argument("--voxel-order", choices=["key", "first"], default="key",
+                    help="row order of the voxelizer's output: key = ascending linear cell index (level 1 of the encoder then runs on the "
+                         "staged-rows kernels with sorted-key neighbour search; the dense BEV output is identical), first = the "
+                         "reference's first-appearance numbering (hash index + gather kernels at level 1)")
     ap.add_argument("--no-graph", action="store_true", help="launch the LiDAR branch kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--mode", choices=["infer", "train-step"], default="infer",
                     help="infer (default): the inference hot path of BASELINE configs[3]; train-step: forward + backward + optimizer "
@@ -486,17 +490,18 @@ def main():
     bev = torch.empty((B, D, H, W, C), dtype=torch.float32, device=dev)
 
     state = {}
+    coors_order = "linear" if args.voxel_order == "key" else None
 
     def lidar_branch():
         # voxelize + mean into capacity-sized buffers, voxel count stays on the device (no host sync), then the
         # sparse encoder on its sync-free fused inference path
         vf, vc, _, cnt = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                               cfg["max_voxels"][1])
+                                               cfg["max_voxels"][1], order=args.voxel_order)
         mid = torch.cuda.Event(enable_timing=True) if state.get("probe") else None
         if mid is not None:
             mid.record()
         with torch.no_grad():
-            out = enc(vf, vc, B, num_voxels=cnt)
+            out = enc(vf, vc, B, num_voxels=cnt, coors_order=coors_order)
         return out, cnt, mid
 
     from bevfusion_amd.sharding import barrier, max_over_ranks, sum_over_ranks
@@ -546,9 +551,9 @@ def main():
         """coordinates only: voxelize + mean, then the encoder's whole rulebook chain (hash, active sets, neighbour tables, slab
         metadata of every level) — SparseEncoder.prepare_geometry"""
         vf, vc, _, cnt = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                               cfg["max_voxels"][1])
+                                               cfg["max_voxels"][1], order=args.voxel_order)
         with torch.no_grad():
-            lvl = enc.prepare_geometry(vc, B, num_voxels=cnt)
+            lvl = enc.prepare_geometry(vc, B, num_voxels=cnt, coors_order=coors_order)
         return vf, vc, cnt, lvl
 
     def lidar_tail(vf, vc, cnt, lvl):
@@ -755,6 +760,7 @@ def main():
                             "too, so the camera reduction is counted twice in `value`"},
                 "lidar_branch_eager_ms": {"voxelize": eager_vox_ms, "sparse_encoder": eager_enc_ms},
                 "hip_graph": graph is not None or graph_tail is not None,
+                "voxel_order": args.voxel_order,
                 "overlap": ("head: voxelization + rulebook chain on a second HIP stream beside the camera stages (the camera stage times, "
                             "bev_pool's roofline figure included, are measured WITH that concurrency)") if overlap_head else
                            ("lidar: the whole LiDAR branch on a second HIP stream beside the camera stages (stage times overlap: the last "

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "bevamd_voxel_compact": (I, [P, P, P, P, I, I, I, P, P, P, P, P]),
     "bevamd_voxelize_mean_batch_workspace_bytes": (Z, [P, I]),
     "bevamd_voxelize_mean_batch": (I, [P, P, I, I, P, P, I, I, I, P, P, P, P, P, P, Z, P]),
+    "bevamd_voxelize_mean_batch_ex": (I, [P, P, I, I, P, P, I, I, I, I, P, P, P, P, P, P, Z, P]),
     # spconv
     "bevamd_spconv_rulebook_workspace_bytes": (Z, [I, I, P, I]),
     "bevamd_spconv_hash_index_bytes": (Z, [I]),
@@ -86,6 +87,9 @@ _SIGNATURES = {
     "bevamd_spconv_slab_slot_bytes": (Z, [I, I]),
     "bevamd_spconv_slab_build": (I, [P, I, I, P, I, P, P, P, P]),
     "bevamd_spconv_slab_build_from_index": (I, [P, I, P, I, P, I, P, I, I, P, P, P, P]),
+    "bevamd_spconv_sorted_index_bytes": (Z, [I, I, P]),
+    "bevamd_spconv_sorted_index_build": (I, [P, I, P, I, P, P, Z, P, P]),
+    "bevamd_spconv_slab_build_from_sorted": (I, [P, I, P, I, P, P, P, P, I, P, I, I, P, P, P, P]),
     "bevamd_spconv_conv_forward_slab": (I, [P, I, I, I, P, P, P, I, I, P, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_wgrad_workspace_bytes": (Z, [I, I, I]),
     "bevamd_spconv_conv_wgrad": (I, [P, P, I, P, I, I, I, I, I, P, P, Z, P]),

@@ -744,6 +744,112 @@ __global__ __launch_bounds__(BM) void sp_slab_from_index_kernel(const int* __res
   slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
 }
 
+
+// ---- sorted-key lookups: a voxel set whose rows are in ascending linear index is its own index -----------------------------
+// (the voxelizer's key-order output, every level a strided convolution produced).  keys[i] = linear index of row i;
+// xstart[b*X + x] = first row of x-plane (b, x), xstart[B*X] = n: a lookup is a binary search inside ONE x-plane's segment
+// (~100 rows at level 1), whose keys the neighbouring rows of a workgroup keep in L1.  No hash insert, no table to clear.
+// status bit 1 (value 2): rows are NOT in strictly ascending order (the caller's promise is broken).
+__global__ __launch_bounds__(256) void sp_sorted_keys_kernel(const int* __restrict__ indices, int n_cap,
+                                                             const int* __restrict__ n_dev, ConvGeom g,
+                                                             uint32_t* __restrict__ keys, int* __restrict__ xstart,
+                                                             int* __restrict__ status) {
+  int n = n_dev ? *n_dev : n_cap;
+  if (n > n_cap) n = n_cap;
+  const int nplanes = g.batch * g.in_shape[0];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (n <= 0) {   // no rows: every plane is empty
+    for (int j = i; j <= nplanes; j += gridDim.x * 256) xstart[j] = 0;
+    return;
+  }
+  if (i >= n) return;
+  const int4 c = ((const int4*)indices)[i];
+  const int bx = c.x * g.in_shape[0] + c.y;
+  const uint32_t key = ((uint32_t)bx * (uint32_t)g.in_shape[1] + (uint32_t)c.z) * (uint32_t)g.in_shape[2] + (uint32_t)c.w;
+  keys[i] = key;
+  int prev = -1;
+  if (i > 0) {
+    const int4 p = ((const int4*)indices)[i - 1];
+    prev = p.x * g.in_shape[0] + p.y;
+    const uint32_t pk = ((uint32_t)prev * (uint32_t)g.in_shape[1] + (uint32_t)p.z) * (uint32_t)g.in_shape[2] + (uint32_t)p.w;
+    if (pk >= key && status) atomicOr(status, 2);
+  }
+  const int top = bx < nplanes ? bx : nplanes;   // a coordinate outside the grid cannot run past the directory
+  for (int j = prev + 1; j <= top; ++j) xstart[j] = i;
+  if (i == n - 1)
+    for (int j = top + 1; j <= nplanes; ++j) xstart[j] = n;
+}
+
+// first position in [lo, hi) whose key is >= t
+__device__ __forceinline__ int sorted_lower_bound(const uint32_t* __restrict__ keys, int lo, int hi, uint32_t t) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Slab metadata (slab_emit: per block of BM output rows and kernel plane kx the input range, + 16-bit slots) of a 3x3x3
+// convolution — submanifold OR strided — whose INPUT set is in ascending linear index, found by sorted-key search: thread t
+// looks at the <= 9 (kx, ky) lines of its output row; the three kz taps of a line are consecutive keys, so one lower_bound
+// (inside the x-plane's segment, continued from the previous line's position) + three compares serve them.  Output rows
+// must be in ascending linear index too (what makes a plane's inputs a contiguous range).  SUBM: the centre tap is the row.
+template <int BM, bool SUBM>
+__global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __restrict__ out_indices, int m_cap,
+                                                                 const int* __restrict__ m_dev, ConvGeom g,
+                                                                 const uint32_t* __restrict__ in_keys,
+                                                                 const int* __restrict__ in_xstart,
+                                                                 int2* __restrict__ hdr, uint16_t* __restrict__ slots,
+                                                                 int* __restrict__ status) {
+  int m = m_dev ? *m_dev : m_cap;
+  if (m > m_cap) m = m_cap;
+  const int nblk = (m + BM - 1) / BM, per = (nblk + 7) >> 3;
+  const int xcd = (int)blockIdx.x & 7, bix = (int)blockIdx.x >> 3;
+  const int blk = (gridDim.x & 7u) == 0 ? xcd * per + bix : (int)blockIdx.x;
+  if (((gridDim.x & 7u) == 0 && bix >= per) || blk >= nblk) return;
+  const int t = threadIdx.x, row = blk * BM + t;
+  const bool live = row < m;
+  const int4 c = live ? ((const int4*)out_indices)[row] : make_int4(0, 0, 0, 0);
+  const int X = g.in_shape[0], Y = g.in_shape[1], Z = g.in_shape[2];
+  const int x0 = c.y * g.stride[0] - g.pad[0], y0 = c.z * g.stride[1] - g.pad[1], z0 = c.w * g.stride[2] - g.pad[2];
+  const int kzf = z0 < 0 ? -z0 : 0;          // first kz tap inside the grid
+  int v[27];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int x = x0 + kx;
+    const bool xok = live && x >= 0 && x < X && kzf < 3 && z0 + kzf < Z;
+    int p = 0, hi = 0;
+    if (xok) {
+      const int bx = c.x * X + x;
+      p = in_xstart[bx];
+      hi = in_xstart[bx + 1];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int y = y0 + ky;
+      const bool ok = xok && y >= 0 && y < Y && p < hi;
+      uint32_t tgt = 0;
+      if (ok) {
+        tgt = (((uint32_t)c.x * (uint32_t)X + (uint32_t)x) * (uint32_t)Y + (uint32_t)y) * (uint32_t)Z + (uint32_t)(z0 + kzf);
+        p = sorted_lower_bound(in_keys, p, hi, tgt);
+      }
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        const int k = (kx * 3 + ky) * 3 + kz;
+        int r = -1;
+        if (SUBM && k == 13) {
+          r = live ? row : -1;
+          if (ok && kz >= kzf && p < hi && in_keys[p] == tgt + (uint32_t)(kz - kzf)) ++p;   // step over the row itself
+        } else if (ok && kz >= kzf && z0 + kz < Z && p < hi) {
+          if (in_keys[p] == tgt + (uint32_t)(kz - kzf)) { r = p; ++p; }
+        }
+        v[k] = r;
+      }
+    }
+  }
+  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+}
+
 }  // namespace bevamd
 
 using namespace bevamd;
@@ -1006,6 +1112,64 @@ int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int
   else { if (index_kind == INDEX_HASH) BEVAMD_GO(256, INDEX_HASH); else BEVAMD_GO(256, INDEX_RANK); }
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("sp_slab_from_index");
+  return BEVAMD_OK;
+}
+
+/* Sorted-key index of a voxel set whose rows are in ascending linear index (b, x, y, z): keys [n_cap] uint32 and the
+ * x-plane directory xstart [batch * shape[0] + 1] int32 (bevamd_spconv_sorted_index_bytes: both, keys first, directory at
+ * byte offset align256(n_cap * 4)).  status (optional int32, device): bit 1 is set when the rows are not strictly ascending. */
+size_t bevamd_spconv_sorted_index_bytes(int n_cap, int batch_size, const int* shape) {
+  if (!shape || batch_size <= 0 || n_cap < 0) return 0;
+  return align_up((size_t)(n_cap > 0 ? n_cap : 1) * 4, 256) + align_up(((size_t)batch_size * shape[0] + 1) * 4, 256);
+}
+
+int bevamd_spconv_sorted_index_build(const int* indices, int n_cap, const int* n_dev, int batch_size, const int* shape,
+                                     void* index, size_t index_bytes, int* status, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvGeom g;
+  const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+  int rc = make_geom(batch_size, shape, shape, one, one, zero, nullptr, 1, g);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n_cap >= 0 && (indices || n_cap == 0), "spconv_sorted_index_build: bad input");
+  const size_t need = bevamd_spconv_sorted_index_bytes(n_cap, batch_size, shape);
+  if (!index || index_bytes < need) {
+    set_error("spconv sorted index: buffer too small (%zu < %zu)", index_bytes, need);
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  uint32_t* keys = (uint32_t*)index;
+  int* xstart = (int*)((char*)index + align_up((size_t)(n_cap > 0 ? n_cap : 1) * 4, 256));
+  sp_sorted_keys_kernel<<<dim3(cdiv(n_cap > 0 ? n_cap : 1, 256)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, keys, xstart, status);
+  BEVAMD_LAUNCH_CHECK("sp_sorted_keys");
+  return BEVAMD_OK;
+}
+
+/* Slab metadata (hdr / slots of bevamd_spconv_slab_build, same layout) of a 3x3x3 convolution from the SORTED-KEY index of its
+ * input set: subm != 0 -> the submanifold convolution over the set itself (out_indices = the set, stride / padding ignored);
+ * else the strided convolution whose active outputs are out_indices [m_cap, 4] on out_shape (rows in ascending linear index,
+ * as bevamd_spconv_downsample emits them).  Replaces the neighbour table (108 B per row written and read back) for layers that
+ * run on the slab kernels. */
+int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
+                                         const int* in_shape, const int* out_shape, const int* stride, const int* padding,
+                                         int subm, const void* in_index, int in_n_cap, int block_rows, void* hdr, void* slots,
+                                         int* status, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvGeom g;
+  const int k3[3] = {3, 3, 3};
+  int rc = make_geom(batch_size, in_shape, subm ? in_shape : out_shape, k3, stride, padding, nullptr, subm, g);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(block_rows == 128 || block_rows == 256, "spconv_slab_build_from_sorted: block_rows %d (128 | 256)", block_rows);
+  BEVAMD_REQUIRE(m_cap >= 0 && in_n_cap >= 0, "spconv_slab_build_from_sorted: bad sizes");
+  if (m_cap == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(out_indices && in_index && hdr && slots, "spconv_slab_build_from_sorted: null buffer");
+  const uint32_t* keys = (const uint32_t*)in_index;
+  const int* xstart = (const int*)((const char*)in_index + align_up((size_t)(in_n_cap > 0 ? in_n_cap : 1) * 4, 256));
+  const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;
+#define BEVAMD_GO(BM, SUBM) \
+  sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, (int2*)hdr, (uint16_t*)slots, status)
+  if (block_rows == 128) { if (subm) BEVAMD_GO(128, true); else BEVAMD_GO(128, false); }
+  else { if (subm) BEVAMD_GO(256, true); else BEVAMD_GO(256, false); }
+#undef BEVAMD_GO
+  BEVAMD_LAUNCH_CHECK("sp_slab_from_sorted");
   return BEVAMD_OK;
 }
 

@@ -47,6 +47,7 @@ struct SlabArgs {
   const int2* hdr;           // [nblocks][PLANES] (lo, cnt)
   const uint16_t* slots;     // [nblocks][27][BM]
   unsigned wimg_bytes;       // size of the filter image (buffer descriptor bound)
+  unsigned slot_bytes;       // size of the slot table (buffer descriptor bound; narrow-row kernels)
   unsigned long long* prof;  // -DBEVAMD_PROFILING builds: [4] cycle sums over all waves (issue, multiply, dma wait, barrier) + [4] = waves
 };
 

@@ -21,14 +21,20 @@ void bevamd_spconv_slab_set_profile_buffer(void* buf) { g_slab_prof = (unsigned 
 /* the ablation mask this library was COMPILED with (-DBEVAMD_SLAB_ABL=mask; 0 in every shipped build) */
 int bevamd_spconv_slab_ablation_mask(void) { return slab::SLAB_ABL; }
 
-/* Rows per block of slab variant `variant` (0 = default) for a cin-channel SubM 3x3x3 convolution, 0 if none is built
- * (cin must be 32, 64 or 128 and cout == cin).  The block size fixes the metadata layout of bevamd_spconv_slab_build. */
+/* Rows per block of slab variant `variant` (0 = default) for a cin-channel 3x3x3 convolution, 0 if none is built (cin 32, 64 or
+ * 128 with cout == cin; cin <= 16 = the narrow-row kernels, 256 rows or 3000128 -> 128).  The block size fixes the metadata
+ * layout of bevamd_spconv_slab_build*. */
 int bevamd_spconv_slab_block_rows(int cin, int variant) {
   return slab::block_rows_of(cin, variant);
 }
 
 /* The variant codes built for `cin` (for sweeps): writes up to max_n codes, returns how many exist. */
 int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
+  if (cin >= 1 && cin <= 16) {
+    if (max_n > 0) codes[0] = slab::SMALL_BASE + 256;
+    if (max_n > 1) codes[1] = slab::SMALL_BASE + 128;
+    return 2;
+  }
   int n = 0, nr = 0;
   const slab::Shape* s = slab::shapes_of(cin, &n);
   const slab::ShapeR* r = slab::shapes_r_of(cin, &nr);
@@ -76,10 +82,12 @@ int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const in
   return BEVAMD_OK;
 }
 
-/* Replaces sparse_conv_ext.indice_conv_half (spconv/src/all.cc:30-33 -> spconv_ops.h:260-361, subM = 1) for a 3x3x3
- * submanifold convolution over rows in ascending linear index, cin == cout in {32, 64, 128}, with the same fused epilogue as
- * bevamd_spconv_conv_forward_tiled and the same results (bit-identical for cin <= 64).  hdr / slots: bevamd_spconv_slab_build
- * with block_rows = bevamd_spconv_slab_block_rows(cin, variant). */
+/* Replaces sparse_conv_ext.indice_conv_half (spconv/src/all.cc:30-33 -> spconv_ops.h:260-361) for a 3x3x3 convolution whose
+ * input rows are in ascending linear index: submanifold with cin == cout in {32, 64, 128}, or the narrow layers — cin <= 16
+ * (feature pitch = the padded width 8 | 16), cout in {16, 32}, submanifold or strided (only the metadata differs:
+ * bevamd_spconv_slab_build_from_sorted) — with the same fused epilogue as bevamd_spconv_conv_forward_tiled and the same
+ * results (bit-identical for cin <= 64).  hdr / slots: bevamd_spconv_slab_build* with
+ * block_rows = bevamd_spconv_slab_block_rows(cin, variant). */
 int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_stride, int num_in, const void* image,
                                     const void* hdr, const void* slots, int block_rows, int num_out,
                                     const int* num_out_dev, int cin, int cout, void* out, int out_stride, const void* bias,
@@ -87,15 +95,19 @@ int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_st
                                     int residual_stride, int relu, int variant, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BEVAMD_REQUIRE(dtype == tile::T_F16 || dtype == tile::T_BF16, "spconv_conv_forward_slab: dtype %d is not 16-bit", dtype);
-  BEVAMD_REQUIRE(cin == cout && (cin == 32 || cin == 64 || cin == 128), "spconv_conv_forward_slab: %d -> %d channels", cin, cout);
+  const bool narrow = cin >= 1 && cin <= 16 && (cout == 16 || cout == 32) && (cout == 16 || cin > 8);
+  BEVAMD_REQUIRE(narrow || (cin == cout && (cin == 32 || cin == 64 || cin == 128)), "spconv_conv_forward_slab: %d -> %d channels", cin, cout);
+  const int cinp = narrow ? (cin <= 8 ? 8 : 16) : cin;
   BEVAMD_REQUIRE(num_out >= 0 && num_in >= 0, "spconv_conv_forward_slab: bad sizes");
   if (num_out == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(features && image && hdr && slots && out, "spconv_conv_forward_slab: null buffer");
   BEVAMD_REQUIRE(block_rows == bevamd_spconv_slab_block_rows(cin, variant),
                  "spconv_conv_forward_slab: metadata built for %d-row blocks, variant %d wants %d", block_rows, variant,
                  bevamd_spconv_slab_block_rows(cin, variant));
-  BEVAMD_REQUIRE(feat_stride >= cin && feat_stride % 8 == 0 && ((uintptr_t)features & 15) == 0,
-                 "spconv_conv_forward_slab: feature pitch %d must be a multiple of 8 and >= %d, 16-byte aligned", feat_stride, cin);
+  BEVAMD_REQUIRE(feat_stride >= cinp && feat_stride % 8 == 0 && ((uintptr_t)features & 15) == 0,
+                 "spconv_conv_forward_slab: feature pitch %d must be a multiple of 8 and >= %d, 16-byte aligned", feat_stride, cinp);
+  BEVAMD_REQUIRE((unsigned long long)num_in * (unsigned long long)feat_stride * 2ull < 0x100000000ull,
+                 "spconv_conv_forward_slab: the feature tensor must be smaller than 4 GiB (buffer descriptor)");
   BEVAMD_REQUIRE(((uintptr_t)image & 15) == 0 && ((uintptr_t)slots & 15) == 0, "spconv_conv_forward_slab: image / slots must be 16-byte aligned");
   BEVAMD_REQUIRE(out_stride >= cout && (!residual || residual_stride >= cout), "spconv_conv_forward_slab: bad output pitch");
   BEVAMD_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "spconv_conv_forward_slab: scale and shift go together");
@@ -110,10 +122,15 @@ int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_st
                    (!bias || ((uintptr_t)bias & 15) == 0) && (!bn_scale || (((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0);
   sa.hdr = (const int2*)hdr;
   sa.slots = (const uint16_t*)slots;
-  sa.wimg_bytes = (unsigned)(tile::image_elems(27, cin, cout / 16) * 2);
+  sa.wimg_bytes = (unsigned)(tile::image_elems(27, cinp, cout / 16) * 2);
+  {
+    const size_t sb = bevamd_spconv_slab_slot_bytes(num_out, block_rows);
+    BEVAMD_REQUIRE(sb < 0x100000000ull, "spconv_conv_forward_slab: slot table of 4 GiB or more");
+    sa.slot_bytes = (unsigned)sb;
+  }
   sa.prof = g_slab_prof;
-  return dtype == tile::T_F16 ? slab::launch_f16(sa, cin, cout / 16, variant, stream)
-                              : slab::launch_bf16(sa, cin, cout / 16, variant, stream);
+  return dtype == tile::T_F16 ? slab::launch_f16(sa, cinp, cout / 16, variant, stream)
+                              : slab::launch_bf16(sa, cinp, cout / 16, variant, stream);
 }
 
 }  // extern "C"

@@ -3,6 +3,7 @@
 #include "spconv_slab.h"
 #include "spconv_slab_regw.h"
 #include "spconv_slab_persist.h"
+#include "spconv_slab_small.h"
 
 namespace bevamd {
 namespace slab {
@@ -12,19 +13,60 @@ namespace slab {
 //   SPS: kernel taps per barrier (1 | 3 | 9)   WR: filter ring slots (2 | 3)
 struct Shape { int kc, mt, nw, sps, wr, cap; };
 
+constexpr int MAX_DEVICES = 64;
+// Per kernel instantiation AND per device: the opt-in to > 64 KiB of dynamic LDS is a per-device function attribute, and so is
+// the occupancy a persistent grid is sized by (a process may drive several GPUs).  Plain ints written with the same value by
+// every thread that gets here first: a benign race.
+struct PerDevice {
+  int raised[MAX_DEVICES];
+  int wg_per_xcd[MAX_DEVICES];
+};
+static inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  return dev >= 0 && dev < MAX_DEVICES ? dev : 0;
+}
+template <typename K>
+static inline void raise_lds_limit(PerDevice& pd, K kern, int bytes) {
+  if (bytes <= 65536) return;
+  const int dev = current_device();
+  if (pd.raised[dev]) return;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetLastError();
+  pd.raised[dev] = 1;
+}
+constexpr int SMALL_BASE = 3000000;   // variant codes of the narrow-row kernels: SMALL_BASE + rows per block
+static inline int small_block_rows(int cinp, int variant) {
+  if (cinp != 8 && cinp != 16) return 0;
+  if (variant == 0 || variant == SMALL_BASE + 256) return 256;
+  if (variant == SMALL_BASE + 128) return 128;
+  return 0;
+}
+// resident workgroups per XCD of a persistent kernel on the current device (0 on error)
+template <typename K>
+static inline int resident_per_xcd(PerDevice& pd, K kern, int threads, int bytes) {
+  const int dev = current_device();
+  if (pd.wg_per_xcd[dev] == 0) {
+    raise_lds_limit(pd, kern, bytes);
+    int cus = 0, occ = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, threads, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    if (occ < 1) occ = 1;
+    pd.wg_per_xcd[dev] = (cus + 7) / 8 * occ;
+  }
+  return pd.wg_per_xcd[dev];
+}
+
 template <int DT, int KC, int CIN, int NT, int MT, int NW, int SPS, int WR, int CAP>
 static int run(const SlabArgs& sa, hipStream_t stream) {
   typedef Plan<KC, CIN, NT, MT, NW, SPS, WR, CAP> P;
   static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
   auto kern = &spconv_slab_kernel<DT, KC, CIN, NT, MT, NW, SPS, WR, CAP>;
-  if (P::BYTES > 65536) {
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipGetLastError();
-      raised = true;
-    }
-  }
+  static PerDevice pd = {};
+  raise_lds_limit(pd, kern, P::BYTES);
   const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
   const long long blocks = (nblk + 7) / 8 * 8;
   kern<<<dim3((unsigned)blocks), dim3(NW * 64), P::BYTES, stream>>>(sa);
@@ -74,14 +116,8 @@ static int run_r(const SlabArgs& sa, hipStream_t stream) {
   typedef PlanR<KC, CIN, NT, MT, RW, CW, CAP> P;
   static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
   auto kern = &spconv_slabr_kernel<DT, KC, CIN, NT, MT, RW, CW, CAP>;
-  if (P::BYTES > 65536) {
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipGetLastError();
-      raised = true;
-    }
-  }
+  static PerDevice pd = {};
+  raise_lds_limit(pd, kern, P::BYTES);
   const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
   const long long blocks = (nblk + 7) / 8 * 8;
   kern<<<dim3((unsigned)blocks), dim3(P::NW * 64), P::BYTES, stream>>>(sa);
@@ -95,19 +131,9 @@ static int run_p(const SlabArgs& sa, hipStream_t stream) {
   typedef PlanP<KC, CIN, NT, MT, RW, CW, CAP> P;
   static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
   auto kern = &spconv_slabp_kernel<DT, KC, CIN, NT, MT, RW, CW, CAP>;
-  static int wg_per_xcd = 0;   // resident workgroups per XCD (per kernel instantiation; one device type per process)
-  if (wg_per_xcd == 0) {
-    if (P::BYTES > 65536) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipGetLastError();
-    }
-    int dev = 0, cus = 0, occ = 0;
-    BEVAMD_HIP_CHECK(hipGetDevice(&dev));
-    BEVAMD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    BEVAMD_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, P::NW * 64, P::BYTES));
-    if (occ < 1) occ = 1;
-    wg_per_xcd = (cus + 7) / 8 * occ;
-  }
+  static PerDevice pd = {};
+  const int wg_per_xcd = resident_per_xcd(pd, kern, P::NW * 64, P::BYTES);
+  if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
   const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
   long long gx = (nblk + 7) / 8;
   if (gx > wg_per_xcd) gx = wg_per_xcd;
@@ -145,12 +171,45 @@ static inline const ShapeR* find_shape_r(int cin, int variant) {
 }
 // rows per block of any variant code (0 = none built)
 static inline int block_rows_of(int cin, int variant) {
+  if (cin <= 16) return cin > 0 ? small_block_rows(cin <= 8 ? 8 : 16, variant) : 0;
   if (variant >= REGW_BASE) {
     const ShapeR* r = find_shape_r(cin, variant);
     return r ? r->rw * 16 * r->mt : 0;
   }
   const Shape* s = find_shape(cin, variant);
   return s ? s->nw * 16 * s->mt : 0;
+}
+
+// ---- narrow-row kernels (spconv_slab_small.h): cin padded to 8 | 16, cout 16 | 32; variant = 3000000 + block rows ----------
+template <int DT, int CIN, int NT, int MT, int NW, int CW, int CAP>
+static int run_s(const SlabArgs& sa, hipStream_t stream) {
+  typedef PlanS<CIN, NT, MT, NW, CW, CAP> P;
+  static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
+  auto kern = &spconv_slabs_kernel<DT, CIN, NT, MT, NW, CW, CAP>;
+  static PerDevice pd = {};
+  const int wg_per_xcd = resident_per_xcd(pd, kern, NW * 64, P::BYTES);
+  if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
+  const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
+  long long gx = (nblk + 7) / 8;
+  if (gx > wg_per_xcd) gx = wg_per_xcd;
+  kern<<<dim3((unsigned)(gx * 8)), dim3(NW * 64), P::BYTES, stream>>>(sa);
+  BEVAMD_LAUNCH_CHECK("spconv_slabs");
+  return BEVAMD_OK;
+}
+template <int DT>
+int launch_s_impl(const SlabArgs& sa, int cinp, int nt, int variant, hipStream_t stream) {
+  const int bm = small_block_rows(cinp, variant);
+  if (bm == 256) {
+    if (cinp == 8 && nt == 1) return run_s<DT, 8, 1, 4, 4, 1, 384>(sa, stream);
+    if (cinp == 16 && nt == 1) return run_s<DT, 16, 1, 4, 4, 1, 384>(sa, stream);
+    if (cinp == 16 && nt == 2) return run_s<DT, 16, 2, 4, 8, 2, 384>(sa, stream);
+  } else if (bm == 128) {
+    if (cinp == 8 && nt == 1) return run_s<DT, 8, 1, 2, 4, 1, 256>(sa, stream);
+    if (cinp == 16 && nt == 1) return run_s<DT, 16, 1, 2, 4, 1, 256>(sa, stream);
+    if (cinp == 16 && nt == 2) return run_s<DT, 16, 2, 2, 8, 2, 256>(sa, stream);
+  }
+  set_error("spconv slab: no narrow-row kernel for padded cin=%d, cout tiles=%d, variant=%d", cinp, nt, variant);
+  return BEVAMD_ERR_UNSUPPORTED;
 }
 
 template <int DT>
@@ -183,6 +242,7 @@ int launch_r_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t 
 
 template <int DT>
 int launch_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t stream) {
+  if (cin <= 16) return launch_s_impl<DT>(sa, cin, nt, variant, stream);
   if (variant >= REGW_BASE) return launch_r_impl<DT>(sa, cin, nt, variant, stream);
   const Shape* s = find_shape(cin, variant);
   if (!s || nt != cin / 16) {

@@ -369,13 +369,35 @@ __global__ void vox_counts_batch_kernel(VoxBatch vb, const uint32_t* __restrict_
   if (total) *total = (int)run;
 }
 
+// Key-order output (order = 1): the surviving voxels of a sweep — still the first max_voxels by first appearance, the
+// reference's cap rule — are written in ascending linear cell index, i.e. in the order the sort already produced, instead of
+// first-appearance order.  surv[J] = 1 on the run head of every surviving voxel (sorted order); its exclusive scan minus the
+// scan value at the sweep's start is the row.  The encoder's dense BEV output does not depend on the row order of the level-1
+// set; rows in linear order are what the staged-rows convolutions and the sorted-key neighbour search need
+// (spconv_indice.hip: sp_slab_from_sorted_kernel).
+__global__ __launch_bounds__(256) void vox_survivors_batch_kernel(VoxBatch vb, const uint32_t* __restrict__ keys,
+                                                                  const uint32_t* __restrict__ idx,
+                                                                  const uint32_t* __restrict__ first_scan, uint32_t ncells,
+                                                                  int max_voxels, uint32_t* __restrict__ surv) {
+  const VoxRow r = vox_locate(vb);
+  if (!r.in) return;
+  const uint32_t k = keys[r.J];
+  uint32_t s = 0u;
+  if (k < ncells && (r.j == 0 || keys[r.J - 1] != k)) {
+    const uint32_t vid = first_scan[r.lo + idx[r.J]] - first_scan[r.lo];
+    s = vid < (uint32_t)max_voxels ? 1u : 0u;
+  }
+  surv[r.J] = s;
+}
+
 // One thread per sorted row; the first row of every run of equal keys (the voxel's earliest point: the sort is stable) sums
 // the run.  The run length comes from the wave's ballot of run boundaries (no dependent walk over the keys), the point indices
 // of the run and then the points themselves are fetched as batches of independent, PREDICATED loads (a lane only requests the
 // rows it owns) before they are added in input order: two memory round trips per voxel instead of two per point.
 __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
     VoxBatch vb, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
-    const uint32_t* __restrict__ first_scan, const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
+    const uint32_t* __restrict__ first_scan, const uint32_t* __restrict__ surv_scan /*null: first-appearance rows*/,
+    const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
     int max_points, int max_voxels, float* __restrict__ feats, int* __restrict__ coords4,
     int* __restrict__ num_points_per_voxel) {
   const VoxRow vr = vox_locate(vb);
@@ -403,7 +425,7 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
   const uint32_t i0 = idx[J];
   const uint32_t vid = first_scan[vr.lo + i0] - first_scan[vr.lo];
   if (vid >= (uint32_t)max_voxels) return;
-  const size_t row = (size_t)rowbase[b] + vid;
+  const size_t row = (size_t)rowbase[b] + (surv_scan ? surv_scan[J] - surv_scan[vr.lo] : vid);
   const float* __restrict__ points = vr.pts;
   const int cnt = (int)(len < (uint32_t)max_points ? len : (uint32_t)max_points);
   const float fc = (float)cnt;
@@ -567,11 +589,26 @@ size_t bevamd_voxelize_mean_batch_workspace_bytes(const int* num_points, int bat
   return voxelize_batch_ws_bytes(sg);
 }
 
+int bevamd_voxelize_mean_batch_ex(const float* const* points, const int* num_points, int batch_size, int num_features,
+                                  const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                                  int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
+                                  int* counts_dev, int* total_dev, void* ws, size_t ws_bytes, void* stream_);
+
 int bevamd_voxelize_mean_batch(const float* const* points, const int* num_points, int batch_size, int num_features,
                                const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
                                int packed, float* feats, int* coords4, int* num_points_per_voxel, int* counts_dev,
                                int* total_dev, void* ws, size_t ws_bytes, void* stream_) {
+  return bevamd_voxelize_mean_batch_ex(points, num_points, batch_size, num_features, voxel_size, coors_range, max_points,
+                                       max_voxels, packed, 0, feats, coords4, num_points_per_voxel, counts_dev, total_dev, ws,
+                                       ws_bytes, stream_);
+}
+
+int bevamd_voxelize_mean_batch_ex(const float* const* points, const int* num_points, int batch_size, int num_features,
+                                  const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                                  int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
+                                  int* counts_dev, int* total_dev, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(order == 0 || order == 1, "voxelize_mean_batch: order %d (0 = first appearance, 1 = linear cell index)", order);
   BEVAMD_REQUIRE(points && num_points, "voxelize_mean_batch: points / num_points are null (host arrays)");
   BEVAMD_REQUIRE(batch_size >= 1 && batch_size <= VOX_MAX_BATCH, "voxelize_mean_batch: batch_size %d (1..%d supported)",
                  batch_size, VOX_MAX_BATCH);
@@ -630,8 +667,16 @@ int bevamd_voxelize_mean_batch(const float* const* points, const int* num_points
   if (rc) return rc;
   vox_counts_batch_kernel<<<1, 64, 0, stream>>>(vbt, first, first_total, max_voxels, packed, counts_dev, rowbase, total_dev);
   BEVAMD_LAUNCH_CHECK("vox_counts_batch");
-  vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, rowbase, num_features, g, ncells, max_points,
-                                                    max_voxels, feats, coords4, num_points_per_voxel);
+  uint32_t* surv = nullptr;
+  if (order == 1) {
+    surv = keys_s == keys_a ? keys_b : keys_a;   // the sort's other key buffer is free from here on
+    vox_survivors_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, ncells, max_voxels, surv);
+    BEVAMD_LAUNCH_CHECK("vox_survivors_batch");
+    rc = exclusive_scan_u32(surv, surv, n, nullptr, sws, sws_bytes, stream);
+    if (rc) return rc;
+  }
+  vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, surv, rowbase, num_features, g, ncells,
+                                                    max_points, max_voxels, feats, coords4, num_points_per_voxel);
   BEVAMD_LAUNCH_CHECK("vox_mean_batch");
   return BEVAMD_OK;
 }

@@ -64,15 +64,20 @@ class SparseEncoder(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     def forward(self, voxel_features, coors, batch_size, **kwargs):
         """voxel_features [N, C_in]; coors [N, 4] int32 (batch, x, y, z) -> dense BEV features [B, C*D, H, W]
-        (sparse_encoder.py:100-132).  `num_voxels=` (int32 device tensor) marks capacity-padded inputs."""
+        (sparse_encoder.py:100-132).  `num_voxels=` (int32 device tensor) marks capacity-padded inputs;
+        `coors_order="linear"`: the caller vouches that the rows are in ascending linear index (b, x, y, z) — what
+        `voxelize_batch_device(..., order="key")` writes — so level 1 takes the staged-rows kernels and the sorted-key
+        neighbour search (the dense output does not depend on the row order)."""
         num_voxels = kwargs.get("num_voxels")
+        coors_order = kwargs.get("coors_order")
         geometry = kwargs.get("geometry")      # fused.prepare_geometry(...) of these coordinates, built ahead of time
         reason = "fused_inference is off"
         if self.fused_inference:
             reason = _fused.unsupported_reason(self, voxel_features)
             if reason is None:
                 try:
-                    out = _fused.run_encoder(self, voxel_features, coors, int(batch_size), num_voxels, geometry=geometry)
+                    out = _fused.run_encoder(self, voxel_features, coors, int(batch_size), num_voxels, geometry=geometry,
+                                             coors_order=coors_order)
                     self.last_path, self.last_path_reason = "fused", None
                     return out
                 except _fused.NotThisCall as e:
@@ -97,10 +102,10 @@ class SparseEncoder(nn.Module):
         b, c, h, w, d = dense.shape
         return dense.permute(0, 1, 4, 2, 3).contiguous().view(b, c * d, h, w)
 
-    def prepare_geometry(self, coors, batch_size, num_voxels=None):
+    def prepare_geometry(self, coors, batch_size, num_voxels=None, coors_order=None):
         """The coordinate-only part of the fused forward (rulebook chain of every level), to be run ahead of / beside other work:
         `lvl = enc.prepare_geometry(coors, B, num_voxels=cnt); ...; enc(feats, coors, B, num_voxels=cnt, geometry=lvl)`."""
-        return _fused.prepare_geometry(self, coors, int(batch_size), num_voxels)
+        return _fused.prepare_geometry(self, coors, int(batch_size), num_voxels, coors_order=coors_order)
 
     def _warn_once(self, reason):
         if reason not in self._warned:

@@ -65,7 +65,7 @@ class Level:
     Buffers are allocated by the caller's (current-stream) allocator; `run_encoder` joins the two streams before it
     returns, so their reuse stays ordered."""
 
-    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None):
+    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False):
         self.indices = indices
         self.n_cap = int(n_cap)
         self.n_dev = n_dev          # int32 device tensor [1] or None (= n_cap rows are all live)
@@ -79,7 +79,12 @@ class Level:
         self._subm = {}
         self._down = {}
         self._slab = {}
-        self.linear_order = False   # rows in ascending linear index (every set a strided convolution produced)
+        self._down_slab = {}
+        self.linear_order = bool(linear_order)   # rows in ascending linear index (every set a strided convolution produced;
+        #                                          level 1 when the caller vouches for it: voxelize(..., order="key"))
+        self.sorted_index = None    # (keys, x-plane directory): the set's own sorted-key index (ops.sorted_index_build)
+        self.sorted_status = None
+        self._sorted_ev = None
 
     @property
     def device(self):
@@ -118,6 +123,25 @@ class Level:
         self.index_kind, self.index_n_cap = INDEX_HASH, self.n_cap
         self.ready = self._mark()
 
+    def ensure_sorted(self, wait=True):
+        """Sorted-key index of a set in linear order (no hash insert, nothing to clear): built once, on the geometry stream."""
+        if not self.linear_order:
+            raise RuntimeError("sorted-key index of a voxel set that is not in linear order")
+        if self.sorted_index is None:
+            self.sorted_index, self.sorted_status = ops.sorted_index_build(self.indices, self.n_cap, self.n_dev, self.batch,
+                                                                           self.shape, stream_ptr=self._stream_ptr())
+            self._sorted_ev = self._mark()
+        if wait:
+            self._await(self._sorted_ev)
+        return self.sorted_index
+
+    def use_sorted(self):
+        """Neighbour search of this set goes through its sorted-key index (level 1 in key order: it has no rank index);
+        BEVAMD_SPCONV_SORTED_ALL=1 extends that to the levels that do have one (tuning)."""
+        if not self.linear_order or not _SORTED:
+            return False
+        return self.index_kind != INDEX_RANK or _SORTED_ALL
+
     def _neighbors(self, out_indices, m_cap, m_dev, out_shape, ksize, stride, padding, subm):
         lib = _capi.load()
         self.ensure_index()
@@ -148,7 +172,12 @@ class Level:
         """Slab metadata (ops.SlabMeta) of the 3x3x3 SubM neighbour table, for `block_rows`-row blocks: built once, on the
         geometry stream, behind the table it rewrites."""
         if block_rows not in self._slab:
-            if (3, 3, 3) in self._subm or not _SLAB_DIRECT:
+            if self.use_sorted():
+                self.ensure_sorted(wait=False)
+                meta = ops.slab_build_from_sorted(self.indices, self.n_cap, self.n_dev, self.batch, self.shape, self.shape,
+                                                  [1, 1, 1], [1, 1, 1], True, self.sorted_index, self.n_cap, block_rows,
+                                                  stream_ptr=self._stream_ptr())
+            elif (3, 3, 3) in self._subm or not _SLAB_DIRECT:
                 nbr = self.subm_neighbors((3, 3, 3), wait=False)
                 meta = ops.slab_build(nbr, self.n_cap, self.n_dev, block_rows, stream_ptr=self._stream_ptr())
             else:   # nobody asked for the int32 table: every row looks its neighbours up itself, 54 B per row written in all
@@ -161,13 +190,37 @@ class Level:
             self._await(ev)
         return meta
 
-    def downsample(self, ksize, stride, padding, wait=True):
-        """(output Level with its rank index, nbr [K, cap_out]) of a strided convolution over this set."""
+    def down_slab(self, ksize, stride, padding, block_rows, wait=True):
+        """Slab metadata of the strided 3x3x3 convolution (ksize, stride, padding) over this set, for `block_rows`-row blocks
+        of OUTPUT rows: from the sorted-key index of this (input) set, behind the downsample that numbered the outputs."""
+        key = (tuple(ksize), tuple(stride), tuple(padding), block_rows)
+        if key not in self._down_slab:
+            out, _ = self.downsample(ksize, stride, padding, wait=False, want_nbr=False)
+            self.ensure_sorted(wait=False)
+            meta = ops.slab_build_from_sorted(out.indices, out.n_cap, out.n_dev, self.batch, self.shape, out.shape, list(stride),
+                                              list(padding), False, self.sorted_index, self.n_cap, block_rows,
+                                              stream_ptr=self._stream_ptr())
+            self._down_slab[key] = (meta, self._mark())
+        meta, ev = self._down_slab[key]
+        if wait:
+            self._await(ev)
+        return meta
+
+    def downsample(self, ksize, stride, padding, wait=True, want_nbr=True):
+        """(output Level with its rank index, nbr [K, cap_out]) of a strided convolution over this set.  want_nbr=False (the
+        convolution reads slab metadata instead): the int32 neighbour table is not built, nbr is None — a later call that
+        does want it (profiling a slab layer) builds it from the output side."""
         key = (tuple(ksize), tuple(stride), tuple(padding))
         if key in self._down:
             out, nbr = self._down[key]
+            ev = None
+            if nbr is None and want_nbr:
+                nbr = self._neighbors(out.indices, out.n_cap, out.n_dev, out.shape, list(ksize), list(stride), list(padding), False)
+                self._down[key] = (out, nbr)
+                ev = self._mark()
             if wait:
                 self._await(out.ready)
+                self._await(ev)
             return out, nbr
         lib = _capi.load()
         dev = self.device
@@ -182,7 +235,7 @@ class Level:
         out_indices = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         num_out = torch.empty(1, dtype=torch.int32, device=dev)
         K = ksize[0] * ksize[1] * ksize[2]
-        nbr = torch.empty((K, cap), dtype=torch.int32, device=dev)
+        nbr = torch.empty((K, cap), dtype=torch.int32, device=dev) if want_nbr else None
         with torch.cuda.device(dev):
             nbytes = lib.bevamd_spconv_rank_index_bytes(self.batch, _capi.ints(out_shape))
             index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -257,12 +310,13 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
     image, bias, scale, shift = folded(conv, bn, dtype)
     lvl = x.level
     slab_variant = _slab_variant_for(conv, lvl, cin, cout)
+    want_nbr = slab_variant is None or LAYER_PROFILE is not None
     if conv.subm:
         # the slab kernels read their own metadata: the int32 neighbour table is only built for them when profiling (pair counts)
-        nbr = lvl.subm_neighbors(conv.kernel_size) if slab_variant is None or LAYER_PROFILE is not None else None
+        nbr = lvl.subm_neighbors(conv.kernel_size) if want_nbr else None
         out_lvl = lvl
     else:
-        out_lvl, nbr = lvl.downsample(conv.kernel_size, conv.stride, conv.padding)
+        out_lvl, nbr = lvl.downsample(conv.kernel_size, conv.stride, conv.padding, want_nbr=want_nbr)
     K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
     out = torch.empty((out_lvl.n_cap, cout), dtype=dtype, device=x.features.device)
     rec = None
@@ -274,7 +328,8 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
                    n_in=lvl.n_dev, n_out=out_lvl.n_dev, n_in_cap=lvl.n_cap, n_out_cap=out_lvl.n_cap, nbr=nbr)
         rec["start"].record()
     if slab_variant is not None:
-        meta = lvl.subm_slab(ops.slab_block_rows(cin, slab_variant))
+        rows = ops.slab_block_rows(cin, slab_variant)
+        meta = lvl.subm_slab(rows) if conv.subm else lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, rows)
         ops.sparse_conv_slab(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                              residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out, variant=slab_variant)
     else:
@@ -323,6 +378,14 @@ _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 
 # 32 / 64 / 128 channels: 186 / 183 / 151 us against 290 / 242 / 193 us of the gather kernels (first cut: 211 / 198 / 164); one
 # frame: 26.7 / 30.8 us against 41 / 35.8 us, 128 channels 38.5-40 against 38.8 us (188 blocks on 256 CUs) -> those layers switch
 # over from 4 frames per step.  The persistent 32-channel kernel was only measured at 8 frames: smaller batches keep its one-block twin.
+# Narrow layers (cin padded to 8 | 16: csrc/spconv_slab_small.h) on a level in linear order — level 1 when the voxelizer wrote
+# its rows in key order: 3000256 = 256-row blocks (the SubM layers share one metadata set), 3000128 = 128-row blocks (the strided
+# 16 -> 32 convolution: its two output tiles go to two waves, 8-wave workgroups, so smaller blocks keep two of them per CU).
+_CHECK = os.environ.get("BEVAMD_SPCONV_CHECK", "0") == "1"   # read the geometry status words back after every fused forward (one sync)
+_SLAB_NARROW_SUBM = 3000256
+_SLAB_NARROW_STRIDED = 3000128
+_SORTED = os.environ.get("BEVAMD_SPCONV_SORTED", "1") != "0"          # sorted-key neighbour search on levels without a rank index
+_SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and on those that have one (tuning)
 _SLAB_DEFAULT = {32: 2324410, 64: 1644222, 128: 1644220}
 _SLAB_DEFAULT_SMALL_BATCH = {32: 1322410}   # below 4 frames per step
 _SLAB_MIN_BATCH = {128: 4}
@@ -339,10 +402,30 @@ def _slab_overrides():
     return out
 
 
+def _narrow_variant_for(conv, lvl, cin, cout):
+    """Variant of the narrow-row slab kernels for this layer, None if it does not apply (3x3x3, cin <= 16, cout 16 | 32, input
+    level in linear order with a sorted-key index)."""
+    if os.environ.get("BEVAMD_SPCONV_SLAB_NARROW", "1") == "0" or not lvl.use_sorted():
+        return None
+    if not (cout in (16, 32) and (cout == 16 or cin > 8)):
+        return None
+    overrides = _slab_overrides()
+    if conv.subm:
+        variant = overrides.get(16, _SLAB_NARROW_SUBM)
+        rows = ops.slab_block_rows(cin, variant)
+        return variant if rows and ops.slab_grid_ok(lvl.shape, rows) else None
+    variant = overrides.get(-16, _SLAB_NARROW_STRIDED)
+    return variant if ops.slab_block_rows(cin, variant) else None
+
+
 def _slab_variant_for(conv, lvl, cin, cout):
     if os.environ.get("BEVAMD_SPCONV_SLAB", "1") == "0":
         return None
-    if not (conv.subm and tuple(conv.kernel_size) == (3, 3, 3) and lvl.linear_order and cin == cout):
+    if tuple(conv.kernel_size) != (3, 3, 3) or not lvl.linear_order:
+        return None
+    if ops.padded_channels(cin) <= 16:
+        return _narrow_variant_for(conv, lvl, cin, cout)
+    if not (conv.subm and cin == cout):
         return None
     if cin not in _SLAB_DEFAULT or lvl.batch < _SLAB_MIN_BATCH.get(cin, 1):
         return None
@@ -436,7 +519,7 @@ def encoder_supported(enc, voxel_features):
 
 
 @torch.no_grad()
-def prepare_geometry(enc, coors, batch_size, num_voxels=None):
+def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None):
     """Everything of `run_encoder` that depends on voxel COORDINATES only — hash index, every level's active set, neighbour
     tables, slab metadata — issued on the current stream (and finished there: the geometry stream, if any, is joined back).
     Returns the level-1 `Level` holding the products; pass it to `SparseEncoder.forward(..., geometry=level)` /
@@ -454,7 +537,7 @@ def prepare_geometry(enc, coors, batch_size, num_voxels=None):
     main = torch.cuda.current_stream(dev)
     if g is not None:
         g.wait_stream(main)
-    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g)
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order))
     try:
         prefetch_geometry(enc, lvl)
     finally:
@@ -473,13 +556,43 @@ def _drop_events(lvl):
         lvl.gstream = None
         lvl._subm = {k: (v[0], None) for k, v in lvl._subm.items()}
         lvl._slab = {k: (v[0], None) for k, v in lvl._slab.items()}
+        lvl._down_slab = {k: (v[0], None) for k, v in lvl._down_slab.items()}
+        lvl._sorted_ev = None
         nxt = None
         for out, _ in lvl._down.values():
             nxt = out
         lvl = nxt
 
 
-def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometry=None):
+def _is_linear(coors_order):
+    if coors_order in (None, "first", "any"):
+        return False
+    if coors_order in ("linear", "key"):
+        return True
+    raise ValueError(f"coors_order must be None or 'linear', got {coors_order!r}")
+
+
+def geometry_status(lvl):
+    """OR of the device status words of every structure built for `lvl` and the levels below it (one host sync; tests and
+    BEVAMD_SPCONV_CHECK=1): bit 0 = a slab range overflowed its 16-bit slots, bit 1 = rows promised to be in linear order
+    were not."""
+    bits, seen = 0, set()
+    while lvl is not None and id(lvl) not in seen:
+        seen.add(id(lvl))
+        words = [m.status for m, _ in list(lvl._slab.values()) + list(lvl._down_slab.values())]
+        if lvl.sorted_status is not None:
+            words.append(lvl.sorted_status)
+        for wd in words:
+            if wd is not None:
+                bits |= int(wd.item())
+        nxt = None
+        for out, _ in lvl._down.values():
+            nxt = out
+        lvl = nxt
+    return bits
+
+
+def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometry=None, coors_order=None):
     """SparseEncoder.forward on the fused path.  voxel_features [N, C_in] (any float dtype), coors [N, 4] int32
     (batch, x, y, z); `num_voxels` (optional int32 device tensor [1]): live row count when the inputs are
     capacity-padded buffers straight from the voxelizer (`voxelize_batch(..., sync=False)`); `geometry`: the Level returned
@@ -508,7 +621,7 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
     main = torch.cuda.current_stream(dev)
     if g is not None:
         g.wait_stream(main)       # fork: coordinates / count are final, recycled buffers are quiescent
-    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g)
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order))
     try:
         if g is not None:
             prefetch_geometry(enc, lvl)
@@ -516,7 +629,13 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
         x = _sequential(enc.conv_input, x)
         x = _sequential(enc.encoder_layers, x)
         x = _sequential(enc.conv_out, x)
-        return dense_bev(x)
+        out = dense_bev(x)
+        if _CHECK:
+            bits = geometry_status(lvl)
+            if bits:
+                raise RuntimeError(f"SparseEncoder fused path: geometry status {bits:#x} (1: slab range overflow, 2: coordinates "
+                                   "passed with coors_order='linear' are not in ascending linear index)")
+        return out
     finally:
         if g is not None:
             main.wait_stream(g)   # join: whatever follows on this stream is ordered behind the geometry kernels
@@ -535,11 +654,14 @@ def prefetch_geometry(enc, lvl):
             continue
         if any(d != 1 for d in m.dilation):
             continue
+        v = _slab_variant_for(m, cur, m.in_channels, m.out_channels)
         if m.subm:
-            v = _slab_variant_for(m, cur, m.in_channels, m.out_channels)
             if v is not None:
                 cur.subm_slab(ops.slab_block_rows(m.in_channels, v), wait=False)
             else:
                 cur.subm_neighbors(m.kernel_size, wait=False)
         else:
-            cur, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False)
+            nxt, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False, want_nbr=v is None or LAYER_PROFILE is not None)
+            if v is not None:
+                cur.down_slab(m.kernel_size, m.stride, m.padding, ops.slab_block_rows(m.in_channels, v), wait=False)
+            cur = nxt

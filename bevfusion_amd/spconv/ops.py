@@ -357,9 +357,45 @@ def slab_build_from_index(indices, m_cap, m_dev, batch, shape, index_kind, index
     return SlabMeta(hdr, slots, int(block_rows), status)
 
 
+def sorted_index_build(indices, n_cap, n_dev, batch, shape, stream_ptr=None):
+    """Sorted-key index (keys + x-plane directory, one uint8 buffer) of a voxel set whose rows are in ascending linear index;
+    returns (index, status) — status bit 1 (value 2) is set on the device if the rows are not strictly ascending."""
+    lib = _capi.load()
+    dev = indices.device
+    with torch.cuda.device(dev):
+        nbytes = int(lib.bevamd_spconv_sorted_index_bytes(int(n_cap), int(batch), _capi.ints(shape)))
+        index = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.bevamd_spconv_sorted_index_build(_capi.ptr(indices), int(n_cap), _capi.ptr(n_dev), int(batch), _capi.ints(shape),
+                                                  _capi.ptr(index), nbytes, _capi.ptr(status),
+                                                  stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
+    _capi.check(rc, "spconv_sorted_index_build")
+    return index, status
+
+
+def slab_build_from_sorted(out_indices, m_cap, m_dev, batch, in_shape, out_shape, stride, padding, subm, in_index, in_n_cap,
+                           block_rows, stream_ptr=None):
+    """Slab metadata of a 3x3x3 convolution (submanifold, or strided with active outputs `out_indices`) from the sorted-key
+    index of its input set (bevamd_spconv_slab_build_from_sorted): no neighbour table."""
+    lib = _capi.load()
+    dev = out_indices.device
+    with torch.cuda.device(dev):
+        hdr = torch.empty(max(lib.bevamd_spconv_slab_hdr_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
+        slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.bevamd_spconv_slab_build_from_sorted(_capi.ptr(out_indices), int(m_cap), _capi.ptr(m_dev), int(batch),
+                                                      _capi.ints(in_shape), _capi.ints(out_shape), _capi.ints(stride),
+                                                      _capi.ints(padding), int(bool(subm)), _capi.ptr(in_index), int(in_n_cap),
+                                                      int(block_rows), _capi.ptr(hdr), _capi.ptr(slots), _capi.ptr(status),
+                                                      stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
+    _capi.check(rc, "spconv_slab_build_from_sorted")
+    return SlabMeta(hdr, slots, int(block_rows), status)
+
+
 def sparse_conv_slab(features, image, meta, num_out, cin, cout, bias=None, bn_scale=None, bn_shift=None, residual=None,
                      relu=False, num_out_dev=None, out=None, variant=0):
-    """`sparse_conv_tiled` for a 3x3x3 SubM convolution over linear-index-ordered rows, through the slab kernels."""
+    """`sparse_conv_tiled` for a 3x3x3 convolution over linear-index-ordered rows, through the slab kernels (SubM with
+    cin == cout in {32, 64, 128}; cin <= 16 with cout in {16, 32}: SubM or strided, depending on what `meta` describes)."""
     lib = _capi.load()
     _require_cuda(features, "features")
     if features.stride(1) != 1:

@@ -290,9 +290,15 @@ _VOXEL_BATCHED = os.environ.get("BEVAMD_VOXEL_BATCHED", "1") != "0"   # one segm
 _VOXEL_MAX_BATCH = 64
 
 
-def _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, packed):
-    """All samples in the launches of one (`bevamd_voxelize_mean_batch`): returns (feats [B*cap, F], coords [B*cap, 4],
-    sizes [B*cap], counts [B], total [1]); rows packed sample after sample when `packed`, else sample b at row b*cap."""
+_ORDERS = {"first": 0, "appearance": 0, None: 0, "key": 1, "linear": 1}
+
+
+def _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, packed, order="first"):
+    """All samples in the launches of one (`bevamd_voxelize_mean_batch_ex`): returns (feats [B*cap, F], coords [B*cap, 4],
+    sizes [B*cap], counts [B], total [1]); rows packed sample after sample when `packed`, else sample b at row b*cap.
+    order: "first" = first-appearance rows (the reference's numbering), "key" = the same rows in ascending linear cell index."""
+    if order not in _ORDERS:
+        raise ValueError(f"voxelize: order must be 'first' or 'key', got {order!r}")
     lib = _capi.load()
     B = len(points_list)
     dev = points_list[0].device
@@ -311,31 +317,34 @@ def _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_poi
     with torch.cuda.device(dev):
         wsb = lib.bevamd_voxelize_mean_batch_workspace_bytes(nums, B)
         ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
-        rc = lib.bevamd_voxelize_mean_batch(ptrs, nums, B, F, _capi.floats(voxel_size), _capi.floats(point_cloud_range),
-                                            int(max_num_points), int(max_voxels), 1 if packed else 0, _capi.ptr(feats),
-                                            _capi.ptr(coords), _capi.ptr(sizes), _capi.ptr(counts), _capi.ptr(total),
-                                            _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+        rc = lib.bevamd_voxelize_mean_batch_ex(ptrs, nums, B, F, _capi.floats(voxel_size), _capi.floats(point_cloud_range),
+                                               int(max_num_points), int(max_voxels), 1 if packed else 0, _ORDERS[order],
+                                               _capi.ptr(feats), _capi.ptr(coords), _capi.ptr(sizes), _capi.ptr(counts),
+                                               _capi.ptr(total), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
     _capi.check(rc, "voxelize_mean_batch")
     return feats, coords, sizes, counts, total
 
 
 @torch.no_grad()
-def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, sync=True):
+def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, sync=True, order="first"):
     """`BEVFusion.voxelize` (bevfusion.py:169-197, hard voxelization + voxelize_reduce) for a batch.
 
     points_list: list of [N_k, F] fp32 GPU tensors.  Returns (feats [M, F] = per-voxel mean,
     coords [M, 4] int32 = (batch_idx, x, y, z), sizes [M] int32).
     With sync=True the outputs are exactly sized (one D2H copy of all counts for the whole batch);
-    with sync=False they are (padded buffers, counts_dev) for callers that stay on the device."""
+    with sync=False they are (padded buffers, counts_dev) for callers that stay on the device.
+    order="key": each sample's rows in ascending linear cell index instead of first appearance (same set, same values)."""
     lib = _capi.load()
     B = len(points_list)
     dev = points_list[0].device
     F = points_list[0].shape[1]
     if _VOXEL_BATCHED and B <= _VOXEL_MAX_BATCH:
         feats, coords, sizes, counts, _ = _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points,
-                                                               max_voxels, packed=False)
+                                                               max_voxels, packed=False, order=order)
         feats, coords, sizes = feats.view(B, max_voxels, F), coords.view(B, max_voxels, 4), sizes.view(B, max_voxels)
     else:
+        if _ORDERS.get(order, -1) != 0:
+            raise ValueError("voxelize_batch: order='key' needs the batched entry (<= 64 samples, BEVAMD_VOXEL_BATCHED=1)")
         feats, coords, sizes, counts = _voxelize_mean_lanes(points_list, voxel_size, point_cloud_range, max_num_points,
                                                             max_voxels)
     if not sync:
@@ -391,15 +400,19 @@ def _voxelize_mean_lanes(points_list, voxel_size, point_cloud_range, max_num_poi
 
 
 @torch.no_grad()
-def voxelize_batch_device(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels):
+def voxelize_batch_device(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, order="first"):
     """`voxelize_batch` that never touches the host: returns (feats [B*max_voxels, F], coords [B*max_voxels, 4],
     sizes [B*max_voxels], total [1] int32 on the device) with the batch packed sample after sample in the first `total`
-    rows — what `SparseEncoder(..., num_voxels=total)` consumes on its sync-free path."""
+    rows — what `SparseEncoder(..., num_voxels=total)` consumes on its sync-free path.  order="key": rows in ascending
+    linear index over the whole packed batch (pass `coors_order="linear"` to the encoder: level 1 then runs on the
+    staged-rows kernels with sorted-key neighbour search)."""
     lib = _capi.load()
     if _VOXEL_BATCHED and len(points_list) <= _VOXEL_MAX_BATCH:
         of, oc, osz, _, total = _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
-                                                     packed=True)
+                                                     packed=True, order=order)
         return of, oc, osz, total
+    if _ORDERS.get(order, -1) != 0:
+        raise ValueError("voxelize_batch_device: order='key' needs the batched entry (<= 64 samples, BEVAMD_VOXEL_BATCHED=1)")
     feats, coords, sizes, counts = voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
                                                   sync=False)
     B, cap, F = feats.shape

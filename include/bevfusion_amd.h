@@ -261,6 +261,16 @@ int bevamd_voxelize_mean_batch(const float* const* points, const int* num_points
                                int packed, float* feats, int* coords4, int* num_points_per_voxel, int* counts_dev,
                                int* total_dev, void* ws, size_t ws_bytes, void* stream);
 
+/* The same with a choice of row order.  order = 0: first appearance (the reference's voxel numbering, bevfusion.py:176-191 /
+ * voxelization_cuda.cu:231-373; what bevamd_voxelize_mean_batch does).  order = 1: the SAME surviving set per sample (the first
+ * max_voxels voxels by first appearance — the reference's cap rule) and the same per-voxel results, written in ascending linear
+ * cell index (x, y, z; z fastest) inside each sample.  The SparseEncoder's dense BEV output does not depend on the row order of
+ * its input set; rows in linear order let level 1 use the staged-rows convolutions and sorted-key neighbour search. */
+int bevamd_voxelize_mean_batch_ex(const float* const* points, const int* num_points, int batch_size, int num_features,
+                                  const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                                  int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
+                                  int* counts_dev, int* total_dev, void* ws, size_t ws_bytes, void* stream);
+
 /* Dynamic scatter.  Replace voxel_layer.dynamic_point_to_voxel_forward / _backward
  *   (voxel/src/voxelization.cpp:6-11 -> voxelization.h:108-140 -> scatter_points_cuda.cu:197-330).
  * bevamd_dynamic_scatter_index: coors [num_points, ndim] int32 (ndim 1..4); rows with a negative entry are dropped.
@@ -466,6 +476,23 @@ int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const in
 int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int* m_dev, int batch_size, const int* shape,
                                         int index_kind, const void* index, int index_n_cap, int block_rows, void* hdr,
                                         void* slots, int* status, void* stream);
+
+/* Sorted-key index: a voxel set whose rows are in ascending linear index (b, x, y, z) is its own lookup structure.
+ * bevamd_spconv_sorted_index_build writes keys [n_cap] uint32 and the x-plane directory [batch * shape[0] + 1] int32 into
+ * `index` (bevamd_spconv_sorted_index_bytes); a lookup is a binary search inside one x-plane's segment.  Replaces the dense
+ * int32 grid of getIndicePair (spconv_ops.h:27-141, indice.cu.h:147-203) and the hash index for such sets.
+ * status (optional int32, device): bit 1 (value 2) is set when the rows are NOT strictly ascending. */
+size_t bevamd_spconv_sorted_index_bytes(int n_cap, int batch_size, const int* shape);
+int bevamd_spconv_sorted_index_build(const int* indices, int n_cap, const int* n_dev, int batch_size, const int* shape,
+                                     void* index, size_t index_bytes, int* status, void* stream);
+/* Slab metadata (hdr / slots as bevamd_spconv_slab_build) of a 3x3x3 convolution from the sorted-key index of its INPUT set:
+ * subm != 0: the submanifold convolution over the set itself (out_indices = the set; stride / padding / out_shape ignored);
+ * subm == 0: the strided convolution with active outputs out_indices [m_cap, 4] on out_shape, rows in ascending linear index
+ * (as bevamd_spconv_downsample emits them).  No neighbour table is built (spconv_ops.h:27-141 writes 2 x 27 x N int32). */
+int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
+                                         const int* in_shape, const int* out_shape, const int* stride, const int* padding,
+                                         int subm, const void* in_index, int in_n_cap, int block_rows, void* hdr, void* slots,
+                                         int* status, void* stream);
 int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_stride, int num_in, const void* image,
                                     const void* hdr, const void* slots, int block_rows, int num_out,
                                     const int* num_out_dev, int cin, int cout, void* out, int out_stride,
