@@ -790,10 +790,12 @@ __device__ __forceinline__ int sorted_lower_bound(const uint32_t* __restrict__ k
 }
 
 // Slab metadata (slab_emit: per block of BM output rows and kernel plane kx the input range, + 16-bit slots) of a 3x3x3
-// convolution — submanifold OR strided — whose INPUT set is in ascending linear index, found by sorted-key search: thread t
-// looks at the <= 9 (kx, ky) lines of its output row; the three kz taps of a line are consecutive keys, so one lower_bound
-// (inside the x-plane's segment, continued from the previous line's position) + three compares serve them.  Output rows
-// must be in ascending linear index too (what makes a plane's inputs a contiguous range).  SUBM: the centre tap is the row.
+// convolution — submanifold OR strided — whose INPUT set is in ascending linear index, found by sorted-key search.  The nine
+// (ky, kz) taps of a kernel plane kx read a window of 3 y-columns x 3 z-cells of ONE input x-plane: in linear order that is a
+// key interval of 2*Z + 3 cells holding a handful of rows.  Thread t therefore does ONE lower_bound per plane (inside the
+// x-plane's segment of the directory) and then walks the rows up to the window's last key, four keys per round trip, turning
+// each into its (ky, kz) tap — 3 searches per row instead of one lookup per tap.  Output rows must be in ascending linear
+// index too (what makes a plane's inputs a contiguous range).  SUBM: the centre tap is the row itself.
 template <int BM, bool SUBM>
 __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __restrict__ out_indices, int m_cap,
                                                                  const int* __restrict__ m_dev, ConvGeom g,
@@ -812,41 +814,44 @@ __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __re
   const int4 c = live ? ((const int4*)out_indices)[row] : make_int4(0, 0, 0, 0);
   const int X = g.in_shape[0], Y = g.in_shape[1], Z = g.in_shape[2];
   const int x0 = c.y * g.stride[0] - g.pad[0], y0 = c.z * g.stride[1] - g.pad[1], z0 = c.w * g.stride[2] - g.pad[2];
-  const int kzf = z0 < 0 ? -z0 : 0;          // first kz tap inside the grid
+  const int ylo = y0 < 0 ? 0 : y0, yhi = y0 + 2 < Y ? y0 + 2 : Y - 1;
+  const int zlo = z0 < 0 ? 0 : z0, zhi = z0 + 2 < Z ? z0 + 2 : Z - 1;
+  const bool win = live && ylo <= yhi && zlo <= zhi;
   int v[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) v[k] = -1;
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
     const int x = x0 + kx;
-    const bool xok = live && x >= 0 && x < X && kzf < 3 && z0 + kzf < Z;
-    int p = 0, hi = 0;
-    if (xok) {
-      const int bx = c.x * X + x;
-      p = in_xstart[bx];
-      hi = in_xstart[bx + 1];
-    }
+    if (!(win && x >= 0 && x < X)) continue;
+    const int bx = c.x * X + x;
+    int q = in_xstart[bx];
+    const int hi = in_xstart[bx + 1];
+    if (q >= hi) continue;
+    const uint32_t plane = (uint32_t)bx * (uint32_t)Y * (uint32_t)Z;
+    const uint32_t kmax = plane + (uint32_t)(yhi * Z + zhi);
+    q = sorted_lower_bound(in_keys, q, hi, plane + (uint32_t)(ylo * Z + zlo));
+    for (bool more = q < hi; more;) {
+      uint32_t key[4];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int y = y0 + ky;
-      const bool ok = xok && y >= 0 && y < Y && p < hi;
-      uint32_t tgt = 0;
-      if (ok) {
-        tgt = (((uint32_t)c.x * (uint32_t)X + (uint32_t)x) * (uint32_t)Y + (uint32_t)y) * (uint32_t)Z + (uint32_t)(z0 + kzf);
-        p = sorted_lower_bound(in_keys, p, hi, tgt);
-      }
+      for (int u = 0; u < 4; ++u) key[u] = in_keys[q + u < hi ? q + u : hi - 1];
 #pragma unroll
-      for (int kz = 0; kz < 3; ++kz) {
-        const int k = (kx * 3 + ky) * 3 + kz;
-        int r = -1;
-        if (SUBM && k == 13) {
-          r = live ? row : -1;
-          if (ok && kz >= kzf && p < hi && in_keys[p] == tgt + (uint32_t)(kz - kzf)) ++p;   // step over the row itself
-        } else if (ok && kz >= kzf && z0 + kz < Z && p < hi) {
-          if (in_keys[p] == tgt + (uint32_t)(kz - kzf)) { r = p; ++p; }
+      for (int u = 0; u < 4; ++u) {
+        if (!more) break;
+        if (q + u >= hi || key[u] > kmax) { more = false; break; }
+        const int r = (int)(key[u] - plane) - y0 * Z;   // (y - y0) * Z + z, y - y0 in [0, 2]
+        const int ky = r >= 2 * Z ? 2 : r >= Z ? 1 : 0;
+        const int kz = r - ky * Z - z0;
+        if (kz >= 0 && kz < 3) {
+          const int tap = ky * 3 + kz;
+#pragma unroll
+          for (int d = 0; d < 9; ++d) v[kx * 9 + d] = tap == d ? q + u : v[kx * 9 + d];
         }
-        v[k] = r;
       }
+      q += 4;
     }
   }
+  if (SUBM) v[13] = live ? row : -1;
   slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
 }
 

@@ -60,6 +60,16 @@ __device__ __forceinline__ f32x4 mfma(const u32x4& w, const u32x4& x, f32x4 acc)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
 
+// Rounding point of the epilogue: the fp32 value is made opaque before it is narrowed, so that hipcc cannot fuse the producing
+// add / fma with the conversion into v_fma_mixlo_f16 (ONE rounding from the exact result; measured: 1-ulp differences in 1e-4 of
+// the elements between the two epilogue flavours below, depending on which pattern the instruction selector happened to see).
+// Every kernel thus rounds twice (fp32 operation, then the cast) — the arithmetic of the unfused reference pipeline.
+template <int DT>
+__device__ __forceinline__ float round_to_storage(float v) {
+  asm volatile("" : "+v"(v));
+  return Num<DT>::to_f32(Num<DT>::from_f32(v));
+}
+
 struct Args {
   const void* feat;     // [n_in, feat_stride] 16-bit
   const void* wimg;     // filter image (see make_filter_image)
@@ -123,19 +133,20 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int row, int col0,
       const uint2 raw = *(const uint2*)((const T*)a.bias + col0);
       const T* b = (const T*)&raw;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(x[j] + Num<DT>::to_f32(b[j])));
+      for (int j = 0; j < 4; ++j) x[j] = round_to_storage<DT>(x[j] + Num<DT>::to_f32(b[j]));
     }
     if (a.scale) {
       const float4 sc = *(const float4*)(a.scale + col0), sh = *(const float4*)(a.shift + col0);
-      x[0] = x[0] * sc.x + sh.x; x[1] = x[1] * sc.y + sh.y; x[2] = x[2] * sc.z + sh.z; x[3] = x[3] * sc.w + sh.w;
+      // one fused multiply-add everywhere the folded BatchNorm is applied (both epilogue flavours: same bits whichever kernel runs a layer)
+      x[0] = __builtin_fmaf(x[0], sc.x, sh.x); x[1] = __builtin_fmaf(x[1], sc.y, sh.y); x[2] = __builtin_fmaf(x[2], sc.z, sh.z); x[3] = __builtin_fmaf(x[3], sc.w, sh.w);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(x[j]));
+      for (int j = 0; j < 4; ++j) x[j] = round_to_storage<DT>(x[j]);
     }
     if (a.residual) {
       const uint2 raw = *(const uint2*)((const T*)a.residual + (size_t)row * a.res_stride + col0);
       const T* r = (const T*)&raw;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(x[j] + Num<DT>::to_f32(r[j])));
+      for (int j = 0; j < 4; ++j) x[j] = round_to_storage<DT>(x[j] + Num<DT>::to_f32(r[j]));
     }
     T p[4];
 #pragma unroll
@@ -146,9 +157,9 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int row, int col0,
   for (int j = 0; j < 4; ++j) {
     if (col0 + j >= a.cout) break;
     float y = x[j];
-    if (a.bias) y = Num<DT>::to_f32(Num<DT>::from_f32(y + Num<DT>::to_f32(((const T*)a.bias)[col0 + j])));
-    if (a.scale) y = Num<DT>::to_f32(Num<DT>::from_f32(y * a.scale[col0 + j] + a.shift[col0 + j]));
-    if (a.residual) y = Num<DT>::to_f32(Num<DT>::from_f32(y + Num<DT>::to_f32(((const T*)a.residual)[(size_t)row * a.res_stride + col0 + j])));
+    if (a.bias) y = round_to_storage<DT>(y + Num<DT>::to_f32(((const T*)a.bias)[col0 + j]));
+    if (a.scale) y = round_to_storage<DT>(__builtin_fmaf(y, a.scale[col0 + j], a.shift[col0 + j]));
+    if (a.residual) y = round_to_storage<DT>(y + Num<DT>::to_f32(((const T*)a.residual)[(size_t)row * a.res_stride + col0 + j]));
     if (a.relu && y < 0.f) y = 0.f;
     op[j] = Num<DT>::from_f32(y);
   }
@@ -382,16 +393,16 @@ struct WaveTile {
           for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(v[e]);
           if (a.bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] + bv[e]));
+            for (int e = 0; e < 8; ++e) x[e] = round_to_storage<DT>(x[e] + bv[e]);
           }
           if (a.scale) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] * sv[e] + hv[e]));
+            for (int e = 0; e < 8; ++e) x[e] = round_to_storage<DT>(__builtin_fmaf(x[e], sv[e], hv[e]));
           }
           if (a.residual) {
             const T* rv = (const T*)&res.v[mt][pass];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(Num<DT>::from_f32(x[e] + Num<DT>::to_f32(rv[e])));
+            for (int e = 0; e < 8; ++e) x[e] = round_to_storage<DT>(x[e] + Num<DT>::to_f32(rv[e]));
           }
           T o[8];
 #pragma unroll

@@ -40,6 +40,7 @@ class NotThisCall(Exception):
 
 
 _GEOM_STREAMS = {}
+_PREFETCHING = [False]   # inside prefetch_geometry: products are built behind the fork point, nothing of this pass runs on the main stream yet
 
 # Per-layer profile (bench.py's `roofline_spconv`): set to a list and every fused convolution appends a record with HIP events
 # around its launch and, after a sync, its pair count.  None (default) = no overhead.  Only meaningful in eager passes.
@@ -95,6 +96,15 @@ class Level:
             return ctypes.c_void_p(self.gstream.cuda_stream)
         return _capi.stream_ptr(self.device)
 
+    def _fork(self):
+        """Called before a product is allocated and built OUTSIDE the up-front rulebook chain (a table a convolution asks for
+        on demand, e.g. the int32 tables of a profiled pass): the geometry stream must first wait for what the main stream has
+        issued so far.  The buffer comes from the main stream's allocator, which hands out a block as soon as its last tensor
+        died — possibly while a convolution that read that tensor is still running — and a geometry-stream kernel writing into
+        it would not be ordered behind that convolution (seen as NaN rows: sp_nbr_clear's -1 words under a running layer)."""
+        if self.gstream is not None and not _PREFETCHING[0]:
+            self.gstream.wait_stream(torch.cuda.current_stream(self.device))
+
     def _mark(self):
         """Event behind everything launched so far on the geometry stream (None on the single-stream path)."""
         if self.gstream is None:
@@ -111,6 +121,7 @@ class Level:
     def ensure_index(self):
         if self.index is not None:
             return
+        self._fork()
         lib = _capi.load()
         dev = self.device
         with torch.cuda.device(dev):
@@ -128,6 +139,7 @@ class Level:
         if not self.linear_order:
             raise RuntimeError("sorted-key index of a voxel set that is not in linear order")
         if self.sorted_index is None:
+            self._fork()
             self.sorted_index, self.sorted_status = ops.sorted_index_build(self.indices, self.n_cap, self.n_dev, self.batch,
                                                                            self.shape, stream_ptr=self._stream_ptr())
             self._sorted_ev = self._mark()
@@ -145,6 +157,7 @@ class Level:
     def _neighbors(self, out_indices, m_cap, m_dev, out_shape, ksize, stride, padding, subm):
         lib = _capi.load()
         self.ensure_index()
+        self._fork()
         dev = self.device
         K = ksize[0] * ksize[1] * ksize[2]
         nbr = torch.empty((K, max(m_cap, 1)), dtype=torch.int32, device=dev)
@@ -172,6 +185,7 @@ class Level:
         """Slab metadata (ops.SlabMeta) of the 3x3x3 SubM neighbour table, for `block_rows`-row blocks: built once, on the
         geometry stream, behind the table it rewrites."""
         if block_rows not in self._slab:
+            self._fork()
             if self.use_sorted():
                 self.ensure_sorted(wait=False)
                 meta = ops.slab_build_from_sorted(self.indices, self.n_cap, self.n_dev, self.batch, self.shape, self.shape,
@@ -197,6 +211,7 @@ class Level:
         if key not in self._down_slab:
             out, _ = self.downsample(ksize, stride, padding, wait=False, want_nbr=False)
             self.ensure_sorted(wait=False)
+            self._fork()
             meta = ops.slab_build_from_sorted(out.indices, out.n_cap, out.n_dev, self.batch, self.shape, out.shape, list(stride),
                                               list(padding), False, self.sorted_index, self.n_cap, block_rows,
                                               stream_ptr=self._stream_ptr())
@@ -222,6 +237,7 @@ class Level:
                 self._await(out.ready)
                 self._await(ev)
             return out, nbr
+        self._fork()
         lib = _capi.load()
         dev = self.device
         out_shape = ops.get_conv_output_size(self.shape, list(ksize), list(stride), list(padding), [1, 1, 1])
@@ -646,6 +662,16 @@ def prefetch_geometry(enc, lvl):
     it: hash index, SubM neighbour tables and downsamples of every level.  The feature pass then finds each product in
     its Level's cache and waits on its event only.  A tree whose module order differs from its execution order merely
     builds some tables later, on demand."""
+    from .conv import SparseConvolution
+
+    _PREFETCHING[0] = True
+    try:
+        _prefetch_geometry(enc, lvl)
+    finally:
+        _PREFETCHING[0] = False
+
+
+def _prefetch_geometry(enc, lvl):
     from .conv import SparseConvolution
 
     cur = lvl

@@ -318,7 +318,9 @@ def test_encoder_key_ordered_path_is_bit_identical_to_first_appearance_path(dev,
     # level 1 ran on the narrow slab kernels: input layer, four 16 -> 16 layers, the strided 16 -> 32
     assert kinds[0][:4] == (5, 16, True, "slab") and all(k[3] == "slab" for k in kinds[1:5]) and kinds[5][:4] == (16, 32, False, "slab")
     assert kinds[5][4] == 3000128 and kinds[1][4] == 3000256
-    assert torch.equal(got, ref) and torch.equal(again, ref) and torch.equal(prepared, ref)
+    assert torch.equal(again, ref), "un-profiled key-order pass"
+    assert torch.equal(prepared, ref), "key-order pass over a prepared geometry"
+    assert torch.equal(got, ref), "profiled key-order pass"
     assert fused.geometry_status(lvl) == 0
     # the promise is checked on the device: first-appearance rows passed off as linear raise the status bit
     lvl_bad = fused.Level(c0, c0.shape[0], t0.reshape(-1)[:1].int().contiguous(), B, list(CFG["sparse_shape"]), linear_order=True)
