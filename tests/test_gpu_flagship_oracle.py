@@ -1,0 +1,209 @@
+"""Direct oracle parity of exactly what the driver's bench times ("next round" item 3).
+
+  (i)   >= 4 frames per step — the regime in which `fused._slab_variant_for` picks the persistent 32-channel kernel (2324410)
+        and the 128-channel slab kernel (1644220), with level 1 in key order (narrow slab kernels 3000256 / 3000128): per level,
+        the fp16 output of the first SubM layer and of the strided convolution leaving the level, each against
+        `oracle.indice_conv` (float64) on the GPU's own stage input, <= 2e-3 * (1 + max|ref|);
+  (ii)  the bench's exact shape — 8 full 10-sweep clouds at the 160 k cap (1.28 M level-1 rows): the fused key-ordered path
+        against the module-by-module path, its level chain (active sets, row order, counts) against the oracle, and the dense
+        output bit-identical to the fused first-appearance path;
+  (iii) end to end: the dense BEV output of the fused encoder on a flagship-grid frame against an ORACLE CHAIN — every layer of
+        `SparseEncoder.forward` (sparse_encoder.py:100-132) restated in float64: `oracle.get_indice_pairs` +
+        `oracle.indice_conv`, eval-mode BatchNorm1d, ReLU, the residual add of `SparseBasicBlock.forward`
+        (sparse_block.py:88-107), `.dense()` + permute + view.
+
+References: sparse_encoder.py:100-132, sparse_block.py:88-107, spconv/conv.py:118-223, spconv_ops.h:27-141, 260-361."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import oracle
+from bevfusion_amd import synth
+from bevfusion_amd.sparse_block import SparseBasicBlock
+from bevfusion_amd.spconv import fused
+from bevfusion_amd.spconv import ops as sops
+from bevfusion_amd.spconv.conv import SparseConvolution
+from bevfusion_amd.spconv.modules import SparseSequential
+from bevfusion_amd.voxel import voxelize_batch_device
+from test_gpu_keyorder import flagship_encoder
+
+pytestmark = pytest.mark.gpu
+CFG = synth.CL_CONFIG
+
+
+def _voxels(dev, sweeps, order, seed0=100):
+    pts = [torch.from_numpy(synth.lidar_points(seed=seed0 + b, sweeps=s)).to(dev) for b, s in enumerate(sweeps)]
+    return voxelize_batch_device(pts, CFG["voxel_size"], CFG["point_cloud_range"], CFG["max_num_points"], CFG["max_voxels"][1],
+                                 order=order)
+
+
+# ---- (i) the variants the driver times, layer by layer against the float64 oracle -------------------------------------------
+def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev):
+    B = 4
+    f, c, _, tot = _voxels(dev, [2, 2, 1, 2], "key")
+    n = int(tot.item())
+    rng = np.random.default_rng(0)
+    lvl = fused.Level(c, c.shape[0], tot.reshape(-1)[:1].int().contiguous(), B, list(CFG["sparse_shape"]), linear_order=True)
+    ind, shape = c[:n].cpu().numpy(), list(CFG["sparse_shape"])
+    widths = [16, 32, 64, 128]
+    expect = {16: 3000256, 32: 2324410, 64: 1644222, 128: 1644220}
+    down = [((3, 3, 3), (2, 2, 2), (1, 1, 1), 32), ((3, 3, 3), (2, 2, 2), (1, 1, 1), 64), ((3, 3, 3), (2, 2, 2), (1, 1, 0), 128),
+            ((1, 1, 3), (1, 1, 2), (0, 0, 0), 128)]
+    x = torch.zeros((lvl.n_cap, 16), dtype=torch.float16, device=dev)
+    x[:n] = torch.from_numpy(rng.standard_normal((n, 16)).astype(np.float32) * 0.5).to(dev).half()
+    for stage, (cw, (ks, st, pd, cout)) in enumerate(zip(widths, down)):
+        n = ind.shape[0]
+        w = torch.from_numpy((rng.standard_normal((3, 3, 3, cw, cw)) / np.sqrt(cw * 27 / 4)).astype(np.float32)).to(dev).half()
+        conv = type("C", (), dict(subm=True, kernel_size=(3, 3, 3)))()
+        variant = fused._slab_variant_for(conv, lvl, cw, cw)
+        assert variant == expect[cw], (cw, variant)                  # exactly the kernels of an 8-frame bench step
+        got = sops.sparse_conv_slab(x, sops.make_filter_image(w), lvl.subm_slab(sops.slab_block_rows(cw, variant)), lvl.n_cap,
+                                    cw, cw, num_out_dev=lvl.n_dev, variant=variant)[:n]
+        _, sp, sn, _ = oracle.get_indice_pairs(ind, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
+        ref = oracle.indice_conv(x[:n].float().cpu().numpy(), w.float().cpu().numpy(), sp, sn, n)
+        err = float(np.max(np.abs(got.float().cpu().numpy() - ref)))
+        assert err <= 2e-3 * (1 + np.abs(ref).max()), (stage, "subm", err)
+        # the strided convolution leaving the level, through the kernel the fused path uses for it
+        oi, op, on, oshape = oracle.get_indice_pairs(ind, B, shape, ks, st, pd, [1, 1, 1], 0, order="cuda")
+        K = int(np.prod(ks))
+        ws = torch.from_numpy((rng.standard_normal(tuple(ks) + (cw, cout)) / np.sqrt(cw * K / 4)).astype(np.float32)).to(dev).half()
+        sconv = type("C", (), dict(subm=False, kernel_size=ks))()
+        svar = fused._slab_variant_for(sconv, lvl, cw, cout)
+        assert (svar is not None) == (stage == 0) and (svar is None or svar == 3000128)
+        nxt, nbr = lvl.downsample(list(ks), list(st), list(pd), want_nbr=svar is None)
+        m = int(nxt.n_dev.item())
+        assert m == oi.shape[0] and np.array_equal(nxt.indices[:m].cpu().numpy(), oi)
+        if svar is not None:
+            meta = lvl.down_slab(list(ks), list(st), list(pd), sops.slab_block_rows(cw, svar))
+            y = sops.sparse_conv_slab(x, sops.make_filter_image(ws), meta, nxt.n_cap, cw, cout, num_out_dev=nxt.n_dev, variant=svar)
+        else:
+            y = sops.sparse_conv_tiled(x, sops.make_filter_image(ws), nbr, nxt.n_cap, K, cw, cout, num_out_dev=nxt.n_dev,
+                                       variant=fused._variant_for(B, K, cw, cout))
+        refy = oracle.indice_conv(x[:n].float().cpu().numpy(), ws.float().cpu().numpy(), op, on, m)
+        erry = float(np.max(np.abs(y[:m].float().cpu().numpy() - refy)))
+        assert erry <= 2e-3 * (1 + np.abs(refy).max()), (stage, "strided", erry)
+        x = torch.relu(y).contiguous()
+        x[m:] = 0
+        lvl, ind, shape = nxt, oi, list(oshape)
+    assert shape == [180, 180, 2] and fused.geometry_status(lvl) == 0
+
+
+# ---- (ii) the bench's exact shape --------------------------------------------------------------------------------------------
+def test_bench_shape_eight_full_clouds_fused_vs_modules_and_oracle_levels(dev):
+    B = 8
+    f1, c1, _, t1 = _voxels(dev, [10] * B, "key", seed0=0)              # bench.py: synth.lidar_points(seed=frame id), 10 sweeps
+    f0, c0, _, t0 = _voxels(dev, [10] * B, "first", seed0=0)
+    n = int(t1.item())
+    assert n == B * CFG["max_voxels"][1]                                 # every frame at the 160 k cap: 1.28 M level-1 rows
+    enc = flagship_encoder(dev)
+    with torch.no_grad():
+        got = enc(f1, c1, B, num_voxels=t1, coors_order="linear")
+        assert enc.last_path == "fused", enc.last_path_reason
+        first = enc(f0, c0, B, num_voxels=t0)
+        enc.fused_inference = False
+        ref = enc(f0.half(), c0, B, num_voxels=t0)
+        assert enc.last_path == "modules"
+    assert tuple(got.shape) == (B, 256, 180, 180)
+    assert torch.equal(got, first)                                       # key-ordered == first-appearance fused path, bit for bit
+    err = float((got.float() - ref.float()).abs().max())
+    assert err <= 1e-2 * (1 + float(ref.float().abs().max())), err
+    # level chain at this shape vs the oracle
+    ind = c1[:n].cpu().numpy()
+    lvl = fused.Level(c1, c1.shape[0], t1.reshape(-1)[:1].int().contiguous(), B, list(CFG["sparse_shape"]), linear_order=True)
+    shape = list(CFG["sparse_shape"])
+    rows = []
+    for ks, st, pd in [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                       ((3, 3, 3), (2, 2, 2), (1, 1, 0)), ((1, 1, 3), (1, 1, 2), (0, 0, 0))]:
+        oi, _, onum, oshape = oracle.get_indice_pairs(ind, B, shape, ks, st, pd, [1, 1, 1], 0, order="cuda")
+        lvl, nbr = lvl.downsample(list(ks), list(st), list(pd))
+        m = int(lvl.n_dev.item())
+        assert m == oi.shape[0] and np.array_equal(lvl.indices[:m].cpu().numpy(), oi)
+        assert np.array_equal((nbr[:, :m] >= 0).sum(1).cpu().numpy(), onum)
+        rows.append(m)
+        ind, shape = oi, list(oshape)
+    assert rows[0] > 2_000_000 and shape == [180, 180, 2]                # the 2.08 M-row level the 32-channel layers run on
+
+
+# ---- (iii) the whole encoder against a float64 oracle chain -------------------------------------------------------------------
+class _OracleTensor:
+    def __init__(self, feats, indices, shape, batch):
+        self.f, self.ind, self.shape, self.batch = feats, indices, shape, batch
+        self.subm_pairs = {}
+
+
+def _bn64(bn, x):
+    g = bn.weight.detach().double().cpu().numpy() if bn.weight is not None else 1.0
+    b = bn.bias.detach().double().cpu().numpy() if bn.bias is not None else 0.0
+    mean, var = bn.running_mean.detach().double().cpu().numpy(), bn.running_var.detach().double().cpu().numpy()
+    return (x - mean) / np.sqrt(var + bn.eps) * g + b
+
+
+def _conv64(conv, t):
+    ks, st, pd = tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)
+    w = conv.weight.detach().float().cpu().numpy()
+    if conv.subm:
+        if ks not in t.subm_pairs:
+            _, sp, sn, _ = oracle.get_indice_pairs(t.ind, t.batch, t.shape, ks, (1, 1, 1), tuple(k // 2 for k in ks), [1, 1, 1], 1,
+                                                   order="cuda")
+            t.subm_pairs[ks] = (sp, sn)
+        sp, sn = t.subm_pairs[ks]
+        out = _OracleTensor(oracle.indice_conv(t.f.astype(np.float32), w, sp, sn, t.ind.shape[0]), t.ind, t.shape, t.batch)
+        out.subm_pairs = t.subm_pairs
+    else:
+        oi, op, on, oshape = oracle.get_indice_pairs(t.ind, t.batch, t.shape, ks, st, pd, [1, 1, 1], 0, order="cuda")
+        out = _OracleTensor(oracle.indice_conv(t.f.astype(np.float32), w, op, on, oi.shape[0]), oi, list(oshape), t.batch)
+    if conv.bias is not None:
+        out.f = out.f + conv.bias.detach().double().cpu().numpy()
+    return out
+
+
+def _walk64(seq, t):
+    mods = list(seq._modules.values())
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, SparseConvolution):
+            t = _conv64(m, t)
+        elif isinstance(m, nn.BatchNorm1d):
+            t.f = _bn64(m, t.f)
+        elif isinstance(m, nn.ReLU):
+            t.f = np.maximum(t.f, 0.0)
+        elif isinstance(m, SparseBasicBlock):                            # sparse_block.py:88-107
+            identity = t.f
+            y = _conv64(m.conv1, t)
+            y.f = np.maximum(_bn64(m.norm1, y.f), 0.0)
+            y = _conv64(m.conv2, y)
+            y.f = np.maximum(_bn64(m.norm2, y.f) + identity, 0.0)
+            t = y
+        elif isinstance(m, SparseSequential):
+            t = _walk64(m, t)
+        else:
+            raise AssertionError(type(m))
+        i += 1
+    return t
+
+
+@pytest.mark.parametrize("order", ["key", "first"])
+def test_encoder_dense_output_vs_float64_oracle_chain(dev, order):
+    f, c, _, tot = _voxels(dev, [2], order, seed0=5)
+    n = int(tot.item())
+    enc = flagship_encoder(dev)
+    with torch.no_grad():
+        got = enc(f, c, 1, num_voxels=tot, coors_order="linear" if order == "key" else None)
+    assert enc.last_path == "fused", enc.last_path_reason
+    t = _OracleTensor(f[:n].half().double().cpu().numpy(), c[:n].cpu().numpy(), list(CFG["sparse_shape"]), 1)   # the fp16 input the path sees
+    t = _walk64(enc.conv_input, t)
+    t = _walk64(enc.encoder_layers, t)
+    t = _walk64(enc.conv_out, t)
+    X, Y, Z = t.shape
+    C = t.f.shape[1]
+    dense = np.zeros((1, C, X, Y, Z))
+    dense[t.ind[:, 0], :, t.ind[:, 1], t.ind[:, 2], t.ind[:, 3]] = t.f     # SparseConvTensor.dense()
+    ref = dense.transpose(0, 1, 4, 2, 3).reshape(1, C * Z, X, Y)          # sparse_encoder.py:126-131
+    assert tuple(got.shape) == ref.shape == (1, 256, 180, 180)
+    g = got.double().cpu().numpy()
+    assert not np.isnan(g).any()
+    err = float(np.max(np.abs(g - ref)))
+    assert err <= 1e-2 * (1 + np.abs(ref).max()), err
+    assert not g[np.abs(ref).sum(1, keepdims=True).repeat(g.shape[1], 1) == 0].any()   # nothing outside the oracle's active BEV cells
