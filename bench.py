@@ -131,6 +131,90 @@ def dry_run(args, rank, world, frame_ids):
             "dry_run": True}), flush=True)
 
 
+def wrap_for_gradient_allreduce(module, world, device=None):
+    """The ONE collective of the path (apis/train.py:48-53): gradients are all-reduced by DistributedDataParallel over
+    torch.distributed ("nccl" = RCCL over xGMI on the GPUs, gloo in --dry-run); a single rank trains the bare module."""
+    if world <= 1:
+        return module
+    if device is not None and device.type == "cuda":
+        return torch.nn.parallel.DistributedDataParallel(module, device_ids=[device.index])
+    return torch.nn.parallel.DistributedDataParallel(module)
+
+
+def dry_run_train(args, rank, world, frame_ids):
+    """`--mode train-step --dry-run`: the DDP wiring of train_step() around a host stub of the trainable part (a small MLP
+    standing in for the SparseEncoder), gloo instead of RCCL: per-rank data (seeded by frame id), the SAME initial weights on
+    every rank, backward through DistributedDataParallel, clip_grad_norm + AdamW.  Reported: whether the per-rank inputs differ,
+    whether the gradients and the updated weights agree on all ranks after the all-reduce, and that they equal the mean of the
+    per-rank gradients computed without DDP."""
+    import torch.distributed as dist
+
+    from bevfusion_amd.sharding import barrier, max_over_ranks, sum_over_ranks
+
+    torch.manual_seed(0)                                   # same initial weights everywhere (as make_encoder does)
+    stub = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
+    solo = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8))
+    solo.load_state_dict(stub.state_dict())
+    model = wrap_for_gradient_allreduce(stub, world)
+    opt = torch.optim.AdamW(stub.parameters(), lr=2e-4, weight_decay=0.01)
+
+    def batch():
+        xs = [torch.randn(16, 64, generator=torch.Generator().manual_seed(1000 + f)) for f in frame_ids]
+        return torch.cat(xs, 0) if xs else torch.zeros(0, 64)
+
+    x = batch()
+    data_sum = float(x.double().sum())
+    # reference: this rank's own gradient without DDP, averaged over the ranks by hand
+    solo(x).square().mean().backward()
+    own = torch.cat([p.grad.reshape(-1) for p in solo.parameters()])
+    mean_of_own = own.clone()
+    if world > 1:
+        dist.all_reduce(mean_of_own)
+        mean_of_own /= world
+
+    def step():
+        model(x).square().mean().backward()
+        g = torch.cat([p.grad.reshape(-1) for p in stub.parameters()]).clone()
+        torch.nn.utils.clip_grad_norm_(stub.parameters(), 35.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return g
+
+    first_grad = step()
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local)
+    frames_per_step = int(sum_over_ranks(len(frame_ids)))
+    weights = torch.cat([p.detach().reshape(-1) for p in stub.parameters()])
+    info = dict(rank=rank, frames=list(frame_ids), data_sum=data_sum, grad_sum=float(first_grad.double().sum()),
+                grad_vs_mean_of_own=float((first_grad - mean_of_own).abs().max()), weight_sum=float(weights.double().sum()))
+    per_rank = [None] * world
+    if world > 1:
+        dist.all_gather_object(per_rank, info)
+    else:
+        per_rank = [info]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "DRY RUN (host stub, no GPU work): DistributedDataParallel wiring of --mode train-step",
+            "value": frames_per_step * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dry-run stub of the training step", "frames_per_step": frames_per_step, "backend": "gloo",
+                       "world_size": world, "per_rank": per_rank,
+                       "ddp": world > 1,
+                       "inputs_differ_across_ranks": len({r["data_sum"] for r in per_rank}) == world,
+                       "gradients_agree_across_ranks": max(r["grad_sum"] for r in per_rank) - min(r["grad_sum"] for r in per_rank) == 0.0,
+                       "weights_agree_across_ranks": max(r["weight_sum"] for r in per_rank) - min(r["weight_sum"] for r in per_rank) == 0.0,
+                       "max_abs_grad_minus_mean_of_per_rank_grads": max(r["grad_vs_mean_of_own"] for r in per_rank)},
+            "dry_run": True}), flush=True)
+
+
 def make_encoder(cfg, dev, dtype):
     from bevfusion_amd.sparse_encoder import SparseEncoder
 
@@ -336,9 +420,7 @@ def train_step(args, rank, world, frame_ids, dev):
     gout = torch.randn((B, D, H, W, C), generator=gen, device=dev)
     pts = [torch.from_numpy(synth.lidar_points(seed=f)).to(dev) for f in frame_ids]
     enc = make_encoder(cfg, dev, torch.float32).train()
-    model = enc
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(enc, device_ids=[dev.index])
+    model = wrap_for_gradient_allreduce(enc, world, dev)
     opt = torch.optim.AdamW(enc.parameters(), lr=2e-4, weight_decay=0.01)
     names = ["bev_pool_fwd", "bev_pool_bwd", "fused_pool_fwd", "fused_pool_bwd", "voxelize", "encoder_fwd", "encoder_bwd+allreduce",
              "clip+adamw"]
@@ -437,7 +519,7 @@ def main():
     else:
         frame_ids = [rank * max(1, args.batch) + b for b in range(max(1, args.batch))]
     if args.dry_run:
-        dry_run(args, rank, world, frame_ids)
+        (dry_run_train if args.mode == "train-step" else dry_run)(args, rank, world, frame_ids)
         if world > 1:
             import torch.distributed as dist
 

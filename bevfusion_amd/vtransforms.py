@@ -16,6 +16,7 @@ Reference defects handled as SURVEY.md lists them: D2 (`get_cam_feats` arity) an
 scalar 1-channel depth, no height expansion — the semantics the released checkpoint's `Conv2d(1, 8, 1)` needs).
 """
 import ctypes
+import warnings
 from typing import Tuple
 
 import torch
@@ -55,6 +56,8 @@ def _fp32(*tensors):
 
 
 class BaseTransform(nn.Module):
+    _warned_sync = False   # the "fingerprinting the calibration costs a device-to-host copy" warning is issued once per process
+
     def __init__(self, in_channels: int, out_channels: int, image_size: Tuple[int, int], feature_size: Tuple[int, int],
                  xbound: Tuple[float, float, float], ybound: Tuple[float, float, float],
                  zbound: Tuple[float, float, float], dbound: Tuple[float, float, float], use_points="lidar",
@@ -89,6 +92,7 @@ class BaseTransform(nn.Module):
         self._plan = None
         self._plan_key = None
         self._pending_key = None
+        self._plan_geom = None          # the geometry tensor a directly-keyed plan was built from (kept alive with the plan)
         self.fused_cam_feats = True
         # 3x3 inverses of the calibration on the device path: False = bevamd_lss_camera_matrices / bevamd_mat3_inverse
         # (fp64 adjugate, no LAPACK call, no host sync); True = torch.inverse like the reference, call for call
@@ -179,7 +183,7 @@ class BaseTransform(nn.Module):
     # -- plan cache: a pooling plan is valid for ONE set of calibration + augmentation matrices --------------
     def invalidate_plan(self):
         """Drop the cached pooling plan (new calibration, new device, ...)."""
-        self._plan = self._plan_key = self._pending_key = None
+        self._plan = self._plan_key = self._pending_key = self._plan_geom = None
 
     @staticmethod
     def _calibration_key(tensors, calibration_id=None):
@@ -189,6 +193,11 @@ class BaseTransform(nn.Module):
         if calibration_id is not None:
             return ("id", calibration_id)
         flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+        if flat.is_cuda and not BaseTransform._warned_sync:
+            BaseTransform._warned_sync = True
+            warnings.warn("cache_geometry=True without calibration_id: the calibration matrices are fingerprinted through a blocking "
+                          "device-to-host copy on every forward (and cannot be captured into a HIP graph); pass calibration_id=<any "
+                          "hashable that changes with the calibration> to stay sync-free", RuntimeWarning, stacklevel=4)
         return ("bytes", str(flat.device), flat.cpu().numpy().tobytes())
 
     def _geometry_or_cached(self, c2l_rots, c2l_trans, intrins, post_rots, post_trans, extra_rots, extra_trans,
@@ -214,7 +223,8 @@ class BaseTransform(nn.Module):
             assert use_cache and self._plan is not None and self._plan_key == key
             return self._plan
         if use_cache:
-            if key is None:   # bev_pool() called directly: the geometry tensor itself is the identity
+            by_tensor = key is None
+            if by_tensor:     # bev_pool() called directly: the geometry tensor itself is the identity
                 key = (("geom", geom_feats.data_ptr(), geom_feats._version, tuple(geom_feats.shape)), Nprime, B,
                        str(geom_feats.device))
             if self._plan is not None and self._plan_key == key:
@@ -222,6 +232,9 @@ class BaseTransform(nn.Module):
         plan = self.make_plan(geom_feats, B)
         if use_cache:
             self._plan, self._plan_key = plan, key
+            # (address, version) only identify the tensor while it is alive: the cache keeps it, so the allocator cannot hand its
+            # address to the geometry of another calibration (a recycled address matched the stale plan)
+            self._plan_geom = geom_feats if by_tensor else None
         return plan
 
     def bev_pool(self, geom_feats, x):

@@ -37,3 +37,17 @@ def test_global_batch_is_split_with_frames_for_rank():
     assert one["n_gpus"] == 1 and one["config"]["per_rank"][0]["frames"] == [0, 1, 2, 3, 4]
     # every frame is processed exactly once whatever the rank count: same checksum
     assert abs(one["config"]["checksum"] - res["config"]["checksum"]) < 1e-6 * abs(one["config"]["checksum"])
+
+
+def test_train_step_dry_run_goes_through_ddp():
+    """`--mode train-step --gpus 2 --dry-run`: the gradient path of the N > 1 training step — per-rank
+    inputs differ, gradients pass through DistributedDataParallel (gloo here, RCCL on the GPUs) and come out identical on
+    both ranks and equal to the mean of the per-rank gradients; the updated weights stay in lock step."""
+    res = run_bench("--mode", "train-step", "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--batch", "2")
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and res["dry_run"] and cfg["ddp"] and cfg["frames_per_step"] == 4
+    assert sorted(tuple(r["frames"]) for r in cfg["per_rank"]) == [(0, 1), (2, 3)]
+    assert cfg["inputs_differ_across_ranks"] and cfg["gradients_agree_across_ranks"] and cfg["weights_agree_across_ranks"]
+    assert cfg["max_abs_grad_minus_mean_of_per_rank_grads"] <= 1e-6
+    one = run_bench("--mode", "train-step", "--dry-run", "--steps", "2", "--warmup", "1", "--batch", "2")
+    assert one["n_gpus"] == 1 and not one["config"]["ddp"]
