@@ -59,6 +59,11 @@ def parse():
                          "lidar: the WHOLE LiDAR branch (one HIP graph) runs on a second stream beside the camera stages, which is how the "
                          "two independent branches of the model can be scheduled; stage times then overlap and the bev_pool roofline figure "
                          "is measured WITH that concurrency")
+    ap.add_argument("--amp", action="store_true",
+                    help="--mode train-step: the reference's DEFAULT training arithmetic (configs/default.yaml:20-22 fp16 -> "
+                         "Fp16OptimizerHook, apis/train.py:75-85): sparse convolutions under torch.autocast(float16) "
+                         "(functional.py:24 custom_fwd(cast_inputs=torch.half)), fp32 master weights, dynamic loss scaling "
+                         "(GradScaler, growth_interval 2000).  Without it the step runs in fp32 throughout.")
     ap.add_argument("--voxel-order", choices=["key", "first"], default="key",
                     help="row order of the voxelizer's output: key = ascending linear cell index (level 1 of the encoder then runs on the "
                          "staged-rows kernels with sorted-key neighbour search; the dense BEV output is identical), first = the "
@@ -422,6 +427,7 @@ def train_step(args, rank, world, frame_ids, dev):
     enc = make_encoder(cfg, dev, torch.float32).train()
     model = wrap_for_gradient_allreduce(enc, world, dev)
     opt = torch.optim.AdamW(enc.parameters(), lr=2e-4, weight_decay=0.01)
+    scaler = torch.amp.GradScaler("cuda", growth_interval=2000) if args.amp else None
     names = ["bev_pool_fwd", "bev_pool_bwd", "fused_pool_fwd", "fused_pool_bwd", "voxelize", "encoder_fwd", "encoder_bwd+allreduce",
              "clip+adamw"]
 
@@ -438,12 +444,23 @@ def train_step(args, rank, world, frame_ids, dev):
         mark(4)
         vf, vc, _ = voxelize_batch(pts, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][0])
         mark(5)
-        y = model(vf, vc, B)
-        mark(6)
-        y.square().mean().backward()
-        mark(7)
-        torch.nn.utils.clip_grad_norm_(enc.parameters(), 35.0)
-        opt.step()
+        if scaler is not None:
+            with torch.autocast("cuda", dtype=torch.float16):
+                y = model(vf, vc, B)
+            mark(6)
+            scaler.scale(y.float().square().mean()).backward()
+            mark(7)
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(enc.parameters(), 35.0)
+            scaler.step(opt)
+            scaler.update()
+        else:
+            y = model(vf, vc, B)
+            mark(6)
+            y.square().mean().backward()
+            mark(7)
+            torch.nn.utils.clip_grad_norm_(enc.parameters(), 35.0)
+            opt.step()
         opt.zero_grad(set_to_none=True)
         feats.grad = depth.grad = ctx.grad = None
         mark(8)
@@ -469,10 +486,12 @@ def train_step(args, rank, world, frame_ids, dev):
         nparam = sum(p.numel() for p in enc.parameters())
         print(json.dumps({
             "metric": "train-step frames/sec of the BEVFusion C+L hot path (fwd + bwd + optimizer step of bev_pool / fused pooling / "
-                      "voxelize / SparseEncoder), fp32",
+                      "voxelize / SparseEncoder), " + ("fp16 mixed precision (the reference's default: configs/default.yaml fp16)" if args.amp else "fp32"),
             "value": frames_per_step * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
+            "dtype": "f16 convolution operands / f32 accumulate, master weights, BatchNorm and pooling (autocast)" if args.amp else "f32",
+            "data": "synthetic",
             "config": {"workload": f"training step of the hot path, {B} frame(s)/GPU (BASELINE configs[4]: 4 per GPU): bev_pool "
                                    f"N'={geom.shape[0]} ({n_kept} kept) x C={C} fwd+bwd, fused depth x context pooling fwd+bwd, hard "
                                    f"voxelize {sum(p.shape[0] for p in pts)} points (cap {cfg['max_voxels'][0]}), SparseEncoder fp32 "

@@ -283,6 +283,301 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const typename E
     for (int e = 0; e < 4; ++e) dst[(size_t)(t * 16 + l4 * 4 + e) * cout_pad + co] = acc[t][e];
 }
 
+// ---------------------------------------------------------------------------
+// filter gradient, second formulation (round 3): ROW-TILE stationary.  The kernel above puts the kernel offset k in the grid, so
+// every offset re-reads the whole out_grad matrix and walks its own column of the neighbour table: 27 passes over M rows each,
+// one dependent (table -> gather) round trip and three workgroup barriers per 32 rows — 1.4-3.1 ms per layer at 4 frames, 10 % of
+// the fp32 MFMA rate.  Here a workgroup owns a slab of rows and a (32 input) x (32 output) channel block and walks its rows ONCE:
+//   * the out_grad tile (32 rows x 32 channels) is staged in LDS once per tile (double buffered: ONE barrier per tile);
+//   * wave w owns the kernel offsets k = w, w + 4, ...: it keeps their accumulators (7 x 4 MFMA tiles) in registers for the whole
+//     slab, fetches nbr[k][tile rows] for all its offsets up front, gathers the 32 neighbour rows of an offset into its PRIVATE
+//     LDS tile while the MFMAs of the previous offset run (no workgroup barrier), and skips an offset no row of the tile reaches
+//     (level 1: 4.6 of 27 taps exist);
+//   * v_mfma_f32_16x16x4_f32 as before (exact fp32 for every feature dtype), A = X^T and B = gY read with ds_read_b32 from rows
+//     48 floats apart (consecutive rows 16 banks apart: the two 32-lane halves of a read hit disjoint banks).
+// Slab partials part[s][k][ci][co] and the fixed-order reduce are unchanged: deterministic, no atomics.
+// ---------------------------------------------------------------------------
+constexpr int WG2_R = 32;          // rows per tile
+constexpr int WG2_NW = 4;          // waves per workgroup; wave w owns kernel offsets w, w + 4, ...
+constexpr int WG2_TARGET_WGS = 768;
+constexpr int WG2_MAX_SLABS = 256;
+
+template <int DT, int CIT, int COT, int KPW>
+__global__ __launch_bounds__(256, 2) void spconv_wgrad2_kernel(const typename Elem<DT>::T* __restrict__ feat,
+                                                            const typename Elem<DT>::T* __restrict__ gout,
+                                                            const int* __restrict__ nbr, int nbr_stride, int m, int K, int cin,
+                                                            int cout, int cinp_tot, int coutp_tot, int rows_per_slab,
+                                                            float* __restrict__ part) {
+  typedef typename Elem<DT>::T T;
+  constexpr int R = WG2_R, CIB = CIT * 16, COB = COT * 16;
+  constexpr int LDA = CIB + 16, LDB = COB + 16;
+  constexpr int A4 = CIB / 4, B4 = COB / 4;          // 4-element pieces per row
+  constexpr int NLD = R * A4 / 64;                   // gathered pieces per lane and offset
+  __shared__ __attribute__((aligned(16))) float fb[2][R * LDB];
+  __shared__ __attribute__((aligned(16))) float fa[WG2_NW][R * LDA];
+  const int s = blockIdx.x, ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+  const int rbeg = s * rows_per_slab;
+  const int rend = rbeg + rows_per_slab < m ? rbeg + rows_per_slab : m;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool vec_a = (cin & 3) == 0, vec_b = (cout & 3) == 0;
+  f32x4 acc[KPW][CIT][COT];
+#pragma unroll
+  for (int kk = 0; kk < KPW; ++kk)
+#pragma unroll
+    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+      for (int b = 0; b < COT; ++b) acc[kk][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // 4 consecutive elements starting at channel c of row `row` (zeros past `width`), widened to fp32
+  auto load4 = [&](const T* base, int row, int width, int c, bool vec) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < 0 || c >= width) return v;
+    const T* p = base + (size_t)row * width + c;
+    if (vec) {
+      if constexpr (DT == DT_F32) {
+        v = *(const float4*)p;
+      } else {
+        const uint2 raw = *(const uint2*)p;
+        const T* e = (const T*)&raw;
+        v = make_float4(Elem<DT>::to_f32(e[0]), Elem<DT>::to_f32(e[1]), Elem<DT>::to_f32(e[2]), Elem<DT>::to_f32(e[3]));
+      }
+    } else {
+      float* f = (float*)&v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < width) f[j] = Elem<DT>::to_f32(p[j]);
+    }
+    return v;
+  };
+
+  int it = 0;
+  for (int r0 = rbeg; r0 < rend; r0 += R, ++it) {
+    const int buf = it & 1;
+    if (tid < R * B4) {   // out_grad tile -> LDS
+      const int row = tid / B4, c4 = tid % B4;
+      const int o = r0 + row;
+      *(float4*)&fb[buf][row * LDB + c4 * 4] = load4(gout, o < rend ? o : -1, cout, co0 + c4 * 4, vec_b);
+    }
+    int idx[KPW];   // neighbour rows of this wave's offsets for the tile's rows (lane & 31 = row)
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      const int k = w + kk * WG2_NW, o = r0 + (lane & 31);
+      idx[kk] = (k < K && o < rend) ? nbr[(size_t)k * nbr_stride + o] : -1;
+    }
+    __syncthreads();   // the tile's out_grad is in place; (double buffer: nobody still reads the buffer the NEXT tile overwrites)
+    float4 nx[NLD];
+    auto gather = [&](int kk) {
+#pragma unroll
+      for (int p = 0; p < NLD; ++p) {
+        const int e = p * 64 + lane, row = e / A4, c4 = e % A4;
+        const int src = __shfl(idx[kk], row, 64);
+        nx[p] = load4(feat, src, cin, ci0 + c4 * 4, vec_a);
+      }
+    };
+    gather(0);
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      const bool live = __ballot(idx[kk] >= 0) != 0ull;   // wave-uniform: some row of the tile has a neighbour at this offset
+      if (live) {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+          const int e = p * 64 + lane, row = e / A4, c4 = e % A4;
+          *(float4*)&fa[w][row * LDA + c4 * 4] = nx[p];
+        }
+      }
+      if (kk + 1 < KPW) gather(kk + 1);   // in flight under the MFMAs below
+      if (live) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is written (wave-private: no barrier)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) {
+          const int r = q * 4 + l4;
+          float a[CIT], b[COT];
+#pragma unroll
+          for (int t = 0; t < CIT; ++t) a[t] = fa[w][r * LDA + t * 16 + l15];
+#pragma unroll
+          for (int t = 0; t < COT; ++t) b[t] = fb[buf][r * LDB + t * 16 + l15];
+#pragma unroll
+          for (int ta = 0; ta < CIT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < COT; ++tb) acc[kk][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[kk][ta][tb], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next offset overwrites the tile
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  // D[i = ci][j = co]: lane holds column co = l15, rows ci = l4 * 4 + e of a tile
+#pragma unroll
+  for (int kk = 0; kk < KPW; ++kk) {
+    const int k = w + kk * WG2_NW;
+    if (k >= K) continue;
+    float* dst = part + ((size_t)s * K + k) * cinp_tot * coutp_tot;
+#pragma unroll
+    for (int ta = 0; ta < CIT; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < COT; ++tb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          dst[(size_t)(ci0 + ta * 16 + l4 * 4 + e) * coutp_tot + co0 + tb * 16 + l15] = acc[kk][ta][tb][e];
+  }
+}
+
+// The same row-tile-stationary filter gradient for 16-BIT features (fp16 / bf16: the reference's default training arithmetic,
+// configs/default.yaml fp16 -> autocast: half operands, fp32 accumulation) on v_mfma_f32_16x16x32_{f16,bf16}: one MFMA covers all
+// 32 rows of a tile (the fp32 flavour needs eight v_mfma_f32_16x16x4_f32 at half the rate each — it is bound by the fp32 MFMA
+// rate at 64 channels and above).  The reduction index of this GEMM is the ROW, but rows are what lie apart in memory: the
+// tiles stay row-major in LDS in their storage type (8-byte pieces, linear writes) and the operands are read with
+// ds_read_b64_tr_b16, the transposing LDS read — lane (c = l & 15, g = l >> 4) supplies the address of row 8g + (c >> 2), columns
+// 4 (c & 3) .. +3, and receives rows 8g .. 8g + 3 of column c (probed on the hardware: tools/ubench/tr16_probe.hip): two reads give
+// the 8 consecutive reduction elements of an A (X^T) or B (gY) fragment.  Products of 16-bit inputs are exact in fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(const s16x8& a, const s16x8& b, f32x4 acc) {
+  if constexpr (DT == DT_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+template <int DT, int CIT, int COT, int KPW>
+__global__ __launch_bounds__(256, 2) void spconv_wgrad16_kernel(const typename Elem<DT>::T* __restrict__ feat,
+                                                                const typename Elem<DT>::T* __restrict__ gout,
+                                                                const int* __restrict__ nbr, int nbr_stride, int m, int K,
+                                                                int cin, int cout, int cinp_tot, int coutp_tot,
+                                                                int rows_per_slab, float* __restrict__ part) {
+  static_assert(DT == DT_F16 || DT == DT_BF16, "16-bit features");
+  typedef uint16_t H;   // raw 16-bit storage
+  constexpr int R = WG2_R, CIB = CIT * 16, COB = COT * 16;
+  constexpr int A8 = CIB / 8, B8 = COB / 8;          // 16-byte (8-element) pieces per row
+  constexpr int NLD = (R * A8 + 63) / 64;            // gathered pieces per lane and offset (R * A8 = 64 | 128)
+  static_assert(R * A8 % 64 == 0, "whole wave instructions");
+  __shared__ __attribute__((aligned(16))) H fb[2][R * COB];
+  __shared__ __attribute__((aligned(16))) H fa[WG2_NW][R * CIB];
+  const H* featb = (const H*)feat;
+  const H* goutb = (const H*)gout;
+  const int s = blockIdx.x, ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
+  const int rbeg = s * rows_per_slab;
+  const int rend = rbeg + rows_per_slab < m ? rbeg + rows_per_slab : m;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool vec_a = (cin & 7) == 0, vec_b = (cout & 7) == 0;
+  f32x4 acc[KPW][CIT][COT];
+#pragma unroll
+  for (int kk = 0; kk < KPW; ++kk)
+#pragma unroll
+    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+      for (int b = 0; b < COT; ++b) acc[kk][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // 8 consecutive 16-bit elements starting at channel c of row `row` (zeros past `width` / for row < 0), as stored
+  auto load8 = [&](const H* base, int row, int width, int c, bool vec) -> uint4 {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < 0 || c >= width) return v;
+    const H* p = base + (size_t)row * width + c;
+    if (vec) {
+      v = *(const uint4*)p;
+    } else {
+      H* e = (H*)&v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c + j < width) e[j] = p[j];
+    }
+    return v;
+  };
+  // fragment of a 16-column tile starting at column c0 of a row-major [R][PITCH] tile: rows 8*l4 .. 8*l4 + 7 of column c0 + l15
+  auto frag = [&](const H* tile, int pitch, int c0) -> s16x8 {
+    const H* p = tile + (l4 * 8 + (l15 >> 2)) * pitch + c0 + (l15 & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * pitch));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  // Everything a tile needs from memory is requested ONE TILE AHEAD: the neighbour rows of this wave's offsets, the gathered
+  // pieces of all its KPW offsets (registers nx), the out_grad piece of this thread.  A piece register is refilled for the next
+  // tile as soon as it has been written to LDS, so the gathers of tile t+1 are in flight under the MFMAs of tile t and a wave
+  // exposes one memory round trip per slab, not one per (tile, offset).
+  auto load_idx = [&](int r0, int (&ix)[KPW]) {
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      const int k = w + kk * WG2_NW, o = r0 + (lane & 31);
+      ix[kk] = (k < K && o < rend) ? nbr[(size_t)k * nbr_stride + o] : -1;
+    }
+  };
+  auto gather = [&](int ixk, uint4 (&dst)[NLD]) {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      const int e = p * 64 + lane, row = e / A8, c8 = e % A8;
+      const int src = __shfl(ixk, row, 64);
+      dst[p] = load8(featb, src, cin, ci0 + c8 * 8, vec_a);
+    }
+  };
+  auto load_gy = [&](int r0) -> uint4 {
+    if (tid >= R * B8) return make_uint4(0u, 0u, 0u, 0u);
+    const int row = tid / B8, c8 = tid % B8, o = r0 + row;
+    return load8(goutb, o < rend ? o : -1, cout, co0 + c8 * 8, vec_b);
+  };
+
+  int idx[KPW], idx_next[KPW];
+  uint4 nx[KPW][NLD];
+  load_idx(rbeg, idx);
+  uint4 gy = load_gy(rbeg);
+#pragma unroll
+  for (int kk = 0; kk < KPW; ++kk) gather(idx[kk], nx[kk]);
+  int it = 0;
+  for (int r0 = rbeg; r0 < rend; r0 += R, ++it) {
+    const int buf = it & 1;
+    load_idx(r0 + R, idx_next);                         // rows past the slab give -1: the refills below become no-ops
+    if (tid < R * B8) *(uint4*)&fb[buf][(tid / B8) * COB + (tid % B8) * 8] = gy;
+    gy = load_gy(r0 + R);
+    __syncthreads();   // the tile's out_grad is in place (double buffer: nobody still reads the buffer the NEXT tile overwrites)
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      const bool live = __ballot(idx[kk] >= 0) != 0ull;   // wave-uniform
+      if (live) {
+#pragma unroll
+        for (int p = 0; p < NLD; ++p) {
+          const int e = p * 64 + lane, row = e / A8, c8 = e % A8;
+          *(uint4*)&fa[w][row * CIB + c8 * 8] = nx[kk][p];
+        }
+      }
+      gather(idx_next[kk], nx[kk]);   // tile t+1, in flight under everything below
+      if (live) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is written (wave-private: no barrier)
+        __builtin_amdgcn_wave_barrier();
+        s16x8 a[CIT], b[COT];
+#pragma unroll
+        for (int t = 0; t < CIT; ++t) a[t] = frag(fa[w], CIB, t * 16);
+#pragma unroll
+        for (int t = 0; t < COT; ++t) b[t] = frag(fb[buf], COB, t * 16);
+#pragma unroll
+        for (int ta = 0; ta < CIT; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < COT; ++tb) acc[kk][ta][tb] = mfma16<DT>(a[ta], b[tb], acc[kk][ta][tb]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next offset overwrites the tile
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) idx[kk] = idx_next[kk];
+  }
+#pragma unroll
+  for (int kk = 0; kk < KPW; ++kk) {
+    const int k = w + kk * WG2_NW;
+    if (k >= K) continue;
+    float* dst = part + ((size_t)s * K + k) * cinp_tot * coutp_tot;
+#pragma unroll
+    for (int ta = 0; ta < CIT; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < COT; ++tb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          dst[(size_t)(ci0 + ta * 16 + l4 * 4 + e) * coutp_tot + co0 + tb * 16 + l15] = acc[kk][ta][tb][e];
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void spconv_wgrad_reduce_kernel(const float* __restrict__ part, int nslabs, int K, int cin,
                                                                   int cout, int cin_pad, int cout_pad,
@@ -396,8 +691,28 @@ int bevamd_spconv_conv_forward(const void* features, int dtype, const void* prep
 /* filter_grad [K, cin, cout] (same dtype as features) = sum over the rulebook of features^T @ out_grad
  * (sparse_conv_ext.indice_conv_backward_*'s filter half, spconv_ops.h:363-456).  nbr is the FORWARD table (nbr[k][o] = input
  * row).  MFMA (exact fp32), no atomics, bit-reproducible.  ws: WG_MAX_SLABS * K * cin_pad * cout_pad fp32 slab partials. */
+// geometry of the row-tile-stationary filter gradient for (K, cin, cout): channel blocks, padded widths, most slabs it will use
+struct Wgrad2Plan { int cit, cot, nci, nco, cinp, coutp, kpw, max_slabs; };
+static bool wgrad2_plan(int K, int cin, int cout, Wgrad2Plan& p) {
+  if (K > 7 * WG2_NW || cin > 128 || cout > 128) return false;
+  p.cit = cin <= 16 ? 1 : 2;
+  p.cot = cout <= 16 ? 1 : 2;
+  p.nci = (cin + p.cit * 16 - 1) / (p.cit * 16);
+  p.nco = (cout + p.cot * 16 - 1) / (p.cot * 16);
+  p.cinp = p.nci * p.cit * 16;
+  p.coutp = p.nco * p.cot * 16;
+  const int need = (K + WG2_NW - 1) / WG2_NW;
+  p.kpw = need <= 1 ? 1 : need <= 2 ? 2 : 7;
+  int sl = WG2_TARGET_WGS / (p.nci * p.nco);
+  p.max_slabs = sl < 1 ? 1 : sl > WG2_MAX_SLABS ? WG2_MAX_SLABS : sl;
+  return true;
+}
+
 size_t bevamd_spconv_wgrad_workspace_bytes(int kernel_volume, int cin, int cout) {
   if (kernel_volume <= 0 || cin <= 0 || cout <= 0 || cin > 128 || cout > 128) return 0;
+  Wgrad2Plan p;
+  if (wgrad2_plan(kernel_volume, cin, cout, p))
+    return align_up((size_t)p.max_slabs * kernel_volume * p.cinp * p.coutp * sizeof(float), 256);
   const int cit = (cin + 15) / 16, cinp = (cit <= 1 ? 1 : cit <= 2 ? 2 : cit <= 4 ? 4 : 8) * 16;
   const int coutp = (cout + 15) / 16 * 16;
   return align_up((size_t)WG_MAX_SLABS * kernel_volume * cinp * coutp * sizeof(float), 256);
@@ -420,6 +735,63 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
   if (!ws || ws_bytes < bevamd_spconv_wgrad_workspace_bytes(kernel_volume, cin, cout)) {
     set_error("spconv_conv_wgrad: workspace too small");
     return BEVAMD_ERR_WORKSPACE;
+  }
+  Wgrad2Plan wp;
+  if (wgrad2_plan(kernel_volume, cin, cout, wp)) {
+    // row-tile-stationary kernel: slabs of whole 32-row tiles, ~768 workgroups over (slab, ci block, co block)
+    int nslabs = (num_out + 4 * WG2_R - 1) / (4 * WG2_R);   // at least 4 tiles per slab
+    if (nslabs > wp.max_slabs) nslabs = wp.max_slabs;
+    if (nslabs < 1) nslabs = 1;
+    int rows_per_slab = ((num_out + nslabs - 1) / nslabs + WG2_R - 1) / WG2_R * WG2_R;
+    nslabs = (num_out + rows_per_slab - 1) / rows_per_slab;
+    float* part = (float*)ws;
+    dim3 grid(nslabs, wp.nci, wp.nco), block(256);
+#define BEVAMD_WG2(DT, T, CIT, COT, KPW) \
+  spconv_wgrad2_kernel<DT, CIT, COT, KPW><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
+                                                                      kernel_volume, cin, cout, wp.cinp, wp.coutp, rows_per_slab, part)
+#define BEVAMD_WG2_K(DT, T, CIT, COT)                                                          \
+  do {                                                                                        \
+    if (wp.kpw == 1) BEVAMD_WG2(DT, T, CIT, COT, 1); else if (wp.kpw == 2) BEVAMD_WG2(DT, T, CIT, COT, 2); \
+    else BEVAMD_WG2(DT, T, CIT, COT, 7);                                                      \
+  } while (0)
+#define BEVAMD_WG2_C(DT, T)                                                                    \
+  do {                                                                                        \
+    if (wp.cit == 1 && wp.cot == 1) BEVAMD_WG2_K(DT, T, 1, 1);                                \
+    else if (wp.cit == 1) BEVAMD_WG2_K(DT, T, 1, 2);                                          \
+    else if (wp.cot == 1) BEVAMD_WG2_K(DT, T, 2, 1);                                          \
+    else BEVAMD_WG2_K(DT, T, 2, 2);                                                           \
+  } while (0)
+#define BEVAMD_WG16(DT, T, CIT, COT, KPW) \
+  spconv_wgrad16_kernel<DT, CIT, COT, KPW><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
+                                                                       kernel_volume, cin, cout, wp.cinp, wp.coutp, rows_per_slab, part)
+#define BEVAMD_WG16_K(DT, T, CIT, COT)                                                         \
+  do {                                                                                        \
+    if (wp.kpw == 1) BEVAMD_WG16(DT, T, CIT, COT, 1); else if (wp.kpw == 2) BEVAMD_WG16(DT, T, CIT, COT, 2); \
+    else BEVAMD_WG16(DT, T, CIT, COT, 7);                                                     \
+  } while (0)
+#define BEVAMD_WG16_C(DT, T)                                                                   \
+  do {                                                                                        \
+    if (wp.cit == 1 && wp.cot == 1) BEVAMD_WG16_K(DT, T, 1, 1);                               \
+    else if (wp.cit == 1) BEVAMD_WG16_K(DT, T, 1, 2);                                         \
+    else if (wp.cot == 1) BEVAMD_WG16_K(DT, T, 2, 1);                                         \
+    else BEVAMD_WG16_K(DT, T, 2, 2);                                                          \
+  } while (0)
+    if (dtype == DT_F32) BEVAMD_WG2_C(DT_F32, float);
+    else if (dtype == DT_F16) BEVAMD_WG16_C(DT_F16, _Float16);
+    else BEVAMD_WG16_C(DT_BF16, uint16_t);
+#undef BEVAMD_WG16_C
+#undef BEVAMD_WG16_K
+#undef BEVAMD_WG16
+#undef BEVAMD_WG2_C
+#undef BEVAMD_WG2_K
+#undef BEVAMD_WG2
+    BEVAMD_LAUNCH_CHECK("spconv_wgrad2");
+    dim3 rgrid2((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048));
+    if (dtype == DT_F32) spconv_wgrad_reduce_kernel<DT_F32><<<rgrid2, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (float*)filter_grad);
+    else if (dtype == DT_F16) spconv_wgrad_reduce_kernel<DT_F16><<<rgrid2, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (_Float16*)filter_grad);
+    else spconv_wgrad_reduce_kernel<DT_BF16><<<rgrid2, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (uint16_t*)filter_grad);
+    BEVAMD_LAUNCH_CHECK("spconv_wgrad_reduce");
+    return BEVAMD_OK;
   }
   const int cit0 = (cin + 15) / 16, cit = cit0 <= 1 ? 1 : cit0 <= 2 ? 2 : cit0 <= 4 ? 4 : 8;
   const int cinp = cit * 16, coutp = (cout + 15) / 16 * 16;
