@@ -34,6 +34,7 @@ _SIGNATURES = {
     "bevamd_bev_pool_cell_of_point": (I, [P, P, I, P, P]),
     "bevamd_bev_pool_fused_backward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_backward_points": (I, [P, P, P, I, I, I, I, I, I, P]),
     # view-transform glue
     "bevamd_depth_raster_workspace_bytes": (Z, [I, I, I]),
     "bevamd_depth_raster": (I, [P, I, I, P, P, P, P, I, I, I, P, P, Z, P]),

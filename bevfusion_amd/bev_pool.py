@@ -9,11 +9,16 @@ MI355X-native additions: `BevPoolPlan` (the rank/sort/interval precompute as a c
 sync-free device object) and the indexed kernels that read features through the sort
 permutation instead of materialising `feats[indices]`.
 """
+import os
+
 import torch
 
 from . import _capi
 
 __all__ = ["bev_pool", "bev_pool_ext", "QuickCumsumCuda", "BevPoolPlan"]
+
+
+_BWD_POINTS = os.environ.get("BEVAMD_BEV_POOL_BWD_POINTS", "1") != "0"   # 0: the row-parallel backward (sorted-row order)
 
 
 def _require_cuda(t, name):
@@ -272,6 +277,14 @@ class BevPoolPlan:
         lib = _capi.load()
         out_grad = out_grad.contiguous().float()
         x_grad = torch.empty((self.n, c), dtype=torch.float32, device=out_grad.device)
+        if c % 4 == 0 and _BWD_POINTS:
+            # point-order walk: a streaming write of x_grad, the gather is on the (cached) cell gradients
+            cop = self.cell_of_point()
+            with torch.cuda.device(out_grad.device):
+                rc = lib.bevamd_bev_pool_backward_points(_capi.ptr(out_grad), _capi.ptr(cop), _capi.ptr(x_grad), self.n, c,
+                                                         self.B, self.D, self.H, self.W, _capi.stream_ptr(out_grad.device))
+            _capi.check(rc, "bev_pool_backward_points")
+            return x_grad
         with torch.cuda.device(out_grad.device):
             rc = lib.bevamd_bev_pool_backward_rows(
                 _capi.ptr(out_grad), _capi.ptr(self.order), _capi.ptr(self.ranks_sorted), _capi.ptr(x_grad),

@@ -332,6 +332,45 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_rows_vec_kernel(
   x_grad[(size_t)order[j] * lpr + cv] = gval;
 }
 
+// The same gradient walked in POINT order: x_grad[i] = out_grad[cell(i)], cell(i) from the plan's cell_of_point (the rank of every
+// frustum point in point order, static per plan).  The row-parallel kernel above writes each 320-byte row where the sort put it —
+// 2.5 cache lines at a scattered address, half lines left to merge in L2 (measured 2.5-2.6 TB/s = 0.31-0.32 of the HBM peak for
+// what is a pure streaming write).  Here consecutive threads write consecutive 16-byte pieces of x_grad — whole lines, in address
+// order — and the scattered side is the READ of out_grad (41.5 MB per frame: it lives in L2 / Infinity Cache).  Four pieces per
+// thread in flight (index -> gradient -> store chains are independent).
+__global__ __launch_bounds__(256) void bev_pool_bwd_points_vec_kernel(const float* __restrict__ out_grad,
+                                                                      const uint32_t* __restrict__ cell_of_point,
+                                                                      uint32_t ncells, size_t total4, int lpr,
+                                                                      float4* __restrict__ x_grad, BevDims s) {
+  constexpr int U = 4;
+  const size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+  uint32_t r[U];
+  int cv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t e = base + (size_t)u * 256;
+    const size_t i = e / (unsigned)lpr;
+    cv[u] = (int)(e - i * (unsigned)lpr);
+    r[u] = e < total4 ? cell_of_point[i] : 0xFFFFFFFFu;
+  }
+  float4 g[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r[u] < ncells) {
+      int gx, gy, gz, gb;
+      decode_rank(r[u], s, gx, gy, gz, gb);
+      g[u] = *(const float4*)(out_grad + cell_offset(gx, gy, gz, gb, s) + (size_t)cv[u] * 4);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t e = base + (size_t)u * 256;
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
+    if (e < total4) __builtin_nontemporal_store(f32x4n{g[u].x, g[u].y, g[u].z, g[u].w}, (f32x4n*)&x_grad[e]);
+  }
+}
+
 __global__ __launch_bounds__(256) void bev_pool_bwd_rows_scalar_kernel(
     const float* __restrict__ out_grad, const uint32_t* __restrict__ order,
     const uint32_t* __restrict__ ranks_sorted, uint32_t ncells, int n, float* __restrict__ x_grad, BevDims s) {
@@ -722,6 +761,26 @@ int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint
 int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* order, const uint32_t* cell_start,
                                   float* out, int n, int c, int b, int d, int h, int w, void* stream_) {
   return bevamd_bev_pool_forward_cells_tuned(x, x_is_bf16, order, cell_start, out, n, c, b, d, h, w, 0, stream_);
+}
+
+int bevamd_bev_pool_backward_points(const float* out_grad, const uint32_t* cell_of_point, float* x_grad, int n, int c, int b,
+                                    int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_dims(n, c, b, d, h, w);
+  if (rc) return rc;
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(out_grad && cell_of_point && x_grad, "bev_pool_backward_points: null buffer");
+  BEVAMD_REQUIRE(vec_path_ok(c, 4, out_grad, x_grad), "bev_pool_backward_points: c=%d must be a multiple of 4 with 16-byte aligned buffers (use bevamd_bev_pool_backward_rows otherwise)", c);
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  BevDims s{b, d, h, w, c};
+  const int lpr = c / 4;
+  const size_t total4 = (size_t)n * lpr;
+  const size_t blocks = (total4 + 1023) / 1024;
+  BEVAMD_REQUIRE(blocks < 0x7FFFFFFFull, "bev_pool_backward_points: too many rows");
+  bev_pool_bwd_points_vec_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(out_grad, cell_of_point, ncells, total4, lpr,
+                                                                                   (float4*)x_grad, s);
+  BEVAMD_LAUNCH_CHECK("bev_pool_bwd_points");
+  return BEVAMD_OK;
 }
 
 int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order, const uint32_t* ranks_sorted,

@@ -151,6 +151,13 @@ int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint
                                         const uint32_t* cell_start, float* out, int n, int c, int b,
                                         int d, int h, int w, int variant, void* stream);
 
+/* The same gradient written in POINT order (x_grad[i] = out_grad[cell of point i], zeros for dropped points): consecutive
+ * 16-byte pieces of x_grad by consecutive threads — a streaming write — with the scattered side on the cached out_grad reads.
+ * cell_of_point [n] comes from bevamd_bev_pool_cell_of_point (static per plan).  c % 4 == 0, 16-byte aligned buffers.
+ * Same values as bevamd_bev_pool_backward_rows / bev_pool_ext.bev_pool_backward (bev_pool_cuda.cu:61-84), bit for bit. */
+int bevamd_bev_pool_backward_points(const float* out_grad, const uint32_t* cell_of_point, float* x_grad, int n, int c, int b,
+                                    int d, int h, int w, void* stream);
+
 /* Native backward (row-parallel): x_grad[order[j], :] = out_grad[cell(ranks_sorted[j]), :],
  * zeros for dropped rows.  Every row of x_grad [n,c] is written once. */
 int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order,
