@@ -220,6 +220,25 @@ def dry_run_train(args, rank, world, frame_ids):
             "dry_run": True}), flush=True)
 
 
+def stored_layer_profile():
+    """Per-layer counter figures of the 21 convolutions from the newest committed rocprofv3 run (profiles/rNN_spconv_layers.json,
+    written by tools/spconv_layers_profile.py): in-graph microseconds from a kernel trace of the replayed step, HBM bytes from the
+    FETCH_SIZE / WRITE_SIZE passes next to the ideal and metadata bytes, L2 hit rate, MFMA busy.  A stored profile of an
+    8-frame step, not measured inside this run."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_spconv_layers.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            prof = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    prof["source"] = os.path.join("profiles", os.path.basename(files[-1])) + " (stored profile, not measured in this run)"
+    return prof
+
+
 def make_encoder(cfg, dev, dtype):
     from bevfusion_amd.sparse_encoder import SparseEncoder
 
@@ -656,6 +675,7 @@ def main():
                     "The op is neither: rows live in L2 and 133 GFLOP/frame is < 0.1 ms of MFMA — fractions are for orientation.",
             "total_us": tot_us, "total_gflop": tot_gf, "tflops": tot_gf * 1e3 / tot_us, "frac_mfma_peak": tot_gf * 1e3 / tot_us / 2500.0,
             "layers": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in l.items()} for l in layers],
+            "stored_profile": stored_layer_profile(),
         }
 
     overlap_head = args.overlap == "head" and sp_dtype != torch.float32 and not args.no_graph
