@@ -31,6 +31,9 @@ _SIGNATURES = {
     "bevamd_bev_pool_forward_cells": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_forward_cells_tuned": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_fused_forward": (I, [P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_fused_schedule_workspace_bytes": (Z, [I]),
+    "bevamd_bev_pool_fused_schedule": (I, [P, P, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
+    "bevamd_bev_pool_fused_forward_scheduled": (I, [P, P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_cell_of_point": (I, [P, P, I, P, P]),
     "bevamd_bev_pool_fused_backward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),

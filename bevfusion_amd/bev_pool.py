@@ -18,6 +18,7 @@ from . import _capi
 __all__ = ["bev_pool", "bev_pool_ext", "QuickCumsumCuda", "BevPoolPlan"]
 
 
+_FUSED_SCHEDULE = os.environ.get("BEVAMD_FUSED_POOL_SCHEDULE", "1") != "0"   # 0: frame-major walk over all XCDs
 _BWD_POINTS = os.environ.get("BEVAMD_BEV_POOL_BWD_POINTS", "1") != "0"   # 0: the row-parallel backward (sorted-row order)
 
 
@@ -122,6 +123,7 @@ class BevPoolPlan:
         self.cell_start = torch.empty(self.ncells + 2, dtype=torch.int32, device=device)
         self.interval_starts = self.interval_lengths = self.n_intervals_dev = self.geom_sorted = None
         self._cell_of_point = None   # rank per frustum point in point order (built on first fused backward)
+        self._fused_sched = {}       # (depth_bins, fh, fw) -> (perm, xcd_start): camera-sector walk of the fused pooling
         if want_intervals:
             cap = max(min(self.n, self.ncells), 1)
             self.interval_starts = torch.empty(cap, dtype=torch.int32, device=device)
@@ -233,12 +235,38 @@ class BevPoolPlan:
             raise RuntimeError("ctx rows x depth_bins must equal the number of frustum points of the plan")
         if out is None:
             out = torch.empty((self.B, self.D, self.H, self.W, c), dtype=torch.float32, device=ctx.device)
+        sched = self.fused_schedule(depth_bins, fh, fw) if _FUSED_SCHEDULE and self.n > 0 else None
         with torch.cuda.device(ctx.device):
-            rc = lib.bevamd_bev_pool_fused_forward(
-                _capi.ptr(depth), _capi.ptr(ctx), is_bf16, _capi.ptr(self.order), _capi.ptr(self.cell_start), _capi.ptr(out),
-                self.n, c, int(depth_bins), int(fh), int(fw), self.B, self.D, self.H, self.W, _capi.stream_ptr(ctx.device))
+            if sched is not None:
+                rc = lib.bevamd_bev_pool_fused_forward_scheduled(
+                    _capi.ptr(depth), _capi.ptr(ctx), is_bf16, _capi.ptr(self.order), _capi.ptr(self.cell_start),
+                    _capi.ptr(sched[0]), _capi.ptr(sched[1]), _capi.ptr(out), self.n, c, int(depth_bins), int(fh), int(fw),
+                    self.B, self.D, self.H, self.W, _capi.stream_ptr(ctx.device))
+            else:
+                rc = lib.bevamd_bev_pool_fused_forward(
+                    _capi.ptr(depth), _capi.ptr(ctx), is_bf16, _capi.ptr(self.order), _capi.ptr(self.cell_start), _capi.ptr(out),
+                    self.n, c, int(depth_bins), int(fh), int(fw), self.B, self.D, self.H, self.W, _capi.stream_ptr(ctx.device))
         _capi.check(rc, "bev_pool_fused_forward")
         return out
+
+    def fused_schedule(self, depth_bins, fh, fw):
+        """(perm, xcd_start) of the fused pooling's camera-sector walk for this plan (csrc/bev_pool_fused.hip): built once per
+        (plan, frustum shape) on the device — one radix sort of the cells — and cached; static per calibration like the plan."""
+        key = (int(depth_bins), int(fh), int(fw))
+        if key not in self._fused_sched:
+            lib = _capi.load()
+            ncells = self.B * self.D * self.H * self.W
+            perm = torch.empty(ncells, dtype=torch.int32, device=self.device)
+            cuts = torch.empty(9, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                wsb = lib.bevamd_bev_pool_fused_schedule_workspace_bytes(ncells)
+                ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=self.device)
+                rc = lib.bevamd_bev_pool_fused_schedule(_capi.ptr(self.order), _capi.ptr(self.cell_start), self.n, key[0], key[1],
+                                                        key[2], self.B, self.D, self.H, self.W, _capi.ptr(perm), _capi.ptr(cuts),
+                                                        _capi.ptr(ws), wsb, _capi.stream_ptr(self.device))
+            _capi.check(rc, "bev_pool_fused_schedule")
+            self._fused_sched[key] = (perm, cuts)
+        return self._fused_sched[key]
 
     def cell_of_point(self):
         if self._cell_of_point is None:

@@ -136,6 +136,20 @@ int bevamd_bev_pool_fused_forward(const float* depth, const void* ctx, int ctx_i
                                   const uint32_t* cell_start, float* out, int n, int c, int depth_bins, int fh,
                                   int fw, int b, int d, int h, int w, void* stream);
 
+/* Camera-sector schedule of the fused pooling (static per plan): perm [b*d*h*w] orders the cells by (frame, camera of the
+ * cell's first point, cell), xcd_start [9] cuts that order into 8 chunks of equal work; bevamd_bev_pool_fused_forward_scheduled
+ * walks chunk x on XCD x, so an XCD reads about one camera's context rows at a time (its own L2 holds them) instead of
+ * sweeping the whole BEV.  Same per-cell summation order: bit-identical to bevamd_bev_pool_fused_forward. */
+size_t bevamd_bev_pool_fused_schedule_workspace_bytes(int ncells);
+int bevamd_bev_pool_fused_schedule(const uint32_t* order, const uint32_t* cell_start, int n, int depth_bins, int fh, int fw,
+                                   int b, int d, int h, int w, uint32_t* perm, uint32_t* xcd_start, void* ws, size_t ws_bytes,
+                                   void* stream);
+int bevamd_bev_pool_fused_forward_scheduled(const float* depth, const void* ctx, int ctx_is_bf16, const uint32_t* order,
+                                            const uint32_t* cell_start, const uint32_t* perm, const uint32_t* xcd_start,
+                                            float* out, int n, int c, int depth_bins, int fh, int fw, int b, int d, int h, int w,
+                                            void* stream);
+
+
 /* Backward of the fused op (fp32 context): d_depth [n] = sum_c out_grad[cell(p), c] * ctx[pixel(p), c] (0 for dropped
  * points), d_ctx [cams*fh*fw, c] = sum over the depth bins of a pixel of depth[p] * out_grad[cell(p), :]; both fully
  * written, no atomics.  cell_of_point [n] (rank per point in POINT order) comes from bevamd_bev_pool_cell_of_point. */

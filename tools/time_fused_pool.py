@@ -1,0 +1,31 @@
+"""Fused depth (x) context pooling: scheduled vs frame-major walk, B flagship frames: tools/time_fused_pool.py [B]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bevfusion_amd import synth, bev_pool as bp
+from bevfusion_amd.bev_pool import BevPoolPlan
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device("cuda:0")
+cfg = synth.CL_CONFIG
+inp = synth.bev_pool_inputs(cfg, batch=B, seed=0, with_feats=False)
+H, W, D = (int(v) for v in inp["nx"]); C = inp["channels"]
+plan = BevPoolPlan.from_geometry(torch.from_numpy(inp["geom"]).to(dev), B, inp["origin"], inp["dx"], inp["nx"])
+fh, fw = cfg["feature_size"]; ncam = cfg["num_cameras"]
+dbins = plan.n // (B * ncam * fh * fw)
+g = torch.Generator(device=dev).manual_seed(1)
+depth = torch.softmax(torch.randn((B * ncam, dbins, fh, fw), generator=g, device=dev), 1).reshape(-1)
+ctx = torch.randn((B * ncam * fh * fw, C), generator=g, device=dev)
+outs = {}
+for name, flag in (("frame-major", False), ("scheduled", True)):
+    bp._FUSED_SCHEDULE = flag
+    for _ in range(3): o = plan.launch_fused(depth, ctx, dbins, fh, fw)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(30): o = plan.launch_fused(depth, ctx, dbins, fh, fw)
+    b.record(); b.synchronize()
+    outs[name] = o.clone()
+    print(f"{name}: {a.elapsed_time(b)/30*1e3:.1f} us per {B} frames = {a.elapsed_time(b)/30*1e3/B:.1f} us/frame")
+print("bit-identical:", torch.equal(outs["frame-major"], outs["scheduled"]))
+perm, cuts = plan.fused_schedule(dbins, fh, fw)
+print("chunk boundaries:", cuts.tolist())
