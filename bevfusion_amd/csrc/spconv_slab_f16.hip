@@ -113,6 +113,7 @@ int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_st
   BEVAMD_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "spconv_conv_forward_slab: scale and shift go together");
   slab::SlabArgs sa;
   tile::Args& a = sa.a;
+  a.hdr = nullptr; a.slots = nullptr; a.slab_rows = 0;   // (the slab kernels read sa.hdr / sa.slots)
   a.feat = features; a.wimg = image; a.nbr = nullptr; a.m_dev = num_out_dev; a.out = out;
   a.bias = bias; a.scale = bn_scale; a.shift = bn_shift; a.residual = residual;
   a.feat_stride = feat_stride; a.n_in = num_in; a.nbr_stride = 0; a.m_cap = num_out; a.K = 27;

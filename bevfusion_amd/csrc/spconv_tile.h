@@ -83,6 +83,12 @@ struct Args {
   // dense tail (optional): out_dense[b][c*dz + z][x][y] = value, rows addressed through out_indices
   int feat_stride, n_in, nbr_stride, m_cap, K, cout, out_stride, res_stride, relu;
   int row_epilogue;  // 1: cout, pitches and pointers allow the LDS-transposed 16-byte epilogue (set by the host)
+  // optional: the rulebook as slab metadata instead of the int32 table (nbr == nullptr): per block of slab_rows output rows and
+  // kernel plane kx the first input row (hdr[blk*3 + kx].x) and 16-bit slots relative to it ([blk][27][slab_rows], 0xFFFF = none)
+  // — half the bytes of the table, built by sorted-key search without clearing / scattering one (spconv_indice.hip).  K = 27.
+  const int2* hdr;
+  const uint16_t* slots;
+  int slab_rows;
 };
 
 constexpr unsigned OOB = 0x80000000u;  // buffer offset that is always out of range (feature bytes < 2 GiB)
@@ -220,6 +226,30 @@ struct WaveTile {
     }
     constexpr int R = 16 * MT, UNR = 8;
     const int total = a.K * R;
+    if (a.nbr == nullptr) {   // slot metadata: a tile never straddles a block (slab_rows % R == 0, checked by the host)
+      const int blk = row0 / a.slab_rows, t0 = row0 - blk * a.slab_rows;
+      const int lo0 = a.hdr[(size_t)blk * 3 + 0].x, lo1 = a.hdr[(size_t)blk * 3 + 1].x, lo2 = a.hdr[(size_t)blk * 3 + 2].x;
+      const uint16_t* sl = a.slots + (size_t)blk * 27 * a.slab_rows + t0;
+      for (int base = 0; base < total; base += 64 * UNR) {
+        unsigned v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          int idx = base + u * 64 + lane;
+          idx = idx < total ? idx : total - 1;
+          const int k = idx / R, r = idx - k * R;
+          v[u] = row0 + r < m ? (unsigned)sl[(size_t)k * a.slab_rows + r] : 0xFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int idx = base + u * 64 + lane;
+          if (idx < total) {
+            const int k = idx / R;
+            nbl[idx] = v[u] == 0xFFFFu ? -1 : (k < 9 ? lo0 : k < 18 ? lo1 : lo2) + (int)v[u];
+          }
+        }
+      }
+      return;
+    }
     for (int base = 0; base < total; base += 64 * UNR) {
       int v[UNR];
 #pragma unroll

@@ -12,6 +12,21 @@ int image_f16(const void* w, int K, int cin, int cout, int transpose_io, void* i
 }  // namespace tile
 }  // namespace bevamd
 
+namespace bevamd {
+// dst [n, pitch] 16-bit = src [n, c] fp32 rounded, zero padded to the pitch the tiled kernels read: one launch instead of
+// zeros + strided copy-cast (two torch kernels in front of the encoder's first convolution)
+template <int DT>
+__global__ __launch_bounds__(256) void sp_pad_cast_rows_kernel(const float* __restrict__ src, int n, int c, int pitch,
+                                                               typename tile::Num<DT>::T* __restrict__ dst) {
+  const size_t total = (size_t)n * pitch;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / pitch;
+    const int col = (int)(i - row * pitch);
+    dst[i] = tile::Num<DT>::from_f32(col < c ? src[row * c + col] : 0.f);
+  }
+}
+}  // namespace bevamd
+
 using namespace bevamd;
 
 extern "C" {
@@ -61,6 +76,7 @@ int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_s
   BEVAMD_REQUIRE(out_stride >= cout && (!residual || residual_stride >= cout), "spconv_conv_forward_tiled: bad output pitch");
   BEVAMD_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "spconv_conv_forward_tiled: scale and shift go together");
   tile::Args a;
+  a.hdr = nullptr; a.slots = nullptr; a.slab_rows = 0;
   a.feat = features; a.wimg = image; a.nbr = nbr; a.m_dev = num_out_dev; a.out = out;
   a.bias = bias; a.scale = bn_scale; a.shift = bn_shift; a.residual = residual;
   a.feat_stride = feat_stride; a.n_in = num_in; a.nbr_stride = nbr_stride; a.m_cap = num_out; a.K = kernel_volume;
@@ -70,6 +86,61 @@ int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_s
                    (!residual || (residual_stride % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
                    (!bias || ((uintptr_t)bias & 15) == 0) && (!bn_scale || (((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0);
   return dtype == tile::T_F16 ? tile::launch_f16(a, cinp, nt, variant, stream) : tile::launch_bf16(a, cinp, nt, variant, stream);
+}
+
+/* bevamd_spconv_conv_forward_tiled for a 3x3x3 convolution whose rulebook is given as slab metadata (hdr / slots of
+ * bevamd_spconv_slab_build*, block_rows = 128 | 256) instead of the int32 neighbour table: the gather kernels decode
+ * `first row of the plane + 16-bit slot` while they load a tile's table into LDS.  Same kernels, same results; half the rulebook
+ * bytes, and no table has to be cleared and scattered first (the strided 32->64 / 64->128 layers of the SparseEncoder, whose input
+ * ranges are too long for the staged-rows kernels). */
+int bevamd_spconv_conv_forward_tiled_slots(const void* features, int dtype, int feat_stride, int num_in, const void* image,
+                                           const void* hdr, const void* slots, int block_rows, int num_out,
+                                           const int* num_out_dev, int cin, int cout, void* out, int out_stride,
+                                           const void* bias, const float* bn_scale, const float* bn_shift, const void* residual,
+                                           int residual_stride, int relu, int variant, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype == tile::T_F16 || dtype == tile::T_BF16, "spconv_conv_forward_tiled_slots: dtype %d is not 16-bit", dtype);
+  BEVAMD_REQUIRE(cin > 0 && cout > 0 && num_out >= 0 && num_in >= 0, "spconv_conv_forward_tiled_slots: bad sizes");
+  BEVAMD_REQUIRE(block_rows == 128 || block_rows == 256, "spconv_conv_forward_tiled_slots: block_rows %d (128 | 256)", block_rows);
+  if (num_out == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(features && image && hdr && slots && out, "spconv_conv_forward_tiled_slots: null buffer");
+  const int cinp = tile::pad_cin(cin), nt = tile::pad_nt(cout);
+  BEVAMD_REQUIRE(cinp && nt, "spconv_conv_forward_tiled_slots: channels %d -> %d exceed 128", cin, cout);
+  BEVAMD_REQUIRE(feat_stride >= cinp && feat_stride % 8 == 0 && ((uintptr_t)features & 15) == 0,
+                 "spconv_conv_forward_tiled_slots: feature pitch %d must be a multiple of 8 and >= %d (zero-padded), 16-byte aligned",
+                 feat_stride, cinp);
+  BEVAMD_REQUIRE((unsigned long long)num_in * feat_stride * 2ull < 0x80000000ull,
+                 "spconv_conv_forward_tiled_slots: feature matrix must be < 2 GiB");
+  BEVAMD_REQUIRE(out_stride >= cout && (!residual || residual_stride >= cout), "spconv_conv_forward_tiled_slots: bad output pitch");
+  BEVAMD_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "spconv_conv_forward_tiled_slots: scale and shift go together");
+  tile::Args a;
+  a.hdr = (const int2*)hdr; a.slots = (const uint16_t*)slots; a.slab_rows = block_rows;
+  a.feat = features; a.wimg = image; a.nbr = nullptr; a.m_dev = num_out_dev; a.out = out;
+  a.bias = bias; a.scale = bn_scale; a.shift = bn_shift; a.residual = residual;
+  a.feat_stride = feat_stride; a.n_in = num_in; a.nbr_stride = 0; a.m_cap = num_out; a.K = 27;
+  a.cout = cout; a.out_stride = out_stride; a.res_stride = residual_stride; a.relu = relu;
+  a.row_epilogue = cout % 8 == 0 && out_stride % 8 == 0 && ((uintptr_t)out & 15) == 0 &&
+                   (!residual || (residual_stride % 8 == 0 && ((uintptr_t)residual & 15) == 0)) &&
+                   (!bias || ((uintptr_t)bias & 15) == 0) && (!bn_scale || (((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0);
+  return dtype == tile::T_F16 ? tile::launch_f16(a, cinp, nt, variant, stream) : tile::launch_bf16(a, cinp, nt, variant, stream);
+}
+
+/* dst [n, pitch] (fp16 / bf16) = src [n, c] fp32 rounded to nearest, columns c .. pitch-1 zero: the encoder's input rows in the
+ * padded pitch the 16-bit convolution kernels read (SparseEncoder.forward's @auto_fp16 cast, sparse_encoder.py:99). */
+int bevamd_spconv_pad_cast_rows(const float* src, int n, int c, int pitch, int dtype, void* dst, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype == tile::T_F16 || dtype == tile::T_BF16, "spconv_pad_cast_rows: dtype %d is not 16-bit", dtype);
+  BEVAMD_REQUIRE(n >= 0 && c > 0 && pitch >= c, "spconv_pad_cast_rows: bad sizes");
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(src && dst, "spconv_pad_cast_rows: null buffer");
+  const size_t total = (size_t)n * pitch;
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == tile::T_F16)
+    sp_pad_cast_rows_kernel<tile::T_F16><<<dim3(blocks), dim3(256), 0, stream>>>(src, n, c, pitch, (_Float16*)dst);
+  else
+    sp_pad_cast_rows_kernel<tile::T_BF16><<<dim3(blocks), dim3(256), 0, stream>>>(src, n, c, pitch, (uint16_t*)dst);
+  BEVAMD_LAUNCH_CHECK("sp_pad_cast_rows");
+  return BEVAMD_OK;
 }
 
 }  // extern "C"

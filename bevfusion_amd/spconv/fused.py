@@ -66,8 +66,11 @@ class Level:
     Buffers are allocated by the caller's (current-stream) allocator; `run_encoder` joins the two streams before it
     returns, so their reuse stays ordered."""
 
-    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False):
+    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False, status_pool=None):
         self.indices = indices
+        # device status words of the products built for this chain of levels: slices of ONE zeroed tensor (a separate
+        # torch.zeros(1) per product put ten 5-us fill kernels in front of the first convolution); [pool, next free]
+        self._status_pool = status_pool
         self.n_cap = int(n_cap)
         self.n_dev = n_dev          # int32 device tensor [1] or None (= n_cap rows are all live)
         self.batch = int(batch)
@@ -95,6 +98,15 @@ class Level:
         if self.gstream is not None:
             return ctypes.c_void_p(self.gstream.cuda_stream)
         return _capi.stream_ptr(self.device)
+
+    def _status(self):
+        """A fresh zeroed int32 word for a product's status (None: the op allocates its own)."""
+        pool = self._status_pool
+        if pool is None or pool[1] >= pool[0].shape[0]:
+            return None
+        word = pool[0][pool[1]:pool[1] + 1]
+        pool[1] += 1
+        return word
 
     def _fork(self):
         """Called before a product is allocated and built OUTSIDE the up-front rulebook chain (a table a convolution asks for
@@ -141,7 +153,8 @@ class Level:
         if self.sorted_index is None:
             self._fork()
             self.sorted_index, self.sorted_status = ops.sorted_index_build(self.indices, self.n_cap, self.n_dev, self.batch,
-                                                                           self.shape, stream_ptr=self._stream_ptr())
+                                                                           self.shape, stream_ptr=self._stream_ptr(),
+                                                                           status=self._status())
             self._sorted_ev = self._mark()
         if wait:
             self._await(self._sorted_ev)
@@ -190,14 +203,15 @@ class Level:
                 self.ensure_sorted(wait=False)
                 meta = ops.slab_build_from_sorted(self.indices, self.n_cap, self.n_dev, self.batch, self.shape, self.shape,
                                                   [1, 1, 1], [1, 1, 1], True, self.sorted_index, self.n_cap, block_rows,
-                                                  stream_ptr=self._stream_ptr())
+                                                  stream_ptr=self._stream_ptr(), status=self._status())
             elif (3, 3, 3) in self._subm or not _SLAB_DIRECT:
                 nbr = self.subm_neighbors((3, 3, 3), wait=False)
-                meta = ops.slab_build(nbr, self.n_cap, self.n_dev, block_rows, stream_ptr=self._stream_ptr())
+                meta = ops.slab_build(nbr, self.n_cap, self.n_dev, block_rows, stream_ptr=self._stream_ptr(), status=self._status())
             else:   # nobody asked for the int32 table: every row looks its neighbours up itself, 54 B per row written in all
                 self.ensure_index()
                 meta = ops.slab_build_from_index(self.indices, self.n_cap, self.n_dev, self.batch, self.shape, self.index_kind,
-                                                 self.index, self.index_n_cap, block_rows, stream_ptr=self._stream_ptr())
+                                                 self.index, self.index_n_cap, block_rows, stream_ptr=self._stream_ptr(),
+                                                 status=self._status())
             self._slab[block_rows] = (meta, self._mark())
         meta, ev = self._slab[block_rows]
         if wait:
@@ -214,7 +228,7 @@ class Level:
             self._fork()
             meta = ops.slab_build_from_sorted(out.indices, out.n_cap, out.n_dev, self.batch, self.shape, out.shape, list(stride),
                                               list(padding), False, self.sorted_index, self.n_cap, block_rows,
-                                              stream_ptr=self._stream_ptr())
+                                              stream_ptr=self._stream_ptr(), status=self._status())
             self._down_slab[key] = (meta, self._mark())
         meta, ev = self._down_slab[key]
         if wait:
@@ -261,7 +275,7 @@ class Level:
                                               _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.ptr(nbr), cap,
                                               self._stream_ptr())
         _capi.check(rc, "spconv_downsample")
-        out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream)
+        out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream, status_pool=self._status_pool)
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
         out.linear_order = True
         out.ready = self._mark()    # behind the downsample: indices, count, rank index and this conv's nbr are final
@@ -326,7 +340,9 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
     image, bias, scale, shift = folded(conv, bn, dtype)
     lvl = x.level
     slab_variant = _slab_variant_for(conv, lvl, cin, cout)
-    want_nbr = slab_variant is None or LAYER_PROFILE is not None
+    # a strided 3x3x3 layer that stays on the gather kernels can still read slot metadata (sorted-key search) instead of a table
+    slots_meta = slab_variant is None and _gather_reads_slots(conv, lvl)
+    want_nbr = (slab_variant is None and not slots_meta) or LAYER_PROFILE is not None
     if conv.subm:
         # the slab kernels read their own metadata: the int32 neighbour table is only built for them when profiling (pair counts)
         nbr = lvl.subm_neighbors(conv.kernel_size) if want_nbr else None
@@ -338,7 +354,8 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
     rec = None
     if LAYER_PROFILE is not None:
         torch.cuda.synchronize()          # the rulebook chain (geometry stream) is out of the way: the events bracket the kernel
-        rec = dict(cin=cin, cout=cout, K=K, subm=bool(conv.subm), kernel="slab" if slab_variant is not None else "gather",
+        rec = dict(cin=cin, cout=cout, K=K, subm=bool(conv.subm),
+                   kernel="slab" if slab_variant is not None else "gather+slots" if slots_meta else "gather",
                    variant=slab_variant if slab_variant is not None else _variant_for(lvl.batch, K, cin, cout),
                    start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True),
                    n_in=lvl.n_dev, n_out=out_lvl.n_dev, n_in_cap=lvl.n_cap, n_out_cap=out_lvl.n_cap, nbr=nbr)
@@ -348,6 +365,11 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
         meta = lvl.subm_slab(rows) if conv.subm else lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, rows)
         ops.sparse_conv_slab(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                              residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out, variant=slab_variant)
+    elif slots_meta:
+        meta = lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, _GATHER_SLOT_ROWS)
+        ops.sparse_conv_tiled_slots(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
+                                    residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
+                                    variant=_variant_for(lvl.batch, K, cin, cout))
     else:
         ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                               residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
@@ -432,6 +454,22 @@ def _narrow_variant_for(conv, lvl, cin, cout):
         return variant if rows and ops.slab_grid_ok(lvl.shape, rows) else None
     variant = overrides.get(-16, _SLAB_NARROW_STRIDED)
     return variant if ops.slab_block_rows(cin, variant) else None
+
+
+_STATUS_WORDS = 64
+_STATUS_POOL = os.environ.get("BEVAMD_SPCONV_STATUS_POOL", "1") != "0"
+_PAD_CAST = os.environ.get("BEVAMD_SPCONV_PAD_CAST", "1") != "0"
+_GATHER_SLOT_ROWS = 128
+# measured at 8 frames and NOT the default: LiDAR branch 3.94 ms with it against 3.83 ms with the int32 tables — the 2-byte slot
+# decode makes the gather kernels 6-13 % slower (196 / 130 us against 185 / 115) and the extra sorted-key searches (128 + 60 us)
+# run under the level-2 layers, which is worth more than the 0.32 ms of table kernels they replace
+_GATHER_SLOTS = os.environ.get("BEVAMD_SPCONV_GATHER_SLOTS", "0") == "1"
+
+
+def _gather_reads_slots(conv, lvl):
+    """Strided 3x3x3 layers left on the gather kernels (32 -> 64, 64 -> 128: their input ranges are too long to stage) read slot
+    metadata built by sorted-key search from the input level instead of an int32 table that has to be cleared and scattered."""
+    return (_GATHER_SLOTS and _SORTED and not conv.subm and tuple(conv.kernel_size) == (3, 3, 3) and lvl.linear_order)
 
 
 def _slab_variant_for(conv, lvl, cin, cout):
@@ -551,9 +589,10 @@ def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None):
     dev = coors.device
     g = geometry_stream(dev)
     main = torch.cuda.current_stream(dev)
+    pool = [torch.zeros(_STATUS_WORDS, dtype=torch.int32, device=dev), 0] if _STATUS_POOL else None   # zeroed BEFORE the fork: ordered ahead of both streams
     if g is not None:
         g.wait_stream(main)
-    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order))
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool)
     try:
         prefetch_geometry(enc, lvl)
     finally:
@@ -619,8 +658,15 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
         raise NotThisCall("empty input")
     cin = voxel_features.shape[1]
     pitch = ops.padded_channels(cin)
-    feats = torch.zeros((n, pitch), dtype=dtype, device=voxel_features.device)
-    feats[:, :cin] = voxel_features
+    if _PAD_CAST and voxel_features.dtype == torch.float32 and voxel_features.is_contiguous():
+        feats = torch.empty((n, pitch), dtype=dtype, device=voxel_features.device)
+        with torch.cuda.device(voxel_features.device):
+            rc = _capi.load().bevamd_spconv_pad_cast_rows(_capi.ptr(voxel_features), n, cin, pitch, ops._dtype_code(feats),
+                                                          _capi.ptr(feats), _capi.stream_ptr(voxel_features.device))
+        _capi.check(rc, "spconv_pad_cast_rows")
+    else:
+        feats = torch.zeros((n, pitch), dtype=dtype, device=voxel_features.device)
+        feats[:, :cin] = voxel_features
     if geometry is not None:
         if geometry.n_cap != n or geometry.batch != int(batch_size):
             raise RuntimeError("run_encoder: `geometry` was prepared for other inputs")
@@ -635,9 +681,10 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
     dev = voxel_features.device
     g = geometry_stream(dev)
     main = torch.cuda.current_stream(dev)
+    pool = [torch.zeros(_STATUS_WORDS, dtype=torch.int32, device=dev), 0] if _STATUS_POOL else None   # zeroed BEFORE the fork: ordered ahead of both streams
     if g is not None:
         g.wait_stream(main)       # fork: coordinates / count are final, recycled buffers are quiescent
-    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order))
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool)
     try:
         if g is not None:
             prefetch_geometry(enc, lvl)
@@ -687,7 +734,11 @@ def _prefetch_geometry(enc, lvl):
             else:
                 cur.subm_neighbors(m.kernel_size, wait=False)
         else:
-            nxt, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False, want_nbr=v is None or LAYER_PROFILE is not None)
+            slots_meta = v is None and _gather_reads_slots(m, cur)
+            nxt, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False,
+                                    want_nbr=(v is None and not slots_meta) or LAYER_PROFILE is not None)
             if v is not None:
                 cur.down_slab(m.kernel_size, m.stride, m.padding, ops.slab_block_rows(m.in_channels, v), wait=False)
+            elif slots_meta:
+                cur.down_slab(m.kernel_size, m.stride, m.padding, _GATHER_SLOT_ROWS, wait=False)
             cur = nxt

@@ -302,6 +302,31 @@ def sparse_conv_tiled(features, image, nbr, num_out, kernel_volume, cin, cout, b
     return out
 
 
+def sparse_conv_tiled_slots(features, image, meta, num_out, cin, cout, bias=None, bn_scale=None, bn_shift=None, residual=None,
+                            relu=False, num_out_dev=None, out=None, variant=0):
+    """`sparse_conv_tiled` for a 3x3x3 convolution whose rulebook is slab metadata (`SlabMeta`) instead of the int32 table."""
+    lib = _capi.load()
+    _require_cuda(features, "features")
+    if features.stride(1) != 1:
+        features = features.contiguous()
+    dt = _dtype_code(features)
+    if out is None:
+        out = torch.empty((num_out, cout), dtype=features.dtype, device=features.device)
+    if num_out == 0:
+        return out
+    if residual is not None and residual.stride(1) != 1:
+        residual = residual.contiguous()
+    with torch.cuda.device(features.device):
+        rc = lib.bevamd_spconv_conv_forward_tiled_slots(
+            _capi.ptr(features), dt, features.stride(0), features.shape[0], _capi.ptr(image), _capi.ptr(meta.hdr),
+            _capi.ptr(meta.slots), meta.block_rows, int(num_out), _capi.ptr(num_out_dev), int(cin), int(cout), _capi.ptr(out),
+            out.stride(0), _capi.ptr(bias), _capi.ptr(bn_scale), _capi.ptr(bn_shift), _capi.ptr(residual),
+            residual.stride(0) if residual is not None else 0, int(bool(relu)), int(variant),
+            _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_conv_forward_tiled_slots")
+    return out
+
+
 # ---- slab (staged-rows) SubM convolution: csrc/spconv_slab.h ------------------------------------------------------------
 def slab_block_rows(cin, variant=0):
     """Rows per block of slab variant `variant` (0 = default) for a cin -> cin 3x3x3 SubM convolution; 0 = not built."""
@@ -326,14 +351,15 @@ class SlabMeta:
         self.hdr, self.slots, self.block_rows, self.status = hdr, slots, block_rows, status
 
 
-def slab_build(nbr, m_cap, m_dev, block_rows, stream_ptr=None):
+def slab_build(nbr, m_cap, m_dev, block_rows, stream_ptr=None, status=None):
     lib = _capi.load()
     dev = nbr.device
     assert nbr.shape[0] == 27 and nbr.dtype == torch.int32
     with torch.cuda.device(dev):
         hdr = torch.empty(max(lib.bevamd_spconv_slab_hdr_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
         slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        if status is None:   # callers on a hot path hand in a slice of one pre-zeroed pool (a 5 us fill kernel per product otherwise)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
         rc = lib.bevamd_spconv_slab_build(_capi.ptr(nbr), nbr.stride(0), int(m_cap), _capi.ptr(m_dev), int(block_rows),
                                           _capi.ptr(hdr), _capi.ptr(slots), _capi.ptr(status),
                                           stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
@@ -341,14 +367,15 @@ def slab_build(nbr, m_cap, m_dev, block_rows, stream_ptr=None):
     return SlabMeta(hdr, slots, int(block_rows), status)
 
 
-def slab_build_from_index(indices, m_cap, m_dev, batch, shape, index_kind, index, index_n_cap, block_rows, stream_ptr=None):
+def slab_build_from_index(indices, m_cap, m_dev, batch, shape, index_kind, index, index_n_cap, block_rows, stream_ptr=None, status=None):
     """The same metadata straight from the voxel set's index (bevamd_spconv_slab_build_from_index): no neighbour table."""
     lib = _capi.load()
     dev = indices.device
     with torch.cuda.device(dev):
         hdr = torch.empty(max(lib.bevamd_spconv_slab_hdr_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
         slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        if status is None:   # callers on a hot path hand in a slice of one pre-zeroed pool (a 5 us fill kernel per product otherwise)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
         rc = lib.bevamd_spconv_slab_build_from_index(_capi.ptr(indices), int(m_cap), _capi.ptr(m_dev), int(batch),
                                                      _capi.ints(shape), int(index_kind), _capi.ptr(index), int(index_n_cap),
                                                      int(block_rows), _capi.ptr(hdr), _capi.ptr(slots), _capi.ptr(status),
@@ -357,7 +384,7 @@ def slab_build_from_index(indices, m_cap, m_dev, batch, shape, index_kind, index
     return SlabMeta(hdr, slots, int(block_rows), status)
 
 
-def sorted_index_build(indices, n_cap, n_dev, batch, shape, stream_ptr=None):
+def sorted_index_build(indices, n_cap, n_dev, batch, shape, stream_ptr=None, status=None):
     """Sorted-key index (keys + x-plane directory, one uint8 buffer) of a voxel set whose rows are in ascending linear index;
     returns (index, status) — status bit 1 (value 2) is set on the device if the rows are not strictly ascending."""
     lib = _capi.load()
@@ -365,7 +392,8 @@ def sorted_index_build(indices, n_cap, n_dev, batch, shape, stream_ptr=None):
     with torch.cuda.device(dev):
         nbytes = int(lib.bevamd_spconv_sorted_index_bytes(int(n_cap), int(batch), _capi.ints(shape)))
         index = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        if status is None:   # callers on a hot path hand in a slice of one pre-zeroed pool (a 5 us fill kernel per product otherwise)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
         rc = lib.bevamd_spconv_sorted_index_build(_capi.ptr(indices), int(n_cap), _capi.ptr(n_dev), int(batch), _capi.ints(shape),
                                                   _capi.ptr(index), nbytes, _capi.ptr(status),
                                                   stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
@@ -374,7 +402,7 @@ def sorted_index_build(indices, n_cap, n_dev, batch, shape, stream_ptr=None):
 
 
 def slab_build_from_sorted(out_indices, m_cap, m_dev, batch, in_shape, out_shape, stride, padding, subm, in_index, in_n_cap,
-                           block_rows, stream_ptr=None):
+                           block_rows, stream_ptr=None, status=None):
     """Slab metadata of a 3x3x3 convolution (submanifold, or strided with active outputs `out_indices`) from the sorted-key
     index of its input set (bevamd_spconv_slab_build_from_sorted): no neighbour table."""
     lib = _capi.load()
@@ -382,7 +410,8 @@ def slab_build_from_sorted(out_indices, m_cap, m_dev, batch, in_shape, out_shape
     with torch.cuda.device(dev):
         hdr = torch.empty(max(lib.bevamd_spconv_slab_hdr_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
         slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        if status is None:   # callers on a hot path hand in a slice of one pre-zeroed pool (a 5 us fill kernel per product otherwise)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
         rc = lib.bevamd_spconv_slab_build_from_sorted(_capi.ptr(out_indices), int(m_cap), _capi.ptr(m_dev), int(batch),
                                                       _capi.ints(in_shape), _capi.ints(out_shape), _capi.ints(stride),
                                                       _capi.ints(padding), int(bool(subm)), _capi.ptr(in_index), int(in_n_cap),

@@ -465,6 +465,18 @@ int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_s
                                      int out_stride, const void* bias, const float* bn_scale,
                                      const float* bn_shift, const void* residual, int residual_stride,
                                      int relu, int variant, void* stream);
+/* The same call with the rulebook of a 3x3x3 convolution given as slab metadata (hdr / slots of bevamd_spconv_slab_build*,
+ * block_rows = 128 | 256) instead of the int32 neighbour table: the gather kernels decode `first row of the plane + 16-bit slot`
+ * while they load a tile's table.  Same kernels and results, half the rulebook bytes, no table to clear and scatter
+ * (spconv_ops.h:27-141 writes 2 x 27 x N int32 per rulebook). */
+int bevamd_spconv_conv_forward_tiled_slots(const void* features, int dtype, int feat_stride, int num_in, const void* image,
+                                           const void* hdr, const void* slots, int block_rows, int num_out,
+                                           const int* num_out_dev, int cin, int cout, void* out, int out_stride,
+                                           const void* bias, const float* bn_scale, const float* bn_shift, const void* residual,
+                                           int residual_stride, int relu, int variant, void* stream);
+/* dst [n, pitch] (dtype 1 = fp16, 2 = bf16) = src [n, c] fp32 rounded to nearest, columns c .. pitch-1 zero: the encoder's input
+ * rows in the padded pitch the 16-bit kernels read (the @auto_fp16 cast of SparseEncoder.forward, sparse_encoder.py:99). */
+int bevamd_spconv_pad_cast_rows(const float* src, int n, int c, int pitch, int dtype, void* dst, void* stream);
 
 /* Slab (staged-rows) forward for 3x3x3 SUBMANIFOLD convolutions over voxel sets whose rows are in ascending linear index
  * ((b*X + x)*Y + y)*Z + z — every set a strided convolution produced (the reference's CUDA row order, spconv_ops.h:130).

@@ -278,6 +278,38 @@ def test_narrow_strided_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, varian
     assert fused.geometry_status(lvl) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 128), (16, 32)])
+@pytest.mark.parametrize("batch,shape,n,pad", [(2, [24, 20, 9], 2500, (1, 1, 1)), (1, [40, 40, 21], 9000, (1, 1, 0)),
+                                                (1, [16, 24, 41], 15000, (1, 1, 1))])
+def test_gather_kernels_reading_slot_metadata_equal_the_table_route(dev, dtype, cin, cout, batch, shape, n, pad):
+    """The strided layers that stay on the gather kernels (32 -> 64, 64 -> 128) decode `plane start + 16-bit slot` while they load
+    a tile's rulebook instead of reading an int32 table: same kernel, same output bits."""
+    rng = np.random.default_rng(n + cin)
+    c4, _, ct = random_sorted_set(rng, batch, shape, n, dev)
+    m = c4.shape[0]
+    cap = m + 77
+    buf = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    buf[:m] = ct
+    n_dev = torch.tensor([m], dtype=torch.int32, device=dev)
+    lvl = fused.Level(buf, cap, n_dev, batch, shape, linear_order=True)
+    x = torch.from_numpy(rng.standard_normal((cap, cin)).astype(np.float32) * 0.5).to(dev).to(dtype)
+    x[m:] = float("nan")
+    w = _filters(rng, (3, 3, 3), cin, cout, dev, dtype)
+    img = sops.make_filter_image(w)
+    out, nbr = lvl.downsample([3, 3, 3], [2, 2, 2], list(pad))
+    meta = lvl.down_slab([3, 3, 3], [2, 2, 2], list(pad), 128)
+    mo = int(out.n_dev.item())
+    scale = torch.from_numpy(rng.uniform(0.7, 1.3, cout).astype(np.float32)).to(dev)
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1).to(dev)
+    for variant in (0, fused._variant_for(8, 27, cin, cout)):
+        for kw in (dict(), dict(bn_scale=scale, bn_shift=shift, relu=True)):
+            got = sops.sparse_conv_tiled_slots(x, img, meta, out.n_cap, cin, cout, num_out_dev=out.n_dev, variant=variant, **kw)[:mo]
+            ref = sops.sparse_conv_tiled(x, img, nbr, out.n_cap, 27, cin, cout, num_out_dev=out.n_dev, variant=variant, **kw)[:mo]
+            assert torch.equal(got, ref), (variant, float((got.float() - ref.float()).abs().max()))
+    assert fused.geometry_status(lvl) == 0
+
+
 # ---- encoder ----------------------------------------------------------------------------------------------------------------
 def flagship_encoder(dev, dtype=torch.float16, seed=0):
     torch.manual_seed(seed)
