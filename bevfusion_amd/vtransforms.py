@@ -335,7 +335,7 @@ class BaseDepthTransform(BaseTransform):
         return depth
 
     def _depth_raster_native(self, points, n_cam, lidar2image, img_aug_matrix, lidar_aug_matrix):
-        """csrc/vtransform.hip: one (winner, write) kernel pair for the whole batch, all cameras at once, no host sync; a pixel hit
+        """csrc/vtransform.hip: one (packed atomicMax, unpack) kernel pair for the whole batch, all cameras at once, no host sync; a pixel hit
         by several points keeps the LAST one in input order (the reference's assignment order on CPU; its GPU
         index_put is unordered)."""
         lib = _capi.load()

@@ -188,7 +188,8 @@ int bevamd_bev_pool_backward_rows(const float* out_grad, const uint32_t* order,
  * depth [ncam, 1, ih, iw] fp32 is fully written (zeros where no point lands).  A pixel hit by several points takes the
  * LAST point in input order (deterministic; = the reference's sequential assignment).  The three GEMMs of the reference are
  * k-ascending fma chains (BLAS sgemm): pixel sets and depths are bit-exact against the reference's own function body on CPU
- * torch given the same inverse.  ws: bevamd_depth_raster_workspace_bytes(ncam, ih, iw). */
+ * torch given the same inverse.  ws: bevamd_depth_raster_workspace_bytes(ncam, ih, iw) (one u64 per pixel; on return
+ * (winning point index + 1) << 32 | depth bits, 0 where nothing landed). */
 size_t bevamd_depth_raster_workspace_bytes(int ncam, int ih, int iw);
 int bevamd_depth_raster(const float* points, int num_points, int num_features, const float* lidar_aug_inv_rot,
                         const float* lidar_aug_trans, const float* lidar2image, const float* img_aug, int ncam,

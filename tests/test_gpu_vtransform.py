@@ -120,7 +120,8 @@ def test_depth_raster_kernel_bit_exact(dev, gold, prefix):
         od, winner = oracle.depth_raster(pts[b], c["l2i"][b], c["ia"][b], c["la"][b], (iH, iW),
                                          inv_lidar_aug_rot=c["inv_lidar_aug_rot"][b])
         assert np.array_equal(od, got)
-        assert np.array_equal(ws[: n_cam * iH * iW * 4].view(torch.int32).cpu().numpy().reshape(n_cam, iH, iW), winner)
+        packed = ws[: n_cam * iH * iW * 8].view(torch.int64).cpu().numpy().reshape(n_cam, iH, iW)     # (index + 1) << 32 | depth bits
+        assert np.array_equal((packed >> 32) - 1, winner)
 
 
 def test_device_inverse_and_module_default_path(dev, gold):
