@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbevfusion_amd.so")
+LIB_PATH = os.environ.get("BEVAMD_LIB") or os.path.join(_HERE, "lib", "libbevfusion_amd.so")   # BEVAMD_LIB: tools/exp_build.sh A/B builds
 
 _lib = None
 

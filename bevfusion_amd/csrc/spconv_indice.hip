@@ -1104,7 +1104,7 @@ int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int
   const int k3[3] = {3, 3, 3}, one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
   int rc = make_geom(batch_size, shape, shape, k3, one, zero, nullptr, 1, g);
   if (rc) return rc;
-  BEVAMD_REQUIRE(block_rows == 128 || block_rows == 256, "spconv_slab_build_from_index: block_rows %d (128 | 256)", block_rows);
+  BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_index: block_rows %d (64 | 128 | 256)", block_rows);
   BEVAMD_REQUIRE(index_kind == INDEX_HASH || index_kind == INDEX_RANK, "spconv_slab_build_from_index: index_kind %d", index_kind);
   BEVAMD_REQUIRE(m_cap >= 0, "spconv_slab_build_from_index: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
@@ -1113,7 +1113,8 @@ int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;   // a multiple of 8: XCD-contiguous block map
 #define BEVAMD_GO(BM, KIND) \
   sp_slab_from_index_kernel<BM, KIND><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix, (int2*)hdr, (uint16_t*)slots, status)
-  if (block_rows == 128) { if (index_kind == INDEX_HASH) BEVAMD_GO(128, INDEX_HASH); else BEVAMD_GO(128, INDEX_RANK); }
+  if (block_rows == 64) { if (index_kind == INDEX_HASH) BEVAMD_GO(64, INDEX_HASH); else BEVAMD_GO(64, INDEX_RANK); }
+  else if (block_rows == 128) { if (index_kind == INDEX_HASH) BEVAMD_GO(128, INDEX_HASH); else BEVAMD_GO(128, INDEX_RANK); }
   else { if (index_kind == INDEX_HASH) BEVAMD_GO(256, INDEX_HASH); else BEVAMD_GO(256, INDEX_RANK); }
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("sp_slab_from_index");
@@ -1162,7 +1163,7 @@ int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, cons
   const int k3[3] = {3, 3, 3};
   int rc = make_geom(batch_size, in_shape, subm ? in_shape : out_shape, k3, stride, padding, nullptr, subm, g);
   if (rc) return rc;
-  BEVAMD_REQUIRE(block_rows == 128 || block_rows == 256, "spconv_slab_build_from_sorted: block_rows %d (128 | 256)", block_rows);
+  BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_sorted: block_rows %d (64 | 128 | 256)", block_rows);
   BEVAMD_REQUIRE(m_cap >= 0 && in_n_cap >= 0, "spconv_slab_build_from_sorted: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(out_indices && in_index && hdr && slots, "spconv_slab_build_from_sorted: null buffer");
@@ -1171,7 +1172,8 @@ int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, cons
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;
 #define BEVAMD_GO(BM, SUBM) \
   sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, (int2*)hdr, (uint16_t*)slots, status)
-  if (block_rows == 128) { if (subm) BEVAMD_GO(128, true); else BEVAMD_GO(128, false); }
+  if (block_rows == 64) { if (subm) BEVAMD_GO(64, true); else BEVAMD_GO(64, false); }
+  else if (block_rows == 128) { if (subm) BEVAMD_GO(128, true); else BEVAMD_GO(128, false); }
   else { if (subm) BEVAMD_GO(256, true); else BEVAMD_GO(256, false); }
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("sp_slab_from_sorted");

@@ -41,7 +41,11 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
   for (int i = 0; s && i < n && i < max_n; ++i) codes[i] = slab::variant_code(s[i]);
   for (int i = 0; r && i < nr && n + i < max_n; ++i) codes[n + i] = slab::variant_code(r[i]);
   for (int i = 0; r && i < nr && n + nr + i < max_n; ++i) codes[n + nr + i] = slab::variant_code(r[i]) + (slab::PERSIST_BASE - slab::REGW_BASE);
-  return n + 2 * nr;
+  int nf = 0;
+#define BEVAMD_ROW(CAP) if (cin == 32) { if (n + 2 * nr + nf < max_n) codes[n + 2 * nr + nf] = slab::FSTAT_BASE + CAP; ++nf; }
+  BEVAMD_SLABF_SHAPES_32(BEVAMD_ROW)
+#undef BEVAMD_ROW
+  return n + 2 * nr + nf;
 }
 
 /* 1 if a voxel set on a [batch, X, Y, Z] grid whose rows are in ascending linear index can use the slab kernels: the input
@@ -69,12 +73,14 @@ size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows) {
 int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const int* m_dev, int block_rows, void* hdr,
                              void* slots, int* status, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  BEVAMD_REQUIRE(block_rows == 128 || block_rows == 256, "spconv_slab_build: block_rows %d (128 | 256)", block_rows);
+  BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build: block_rows %d (64 | 128 | 256)", block_rows);
   BEVAMD_REQUIRE(m_cap >= 0 && nbr_stride >= m_cap, "spconv_slab_build: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(nbr && hdr && slots, "spconv_slab_build: null buffer");
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows);
-  if (block_rows == 128)
+  if (block_rows == 64)
+    slab::slab_build_kernel<64><<<dim3(nblk), dim3(64), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);
+  else if (block_rows == 128)
     slab::slab_build_kernel<128><<<dim3(nblk), dim3(128), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);
   else
     slab::slab_build_kernel<256><<<dim3(nblk), dim3(256), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);

@@ -4,6 +4,7 @@
 #include "spconv_slab_regw.h"
 #include "spconv_slab_persist.h"
 #include "spconv_slab_small.h"
+#include "spconv_slab_fstat.h"
 
 namespace bevamd {
 namespace slab {
@@ -169,9 +170,47 @@ static inline const ShapeR* find_shape_r(int cin, int variant) {
     if (variant_code(s[i]) == variant) return s + i;
   return nullptr;
 }
+// ---- filter-stationary kernels (spconv_slab_fstat.h), 32 -> 32: variant = 4000000 + CAP; 64-row blocks, BAKED slots --
+constexpr int FSTAT_BASE = 4000000;
+#define BEVAMD_SLABF_SHAPES_32(X) X(112) X(96)
+static inline bool fstat_built(int cin, int variant) {
+#define BEVAMD_ROW(CAP) if (cin == 32 && variant == FSTAT_BASE + CAP) return true;
+  BEVAMD_SLABF_SHAPES_32(BEVAMD_ROW)
+#undef BEVAMD_ROW
+  return false;
+}
+template <int DT, int CAP>
+static int run_f(const SlabArgs& sa, hipStream_t stream) {
+  typedef PlanF<CAP> P;
+  static_assert(P::BYTES <= 40 * 1024, "four waves per CU: 40 KiB of LDS each");
+  auto kern = &spconv_slabf_kernel<DT, CAP>;
+  static PerDevice pd = {};
+  const int wg_per_xcd = resident_per_xcd(pd, kern, 64, P::BYTES);
+  if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
+  const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
+  long long gx = (nblk + 7) / 8;
+  if (gx > wg_per_xcd) gx = wg_per_xcd;
+  kern<<<dim3((unsigned)(gx * 8)), dim3(64), P::BYTES, stream>>>(sa);
+  BEVAMD_LAUNCH_CHECK("spconv_slabf");
+  return BEVAMD_OK;
+}
+template <int DT>
+int launch_f_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t stream) {
+  if (cin == 32 && nt == 2 && !sa.a.row_epilogue) {
+    set_error("spconv slab: the filter-stationary kernels need 16-byte aligned rows (pitches multiples of 8)");
+    return BEVAMD_ERR_UNSUPPORTED;
+  }
+#define BEVAMD_ROW(CAP) if (cin == 32 && nt == 2 && variant == FSTAT_BASE + CAP) return run_f<DT, CAP>(sa, stream);
+  BEVAMD_SLABF_SHAPES_32(BEVAMD_ROW)
+#undef BEVAMD_ROW
+  set_error("spconv slab: no filter-stationary kernel for cin=%d, cout tiles=%d, variant=%d", cin, nt, variant);
+  return BEVAMD_ERR_UNSUPPORTED;
+}
+
 // rows per block of any variant code (0 = none built)
 static inline int block_rows_of(int cin, int variant) {
   if (cin <= 16) return cin > 0 ? small_block_rows(cin <= 8 ? 8 : 16, variant) : 0;
+  if (variant >= FSTAT_BASE) return fstat_built(cin, variant) ? BAKED_ROWS : 0;
   if (variant >= REGW_BASE) {
     const ShapeR* r = find_shape_r(cin, variant);
     return r ? r->rw * 16 * r->mt : 0;
@@ -243,6 +282,7 @@ int launch_r_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t 
 template <int DT>
 int launch_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t stream) {
   if (cin <= 16) return launch_s_impl<DT>(sa, cin, nt, variant, stream);
+  if (variant >= FSTAT_BASE) return launch_f_impl<DT>(sa, cin, nt, variant, stream);
   if (variant >= REGW_BASE) return launch_r_impl<DT>(sa, cin, nt, variant, stream);
   const Shape* s = find_shape(cin, variant);
   if (!s || nt != cin / 16) {

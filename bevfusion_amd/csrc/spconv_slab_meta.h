@@ -12,6 +12,17 @@ constexpr int PLANES = 3;         // kx planes of the 3x3x3 kernel: the 9 (ky, k
 constexpr int TAPS = 9;           // taps per plane
 constexpr unsigned NO_SLOT = 0xFFFFu;
 
+// BAKED metadata (64-row blocks, the filter-stationary kernels of spconv_slab_fstat.h): a slot is stored as the LDS byte
+// offset the kernel reads it from — staged row s of the range lives in LDS row e = s + 1 of 64 bytes (row 0 is the zero row a
+// missing neighbour reads), with the kernel's bank swizzle already folded in: entry = e*64 | ((e >> 2) & 3) << 4, 0 = none.  The
+// address of a fragment is then ONE v_xor of the entry with the lane's 16-byte piece (measured on the 32-channel layers:
+// 12 VALU instructions per slot of index arithmetic before, 12 % of the layer).  A range too long for 16 bits of bytes
+// (> 1022 rows) keeps raw slots and says so in the header (HDR_RAW in the row count); the kernel then takes its general path.
+constexpr unsigned HDR_RAW = 0x40000000u;
+constexpr int BAKED_ROWS = 64;        // block size that implies the baked format
+constexpr int BAKED_ROW_BYTES = 64;   // 32 channels of 16 bits
+__host__ __device__ __forceinline__ unsigned baked_entry(unsigned e) { return e * BAKED_ROW_BYTES | (((e >> 2) & 3u) << 4); }
+
 // One workgroup of BM threads per block; thread t holds the 27 neighbour rows v[] of output row blk*BM + t (-1 = none).
 template <int BM>
 __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, int2* __restrict__ hdr,
@@ -44,12 +55,13 @@ __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, in
     int cnt = hi >= 0 ? hi - lo + 1 : 0;
     if (hi < 0) lo = 0;
     if (cnt > 0xFFFE) { cnt = 0xFFFE; overflow = true; }   // cannot happen for rows in linear-index order on grids the host admits
-    if (t == 0) hdr[(size_t)blk * PLANES + j] = make_int2(lo, cnt);
+    const bool baked = BM == BAKED_ROWS && (cnt + 1) * BAKED_ROW_BYTES <= 0xFFFF;
+    if (t == 0) hdr[(size_t)blk * PLANES + j] = make_int2(lo, BM == BAKED_ROWS && !baked ? (int)((unsigned)cnt | HDR_RAW) : cnt);
 #pragma unroll
     for (int d = 0; d < TAPS; ++d) {
       const int k = j * TAPS + d, x = v[k];
-      unsigned s = NO_SLOT;
-      if (x >= 0 && x - lo < cnt) s = (unsigned)(x - lo);
+      unsigned s = baked ? 0u : NO_SLOT;
+      if (x >= 0 && x - lo < cnt) s = baked ? baked_entry((unsigned)(x - lo) + 1u) : (unsigned)(x - lo);
       slots[((size_t)blk * 27 + k) * BM + t] = (uint16_t)s;
     }
   }

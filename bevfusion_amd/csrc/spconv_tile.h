@@ -70,6 +70,59 @@ __device__ __forceinline__ float round_to_storage(float v) {
   return Num<DT>::to_f32(Num<DT>::from_f32(v));
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// The tail of every 16-bit epilogue: 8 consecutive channels of one row, given as the conv result ALREADY rounded to 16 bits
+// (`raw`), through bias add, folded BatchNorm, residual add and ReLU — each a stored 16-bit tensor in the unfused reference
+// pipeline, so each rounds once.  fp16 runs on packed halves: the adds are v_pk_add_f16 (the reference's own half add: one
+// rounding from the exact sum), BatchNorm is an fp32 fma rounded to half (kept opaque so that no v_fma_mix fuses the two
+// roundings), ReLU clears the halves whose sign bit is set (integer: a NaN with a clear sign bit — what the hardware's own
+// invalid operations produce — stays a NaN, as in the reference).  4-5 VALU instructions per channel instead of 14: measured
+// 25-50 us of the 170-190 us 32-channel layers went into this tail.  bf16 has no packed arithmetic and keeps fp32 steps.
+template <int DT>
+__device__ __forceinline__ unsigned finish_pair(unsigned raw, bool has_bias, unsigned bias, bool has_scale, float s0, float s1, float h0, float h1,
+                                                bool has_res, unsigned res, bool relu) {
+  typedef typename Num<DT>::T T;
+  if constexpr (DT == T_F16) {
+    f16x2 y = __builtin_bit_cast(f16x2, raw);
+    if (has_bias) y = y + __builtin_bit_cast(f16x2, bias);
+    if (has_scale) {
+      float f0 = __builtin_fmaf((float)y[0], s0, h0), f1 = __builtin_fmaf((float)y[1], s1, h1);
+      asm volatile("" : "+v"(f0), "+v"(f1));
+      y = f16x2{(_Float16)f0, (_Float16)f1};
+    }
+    if (has_res) y = y + __builtin_bit_cast(f16x2, res);
+    if (relu) {
+      const s16x2 b = __builtin_bit_cast(s16x2, y);
+      y = __builtin_bit_cast(f16x2, (s16x2)(b & ~(b >> 15)));
+    }
+    return __builtin_bit_cast(unsigned, y);
+  } else {
+    const float sv[2] = {s0, s1}, hv[2] = {h0, h1};
+    unsigned o = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float x = Num<DT>::to_f32((T)(raw >> (16 * e)));
+      if (has_bias) x = round_to_storage<DT>(x + Num<DT>::to_f32((T)(bias >> (16 * e))));
+      if (has_scale) x = round_to_storage<DT>(__builtin_fmaf(x, sv[e], hv[e]));
+      if (has_res) x = round_to_storage<DT>(x + Num<DT>::to_f32((T)(res >> (16 * e))));
+      const unsigned h = (unsigned)Num<DT>::from_f32(x);
+      o |= (relu && (h & 0x8000u) ? 0u : h) << (16 * e);   // sign bit set -> +0: the fp16 path's rule
+    }
+    return o;
+  }
+}
+template <int DT>
+__device__ __forceinline__ u32x4 finish8(u32x4 raw, bool has_bias, u32x4 bias, bool has_scale, const float (&sv)[8], const float (&hv)[8],
+                                         bool has_res, u32x4 res, bool relu) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    o[i] = finish_pair<DT>(raw[i], has_bias, bias[i], has_scale, sv[2 * i], sv[2 * i + 1], hv[2 * i], hv[2 * i + 1], has_res, res[i], relu);
+  return o;
+}
+
 struct Args {
   const void* feat;     // [n_in, feat_stride] 16-bit
   const void* wimg;     // filter image (see make_filter_image)
@@ -129,45 +182,32 @@ template <int DT>
 __device__ __forceinline__ void epilogue_store(const Args& a, int row, int col0, f32x4 v) {
   typedef typename Num<DT>::T T;
   if (col0 >= a.cout) return;
-  float x[4];
+  T p[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) x[j] = Num<DT>::to_f32(Num<DT>::from_f32(v[j]));
+  for (int j = 0; j < 4; ++j) p[j] = Num<DT>::from_f32(v[j]);
   T* op = (T*)a.out + (size_t)row * a.out_stride + col0;
   const bool fast = col0 + 4 <= a.cout && ((a.out_stride | a.res_stride) & 3) == 0;  // wave-uniform except at the cout edge
   if (fast) {
-    if (a.bias) {
-      const uint2 raw = *(const uint2*)((const T*)a.bias + col0);
-      const T* b = (const T*)&raw;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = round_to_storage<DT>(x[j] + Num<DT>::to_f32(b[j]));
-    }
-    if (a.scale) {
-      const float4 sc = *(const float4*)(a.scale + col0), sh = *(const float4*)(a.shift + col0);
-      // one fused multiply-add everywhere the folded BatchNorm is applied (both epilogue flavours: same bits whichever kernel runs a layer)
-      x[0] = __builtin_fmaf(x[0], sc.x, sh.x); x[1] = __builtin_fmaf(x[1], sc.y, sh.y); x[2] = __builtin_fmaf(x[2], sc.z, sh.z); x[3] = __builtin_fmaf(x[3], sc.w, sh.w);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = round_to_storage<DT>(x[j]);
-    }
-    if (a.residual) {
-      const uint2 raw = *(const uint2*)((const T*)a.residual + (size_t)row * a.res_stride + col0);
-      const T* r = (const T*)&raw;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = round_to_storage<DT>(x[j] + Num<DT>::to_f32(r[j]));
-    }
-    T p[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = Num<DT>::from_f32(a.relu && x[j] < 0.f ? 0.f : x[j]);
-    *(uint2*)op = *(const uint2*)p;
+    const uint2 raw = *(const uint2*)p;
+    uint2 b = make_uint2(0u, 0u), r = make_uint2(0u, 0u);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) b = *(const uint2*)((const T*)a.bias + col0);
+    if (a.scale) { sc = *(const float4*)(a.scale + col0); sh = *(const float4*)(a.shift + col0); }
+    if (a.residual) r = *(const uint2*)((const T*)a.residual + (size_t)row * a.res_stride + col0);
+    uint2 o;
+    o.x = finish_pair<DT>(raw.x, a.bias != nullptr, b.x, a.scale != nullptr, sc.x, sc.y, sh.x, sh.y, a.residual != nullptr, r.x, a.relu != 0);
+    o.y = finish_pair<DT>(raw.y, a.bias != nullptr, b.y, a.scale != nullptr, sc.z, sc.w, sh.z, sh.w, a.residual != nullptr, r.y, a.relu != 0);
+    *(uint2*)op = o;
     return;
   }
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 4; ++j) {   // the cout edge, element by element through the same arithmetic (low half of a pair)
     if (col0 + j >= a.cout) break;
-    float y = x[j];
-    if (a.bias) y = round_to_storage<DT>(y + Num<DT>::to_f32(((const T*)a.bias)[col0 + j]));
-    if (a.scale) y = round_to_storage<DT>(__builtin_fmaf(y, a.scale[col0 + j], a.shift[col0 + j]));
-    if (a.residual) y = round_to_storage<DT>(y + Num<DT>::to_f32(((const T*)a.residual)[(size_t)row * a.res_stride + col0 + j]));
-    if (a.relu && y < 0.f) y = 0.f;
-    op[j] = Num<DT>::from_f32(y);
+    const unsigned raw = (unsigned)*(const uint16_t*)&p[j];
+    const unsigned b = a.bias ? (unsigned)((const uint16_t*)a.bias)[col0 + j] : 0u;
+    const unsigned r = a.residual ? (unsigned)((const uint16_t*)a.residual)[(size_t)row * a.res_stride + col0 + j] : 0u;
+    const float s0 = a.scale ? a.scale[col0 + j] : 1.f, h0 = a.scale ? a.shift[col0 + j] : 0.f;
+    const unsigned o = finish_pair<DT>(raw, a.bias != nullptr, b, a.scale != nullptr, s0, 1.f, h0, 0.f, a.residual != nullptr, r, a.relu != 0);
+    *(uint16_t*)&op[j] = (uint16_t)o;
   }
 }
 
@@ -389,13 +429,9 @@ struct WaveTile {
     Residual res;
     if (pre) res = *pre;
     else if (a.residual) load_residual(a, res);
-    float bv[8], sv[8], hv[8];
-    if (a.bias && col_ok) {
-      const u32x4 br = *(const u32x4*)((const T*)a.bias + col0);
-      const T* b = (const T*)&br;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = Num<DT>::to_f32(b[e]);
-    }
+    float sv[8], hv[8];
+    u32x4 bias16 = u32x4{0u, 0u, 0u, 0u};
+    if (a.bias && col_ok) bias16 = *(const u32x4*)((const T*)a.bias + col0);
     if (a.scale && col_ok) {
       const float4 s0 = *(const float4*)(a.scale + col0), s1 = *(const float4*)(a.scale + col0 + 4);
       const float4 h0 = *(const float4*)(a.shift + col0), h1 = *(const float4*)(a.shift + col0 + 4);
@@ -417,27 +453,8 @@ struct WaveTile {
         const int row = row0 + mt * 16 + r;
         if (col_ok && row < m) {
           const u32x4 raw = *(const u32x4*)(sc + r * RB + j * 16);
-          const T* v = (const T*)&raw;
-          float x[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = Num<DT>::to_f32(v[e]);
-          if (a.bias) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = round_to_storage<DT>(x[e] + bv[e]);
-          }
-          if (a.scale) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = round_to_storage<DT>(__builtin_fmaf(x[e], sv[e], hv[e]));
-          }
-          if (a.residual) {
-            const T* rv = (const T*)&res.v[mt][pass];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = round_to_storage<DT>(x[e] + Num<DT>::to_f32(rv[e]));
-          }
-          T o[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = Num<DT>::from_f32(a.relu && x[e] < 0.f ? 0.f : x[e]);
-          *(u32x4*)((T*)a.out + (size_t)row * a.out_stride + col0) = *(const u32x4*)o;
+          const u32x4 o = finish8<DT>(raw, a.bias != nullptr, bias16, a.scale != nullptr, sv, hv, a.residual != nullptr, res.v[mt][pass], a.relu != 0);
+          *(u32x4*)((T*)a.out + (size_t)row * a.out_stride + col0) = o;
         }
       }
     }

@@ -424,7 +424,10 @@ _SLAB_NARROW_SUBM = 3000256
 _SLAB_NARROW_STRIDED = 3000128
 _SORTED = os.environ.get("BEVAMD_SPCONV_SORTED", "1") != "0"          # sorted-key neighbour search on levels without a rank index
 _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and on those that have one (tuning)
-_SLAB_DEFAULT = {32: 2324410, 64: 1644222, 128: 1644220}
+# 32 channels from 4 frames: the filter-stationary kernel (spconv_slab_fstat.h; 64-row blocks, baked slots): 159 us isolated against 190
+# of the persistent register-ring kernel 2324410, 5.58-5.60 against 5.77-5.78 ms per 8-frame step on the same box (its results
+# agree with the other kernels' to fp32 rounding, not bit for bit: v_mfma_32x32x16 sums 16 channels per step)
+_SLAB_DEFAULT = {32: 4000112, 64: 1644222, 128: 1644220}
 _SLAB_DEFAULT_SMALL_BATCH = {32: 1322410}   # below 4 frames per step
 _SLAB_MIN_BATCH = {128: 4}
 # BEVAMD_SPCONV_SLAB_DIRECT=0: build the slab metadata from the int32 neighbour table instead of straight from the rank index

@@ -58,6 +58,8 @@ def run_gather(f, w, rb, **kw):
 
 def same_order(c, variant):
     """Variant code = KC*10000 + ...: rows staged whole (KC == Cin) keep the gather kernels' summation order."""
+    if variant >= 4000000:                                           # filter-stationary kernels: v_mfma_32x32x16 sums 16 channels per step
+        return False
     kc = (variant or sops.slab_variants(c)[0]) % 1000000 // 10000   # 1xxxxxx: the register-filter kernels, same KC field
     return kc == c
 
@@ -109,6 +111,58 @@ def test_block_metadata_matches_numpy(dev):
         assert np.median(hdr[:, :, 1][hdr[:, :, 1] > 0]) <= 1.5 * bm
 
 
+def test_baked_block_metadata_matches_numpy(dev):
+    """64-row blocks carry BAKED slots (spconv_slab_meta.h): entry = LDS byte offset of staged row s = (s + 1) * 64 with the bank
+    swizzle bits (((s + 1) >> 2) & 3) << 4 folded in, 0 = no neighbour; a range of more than 1022 rows keeps raw slots and sets
+    bit 30 of its row count."""
+    rng = np.random.default_rng(6)
+    for shape, dense, want_raw, n in (((24, 20, 9), (), False, 700), ((6, 60, 20), (2,), True, 100)):
+        ind = sorted_indices(rng, 1, shape, n, dense)
+        rb = spconv.build_rulebook(torch.from_numpy(ind).to(dev), 1, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, True)
+        nbr = rb.nbr.cpu().numpy()[:, : rb.num_out]
+        bm = 64
+        meta = sops.slab_build(rb.nbr, rb.num_out, None, bm)
+        nblk = (rb.num_out + bm - 1) // bm
+        hdr = meta.hdr.cpu().numpy().view(np.int32).reshape(-1)[: nblk * 6].reshape(nblk, 3, 2)
+        slots = meta.slots.cpu().numpy().view(np.uint16)[: nblk * 27 * bm].reshape(nblk, 27, bm)
+        saw_raw = False
+        for b in range(nblk):
+            rows = slice(b * bm, min((b + 1) * bm, rb.num_out))
+            for j in range(3):
+                v = nbr[9 * j: 9 * j + 9, rows]
+                got = slots[b, 9 * j: 9 * j + 9, : v.shape[1]]
+                if not (v >= 0).any():
+                    assert hdr[b, j, 1] == 0 and (got == 0).all()
+                    continue
+                lo, hi = v[v >= 0].min(), v[v >= 0].max()
+                cnt = hi - lo + 1
+                raw = (cnt + 1) * 64 > 0xFFFF
+                saw_raw |= raw
+                assert tuple(hdr[b, j]) == (lo, cnt | (0x40000000 if raw else 0))
+                e = v - lo + 1
+                want = np.where(v >= 0, v - lo, 0xFFFF) if raw else np.where(v >= 0, e * 64 | (((e >> 2) & 3) << 4), 0)
+                assert np.array_equal(got, want.astype(np.uint16))
+        assert saw_raw == want_raw
+
+
+@pytest.mark.parametrize("c", [32])
+def test_filter_stationary_kernels_on_raw_flagged_ranges(dev, c):
+    """A completely filled 60 x 20 x-plane: the kernel planes that look into it span > 1022 rows, their slots stay raw (HDR_RAW) and
+    the filter-stationary kernels take their general path for them, piece by piece."""
+    rng = np.random.default_rng(77)
+    f, w, rb, ref = make_case(rng, dev, c, torch.float16, B=1, shape=(6, 60, 20), n=100, dense_planes=(2,))
+    base = run_gather(f, w, rb)
+    fs = [v for v in sops.slab_variants(c) if v >= 4000000]
+    assert fs
+    for v in fs:
+        out, meta = run_slab(f, w, rb, variant=v)
+        nblk = (rb.num_out + 63) // 64
+        cnt = meta.hdr.cpu().numpy().view(np.int32).reshape(-1)[: nblk * 6].reshape(nblk, 3, 2)[:, :, 1]
+        assert (cnt & 0x40000000).any()
+        assert_close(out, ref, torch.float16)
+        assert_same(out, base, c, v)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("c", [32, 64, 128])
 def test_every_variant_vs_oracle_and_gather(dev, c, dtype):
@@ -137,8 +191,8 @@ def test_long_ranges_take_the_piece_loop(dev, c):
         out, meta = run_slab(f, w, rb, variant=v)
         bm = meta.block_rows
         nblk = (rb.num_out + bm - 1) // bm
-        cnt = meta.hdr.cpu().numpy().view(np.int32).reshape(-1)[: nblk * 6].reshape(nblk, 3, 2)[:, :, 1]
-        assert cnt.max() > 1.5 * bm, "the case must exercise multi-piece ranges"
+        cnt = meta.hdr.cpu().numpy().view(np.int32).reshape(-1)[: nblk * 6].reshape(nblk, 3, 2)[:, :, 1] & 0x3FFFFFFF
+        assert cnt.max() > (1.5 * bm if bm > 64 else 200), "the case must exercise multi-piece ranges"
         assert_close(out, ref, torch.float16)
         assert_same(out, base, c, v)
 
@@ -217,12 +271,19 @@ def test_persistent_kernels_walk_several_blocks_per_workgroup(dev, c, rows):
         meta = sops.slab_build(nbr, n, m_dev, bm)
         kw = dict(residual=res, relu=True, num_out_dev=m_dev)
         got = sops.sparse_conv_slab(f, img, meta, n, c, c, variant=v, out=torch.zeros_like(f), **kw)
-        twin = sops.sparse_conv_slab(f, img, meta, n, c, c, variant=v - 1000000, out=torch.zeros_like(f), **kw)
+        if v >= 4000000:   # filter-stationary: 64-row blocks of its own; the twin is the default register-filter kernel
+            tv = [x for x in sops.slab_variants(c) if 1000000 <= x < 2000000][0]
+            tmeta = sops.slab_build(nbr, n, m_dev, sops.slab_block_rows(c, tv))
+            twin = sops.sparse_conv_slab(f, img, tmeta, n, c, c, variant=tv, out=torch.zeros_like(f), **kw)
+            assert ulp_close(got, twin, 2)
+            twin = got
+        else:
+            twin = sops.sparse_conv_slab(f, img, meta, n, c, c, variant=v - 1000000, out=torch.zeros_like(f), **kw)
         assert torch.equal(got, twin)
         assert float(got[:live].float().abs().sum()) > 0 and float(got[live:].float().abs().sum()) == 0
 
 
-@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("bm", [64, 128, 256])
 def test_metadata_straight_from_the_index_equals_the_table_route(dev, bm):
     """bevamd_spconv_slab_build_from_index (27 lookups per row, no int32 table) writes the same (range, slots) as
     bevamd_spconv_neighbors + bevamd_spconv_slab_build: on a hash-indexed set in linear order, on the rank-indexed output of a
