@@ -64,7 +64,8 @@ def test_product_op_refuses_cpu_tensors():
 
 def test_host_side_tables_of_the_slab_kernels():
     """Pure host logic of the staged-rows convolution family: variant codes (LDS-filter, 1xxxxxx register-filter, 2xxxxxx
-    persistent), their block sizes, the 16-bit slot bound of a grid, the metadata sizes."""
+    persistent, 4xxxxxx filter-stationary: 32 channels, 64-row blocks with baked slots), their block sizes, the 16-bit slot bound of
+    a grid, the metadata sizes."""
     lib = _capi.load()
     for cin in (32, 64, 128):
         codes = (ctypes.c_int * 64)()
@@ -72,12 +73,14 @@ def test_host_side_tables_of_the_slab_kernels():
         got = [codes[i] for i in range(n)]
         assert n >= 3 and len(set(got)) == n
         regw = [v for v in got if 1000000 <= v < 2000000]
-        pers = [v for v in got if v >= 2000000]
+        pers = [v for v in got if 2000000 <= v < 3000000]
+        fstat = [v for v in got if v >= 4000000]
         assert regw and sorted(v + 1000000 for v in regw) == sorted(pers)      # every shape is built in both flavours
+        assert bool(fstat) == (cin == 32) and all(lib.bevamd_spconv_slab_block_rows(cin, v) == 64 for v in fstat)
         for v in got:
             rows = lib.bevamd_spconv_slab_block_rows(cin, v)
-            assert rows in (128, 256)
-            if v >= 1000000:                                                   # RW * 16 * MT from the code itself
+            assert rows in (128, 256) or v in fstat
+            if 1000000 <= v < 3000000:                                                   # RW * 16 * MT from the code itself
                 assert rows == (v // 100 % 10) * 16 * (v // 1000 % 10)
                 assert lib.bevamd_spconv_slab_block_rows(cin, v % 1000000 + 2000000) == rows   # the persistent twin: same blocks
         assert lib.bevamd_spconv_slab_block_rows(cin, 0) == lib.bevamd_spconv_slab_block_rows(cin, got[0])
@@ -87,6 +90,7 @@ def test_host_side_tables_of_the_slab_kernels():
     assert lib.bevamd_spconv_slab_grid_ok(shape, 256) == 1                     # 256 + 722 * 21 + 2 rows fit 16-bit slots
     wide = (ctypes.c_int * 3)(720, 4000, 21)
     assert lib.bevamd_spconv_slab_grid_ok(wide, 128) == 0
+    assert lib.bevamd_spconv_slab_block_rows(64, 4000112) == 0                 # the filter-stationary kernels exist for 32 channels only
     assert lib.bevamd_spconv_slab_hdr_bytes(1000, 128) == 8 * 3 * 8
     assert lib.bevamd_spconv_slab_slot_bytes(1000, 128) == 8 * 27 * 128 * 2
     assert lib.bevamd_spconv_slab_ablation_mask() == 0                         # shipped builds compile nothing out
