@@ -482,9 +482,18 @@ int bevamd_spconv_pad_cast_rows(const float* src, int n, int c, int pitch, int d
 /* Slab (staged-rows) forward for 3x3x3 SUBMANIFOLD convolutions over voxel sets whose rows are in ascending linear index
  * ((b*X + x)*Y + y)*Z + z — every set a strided convolution produced (the reference's CUDA row order, spconv_ops.h:130).
  * Same operator, epilogue and results as bevamd_spconv_conv_forward_tiled (sparse_conv_ext.indice_conv_half, all.cc:30-33 ->
- * spconv_ops.h:260-361 with subM = 1), cin == cout in {32, 64, 128}; bit-identical to it for cin <= 64.  Instead of gathering
+ * spconv_ops.h:260-361 with subM = 1), cin == cout in {32, 64, 128}; bit-identical to it for cin <= 64, except the
+ * filter-stationary 32-channel variants (codes 4xxxxxx, csrc/spconv_slab_fstat.h: v_mfma_32x32x16 reduces 16 channels per
+ * instruction, the fp32 sums associate differently; equal within 2 units of the 16-bit result's last place).  Instead of gathering
  * 19-27 neighbour rows per output row through the texture path, a workgroup copies the ~9 contiguous input ranges its block
  * of rows reads (one per kernel line (kx, ky)) into LDS and feeds the MFMAs from there (csrc/spconv_slab.h).
+ * Block sizes: 128 | 256 rows with raw 16-bit slots (0xFFFF = no neighbour); 64 rows = the BAKED format of the filter-
+ * stationary kernels: a slot is the LDS byte offset of staged row s, (s + 1) * 64 | (((s + 1) >> 2) & 3) << 4, 0 = none; a
+ * range of more than 1022 rows keeps raw slots and sets bit 30 of its row count (csrc/spconv_slab_meta.h).
+ * Epilogue arithmetic of every 16-bit kernel (csrc/spconv_tile.h: finish_pair): the conv result, bias add, folded BatchNorm,
+ * residual add and ReLU each round once, as the stored 16-bit tensors of the unfused reference pipeline do — fp16: packed half
+ * adds (the reference's own half add), fp32 fma rounded to half, ReLU = "sign bit set -> +0" (a NaN with a clear sign bit stays
+ * a NaN).
  *   bevamd_spconv_slab_block_rows(cin, variant)   rows per block of a variant (0 = default variant; returns 0 if not built)
  *   bevamd_spconv_slab_variants(cin, codes, n)     the variant codes built for cin (tuning sweeps)
  *   bevamd_spconv_slab_grid_ok(shape, block_rows)  1 if ranges on this [X, Y, Z] grid always fit the 16-bit slots
