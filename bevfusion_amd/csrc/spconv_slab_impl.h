@@ -36,6 +36,13 @@ static inline void raise_lds_limit(PerDevice& pd, K kern, int bytes) {
   (void)hipGetLastError();
   pd.raised[dev] = 1;
 }
+// tuning knob (percent of the resident workgroups a persistent grid is sized to; default 100): BEVAMD_SLAB_GRID_PCT
+static inline long long persistent_cap(int wg_per_xcd) {
+  static int pct = -1;
+  if (pct < 0) { const char* e = getenv("BEVAMD_SLAB_GRID_PCT"); pct = e ? atoi(e) : 100; if (pct < 10 || pct > 100) pct = 100; }
+  const long long c = (long long)wg_per_xcd * pct / 100;
+  return c < 1 ? 1 : c;
+}
 constexpr int SMALL_BASE = 3000000;   // variant codes of the narrow-row kernels: SMALL_BASE + rows per block
 static inline int small_block_rows(int cinp, int variant) {
   if (cinp != 8 && cinp != 16) return 0;
@@ -137,7 +144,7 @@ static int run_p(const SlabArgs& sa, hipStream_t stream) {
   if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
   const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
   long long gx = (nblk + 7) / 8;
-  if (gx > wg_per_xcd) gx = wg_per_xcd;
+  if (gx > persistent_cap(wg_per_xcd)) gx = persistent_cap(wg_per_xcd);
   kern<<<dim3((unsigned)(gx * 8)), dim3(P::NW * 64), P::BYTES, stream>>>(sa);
   BEVAMD_LAUNCH_CHECK("spconv_slabp");
   return BEVAMD_OK;
@@ -189,7 +196,7 @@ static int run_f(const SlabArgs& sa, hipStream_t stream) {
   if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
   const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
   long long gx = (nblk + 7) / 8;
-  if (gx > wg_per_xcd) gx = wg_per_xcd;
+  if (gx > persistent_cap(wg_per_xcd)) gx = persistent_cap(wg_per_xcd);
   kern<<<dim3((unsigned)(gx * 8)), dim3(64), P::BYTES, stream>>>(sa);
   BEVAMD_LAUNCH_CHECK("spconv_slabf");
   return BEVAMD_OK;
@@ -230,7 +237,7 @@ static int run_s(const SlabArgs& sa, hipStream_t stream) {
   if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
   const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
   long long gx = (nblk + 7) / 8;
-  if (gx > wg_per_xcd) gx = wg_per_xcd;
+  if (gx > persistent_cap(wg_per_xcd)) gx = persistent_cap(wg_per_xcd);
   kern<<<dim3((unsigned)(gx * 8)), dim3(NW * 64), P::BYTES, stream>>>(sa);
   BEVAMD_LAUNCH_CHECK("spconv_slabs");
   return BEVAMD_OK;
