@@ -51,14 +51,21 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed number of frames per step for the WHOLE job, split over the ranks with sharding.frames_for_rank "
                          "(strong scaling); default 0 = --batch frames on every GPU (weak scaling)")
-    ap.add_argument("--overlap", choices=["voxel", "head", "lidar", "none"], default="none",
-                    help="none (default): camera stages, then the whole LiDAR branch, back to back; voxel: only the voxelizer (22 "
+    ap.add_argument("--overlap", choices=["pipeline", "voxel", "head", "lidar", "none"], default="none",
+                    help="none (default): camera stages, then the whole LiDAR branch, back to back; pipeline: the stages of the two "
+                         "independent branches interleaved so that each HBM-bound camera kernel has at most a light partner: bev_pool "
+                         "runs first with only the voxelizer beside it (second HIP stream), the rulebook chain "
+                         "(SparseEncoder.prepare_geometry) starts when bev_pool has finished and runs beside the depth raster and the "
+                         "fused pooling, the convolutions follow after the join and run alone (measured at the end of round 3: 5.51-5.52 against 5.55 ms — "
+                         "even the voxelizer alone costs bev_pool 24 %, 1.27 against 1.03 ms; not a gain); voxel: only the voxelizer (22 "
                          "short dependent launches, 0.3 ms) runs on a second HIP stream beside the depth raster / fused pooling stages — it is "
-                         "done long before bev_pool starts, whose roofline figure stays clean — and the encoder follows after the join; "
+                         "done long before bev_pool starts, whose roofline figure stays clean — and the encoder follows after the join (5.34-5.38 "
+                         "against 5.42-5.47 ms: the raster and the fused pooling pay 0.17 ms for the 0.3 ms hidden); "
                          "head: the LiDAR branch's head — "
                          "voxelization + the whole rulebook chain (SparseEncoder.prepare_geometry) — runs on a second HIP stream beside the "
-                         "camera stages and the convolutions follow after the join (measured: 7.58 vs 7.74 ms per 8-frame step, the camera "
-                         "kernels slow down by what the head saves and bev_pool drops from 0.61 to 0.50 of the HBM peak — not the default); "
+                         "camera stages and the convolutions follow after the join (round 3: 5.23-5.33 against 5.42-5.55 ms per 8-frame step — the 21 "
+                         "convolutions then run alone in 2.87 ms — but the camera kernels pay 0.66 ms of it and bev_pool drops from 0.64 to "
+                         "0.42 of the HBM peak: the default keeps the branches apart and that figure clean); "
                          "lidar: the WHOLE LiDAR branch (one HIP graph) runs on a second stream beside the camera stages, which is how the "
                          "two independent branches of the model can be scheduled; stage times then overlap and the bev_pool roofline figure "
                          "is measured WITH that concurrency")
@@ -717,6 +724,7 @@ def main():
 
     overlap_head = args.overlap == "head" and sp_dtype != torch.float32 and not args.no_graph
     overlap_voxel = args.overlap == "voxel" and sp_dtype != torch.float32 and not args.no_graph
+    overlap_pipe = args.overlap == "pipeline" and sp_dtype != torch.float32 and not args.no_graph
 
     def lidar_head():
         """coordinates only: voxelize + mean, then the encoder's whole rulebook chain (hash, active sets, neighbour tables, slab
@@ -742,9 +750,14 @@ def main():
         lidar_head = voxel_head
         overlap_head = True   # same fork / join around the camera stages, a shorter head
 
+    def geometry_head(vf, vc, cnt, _):
+        with torch.no_grad():
+            return vf, vc, cnt, enc.prepare_geometry(vc, B, num_voxels=cnt, coors_order=coors_order)
+
     graph = graph_head = graph_tail = None
     overlap_lidar = args.overlap == "lidar" and not args.no_graph
-    head_stream = torch.cuda.Stream() if (overlap_head or overlap_lidar) else None
+    head_stream = torch.cuda.Stream() if (overlap_head or overlap_lidar or overlap_pipe) else None
+    graph_vox = graph_geo = None
     if not args.no_graph:
         # the LiDAR branch has no host sync: capture it once, replay it per frame (HIP graph, one launch)
         side = torch.cuda.Stream()
@@ -752,11 +765,25 @@ def main():
         with torch.cuda.stream(side):
             if overlap_head:
                 lidar_tail(*lidar_head())
+            elif overlap_pipe:
+                lidar_tail(*geometry_head(*voxel_head()))
             else:
                 lidar_branch()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if overlap_head:
+        if overlap_pipe:
+            graph_vox = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_vox):
+                state["vox"] = voxel_head()
+            graph_geo = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_geo, pool=graph_vox.pool()):
+                state["head"] = geometry_head(*state["vox"])
+            graph_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_tail, pool=graph_vox.pool()):
+                state["lidar_bev"] = lidar_tail(*state["head"])
+            state["n_voxels_dev"] = state["head"][2]
+            assert enc.last_path == "fused", enc.last_path_reason
+        elif overlap_head:
             graph_head = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_head):
                 state["head"] = lidar_head()
@@ -825,9 +852,42 @@ def main():
               "voxelize_mean + sparse_encoder" if not overlap_head else
               ("join + sparse_encoder (the voxelizer ran beside the first camera stages on a second stream)" if overlap_voxel else
                "join + sparse_encoder convolutions (voxelize + rulebooks ran beside the camera stages on a second stream)")]
+    if overlap_pipe:
+        STAGES = ["bev_pool_forward_cells (voxelizer beside it on a second stream)",
+                  "depth_raster (rulebook chain beside it)", "fused_depth_context_pool (rulebook chain beside it)",
+                  "join + sparse_encoder convolutions"]
     NSTAGE = len(STAGES)
+    bp_done = torch.cuda.Event() if overlap_pipe else None
+
+    def step_pipeline(ev=None):
+        main_stream = torch.cuda.current_stream()
+        head_stream.wait_stream(main_stream)                                  # fork
+        with torch.cuda.stream(head_stream):
+            graph_vox.replay()                                                # LiDAR: voxelizer, beside bev_pool
+        if ev:
+            ev[0].record()
+        plan.launch_forward(feats, bev)                                       # the API-level bev_pool op (one kernel; roofline)
+        bp_done.record(main_stream)
+        if ev:
+            ev[1].record()
+        with torch.cuda.stream(head_stream):
+            head_stream.wait_event(bp_done)
+            graph_geo.replay()                                                # LiDAR: rulebook chain, beside raster + fused pooling
+        with torch.no_grad():
+            state["depth_img"] = vt.depth_raster(img_stub, pts_list, t_l2i, t_ia, t_la)
+        if ev:
+            ev[2].record()
+        plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
+        if ev:
+            ev[3].record()
+        main_stream.wait_stream(head_stream)                                  # join
+        graph_tail.replay()                                                   # LiDAR: the 21 convolutions + dense tail, alone
+        if ev:
+            ev[4].record()
 
     def step(ev=None):
+        if overlap_pipe:
+            return step_pipeline(ev)
         main_stream = torch.cuda.current_stream()
         if overlap_head:   # fork: LiDAR head on its own stream, underneath the camera stages
             head_stream.wait_stream(main_stream)
@@ -876,6 +936,8 @@ def main():
     stage_ms = [float(np.mean([e[s].elapsed_time(e[s + 1]) for e in evs])) for s in range(NSTAGE)]
     state["n_voxels"] = int(state["n_voxels_dev"].reshape(-1)[0])
     assert tuple(state["lidar_bev"].shape) == (B, 256, 180, 180)
+    if overlap_pipe:   # report in the canonical order (raster, fused pooling, bev_pool, LiDAR)
+        stage_ms = [stage_ms[1], stage_ms[2], stage_ms[0], stage_ms[3]]
     kern_ms = stage_ms[2]  # the bev_pool stage is exactly one kernel launch
     fused_ms = stage_ms[1]
 
@@ -944,7 +1006,10 @@ def main():
                 "lidar_branch_eager_ms": {"voxelize": eager_vox_ms, "sparse_encoder": eager_enc_ms},
                 "hip_graph": graph is not None or graph_tail is not None,
                 "voxel_order": args.voxel_order,
-                "overlap": ("voxel: the voxelizer on a second HIP stream beside the depth raster / fused pooling stages (finished before "
+                "overlap": ("pipeline: bev_pool first with the voxelizer beside it (second HIP stream), then depth raster + fused pooling with "
+                            "the rulebook chain beside them, then the convolutions alone (stage_ms in the canonical order; `stages` names "
+                            "the execution order)") if overlap_pipe else
+                           ("voxel: the voxelizer on a second HIP stream beside the depth raster / fused pooling stages (finished before "
                             "bev_pool starts); the encoder, rulebook chain included, follows after the join") if overlap_voxel else
                            ("head: voxelization + rulebook chain on a second HIP stream beside the camera stages (the camera stage times, "
                             "bev_pool's roofline figure included, are measured WITH that concurrency)") if overlap_head else
