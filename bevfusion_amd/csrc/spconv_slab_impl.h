@@ -36,10 +36,11 @@ static inline void raise_lds_limit(PerDevice& pd, K kern, int bytes) {
   (void)hipGetLastError();
   pd.raised[dev] = 1;
 }
-// tuning knob (percent of the resident workgroups a persistent grid is sized to; default 100): BEVAMD_SLAB_GRID_PCT
+// tuning knob (percent of the resident workgroups a persistent grid is sized to; default 100; > 100 = oversubscribed: workgroups
+// that start late take over from finished ones instead of becoming stragglers): BEVAMD_SLAB_GRID_PCT
 static inline long long persistent_cap(int wg_per_xcd) {
   static int pct = -1;
-  if (pct < 0) { const char* e = getenv("BEVAMD_SLAB_GRID_PCT"); pct = e ? atoi(e) : 100; if (pct < 10 || pct > 100) pct = 100; }
+  if (pct < 0) { const char* e = getenv("BEVAMD_SLAB_GRID_PCT"); pct = e ? atoi(e) : 100; if (pct < 10 || pct > 1600) pct = 100; }
   const long long c = (long long)wg_per_xcd * pct / 100;
   return c < 1 ? 1 : c;
 }
