@@ -3,7 +3,7 @@
 // What bounds the register-ring kernels (spconv_slab_regw.h / _persist.h) on the 32-channel layers, measured on experiment
 // builds (tools/time_slab_variant.py, 8 frames, 2.08 M rows, 191 us; the MFMA work is 46 us): slot -> LDS address arithmetic
 // 23 us, the per-tap filter loads 40 us, row + slot staging 60 us, the epilogue 50 us; the ds_read_b128 fragment reads and the
-// MFMAs themselves are free (compiling either out changes nothing).  Counters (profiles/r03_slab32_pmc.txt): a wave issues
+// MFMAs themselves are free (compiling either out changes nothing).  Counters (profiles/r03_slab32_pmc.txt, r03_slab32_experiments.txt): a wave issues
 // 9 instructions per MFMA and a SIMD can start one instruction of a wave every ~4 cycles, so with 2 waves per SIMD the
 // 16-cycle MFMA can be at most ~1/3 busy — the kernels are ISSUE-bound, and 2/3 of what goes through the vector-memory pipe is
 // the filter (27 taps x 2 KiB x 4 waves per 256 rows).
