@@ -197,20 +197,47 @@ def test_long_ranges_take_the_piece_loop(dev, c):
         assert_same(out, base, c, v)
 
 
-def test_isolated_voxels_empty_lines_and_tiny_sets(dev):
+@pytest.mark.parametrize("c", [32, 64])
+def test_isolated_voxels_empty_lines_and_tiny_sets(dev, c):
     rng = np.random.default_rng(3)
     for n in (1, 7, 130):                                         # far apart: only the centre plane has rows
         shape = (40, 40, 20)
         lin = np.sort(rng.choice(np.arange(0, 40 * 40 * 20, 97), size=n, replace=False))
         ind = np.concatenate([np.zeros((n, 1), np.int64), np.stack(np.unravel_index(lin, shape), 1)], 1).astype(np.int32)
         oi, opairs, onum, _ = oracle.get_indice_pairs(ind, 1, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
-        w = torch.from_numpy((rng.standard_normal((3, 3, 3, 64, 64)) * 0.05).astype(np.float32)).half()
-        f = torch.from_numpy(rng.standard_normal((n, 64)).astype(np.float32)).half()
+        w = torch.from_numpy((rng.standard_normal((3, 3, 3, c, c)) * 0.05).astype(np.float32)).half()
+        f = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).half()
         ref = oracle.indice_conv(f.float().numpy(), w.float().numpy(), opairs, onum, n)
         rb = spconv.build_rulebook(torch.from_numpy(ind).to(dev), 1, list(shape), [3, 3, 3], [1, 1, 1], [1, 1, 1], 1, True)
-        for v in sops.slab_variants(64):
+        for v in sops.slab_variants(c):
             out, _ = run_slab(f.to(dev), w.to(dev), rb, variant=v)
             assert_close(out, ref, torch.float16)
+
+
+def test_row_pitches_wider_than_the_channel_count(dev):
+    """Features, output and residual as column slices of wider tensors (pitch 48 / 40 / 56 elements for 32 channels): the
+    filter-stationary kernel stages and stores by PITCH (LDS-DMA source offsets, 16-byte row stores); bias + BatchNorm + residual +
+    ReLU; bf16 as well."""
+    rng = np.random.default_rng(21)
+    c = 32
+    for dtype in (torch.float16, torch.bfloat16):
+        f, w, rb, _ = make_case(rng, dev, c, dtype, n=900)
+        m = rb.num_out
+        wide_f = torch.zeros((f.shape[0], 48), dtype=dtype, device=dev)
+        wide_f[:, :c] = f
+        wide_r = torch.randn((m, 40), device=dev).to(dtype)
+        bias = torch.randn(c, device=dev).to(dtype)
+        scale, shift = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+        kw = dict(bias=bias, bn_scale=scale, bn_shift=shift, relu=True)
+        base = run_gather(f, w, rb, residual=wide_r[:, :c].contiguous(), **kw)
+        for v in [x for x in sops.slab_variants(c) if x >= 4000000]:
+            wide_o = torch.full((m, 56), 3.0, dtype=dtype, device=dev)
+            meta = sops.slab_build(rb.nbr, m, None, sops.slab_block_rows(c, v))
+            out = sops.sparse_conv_slab(wide_f[:, :c], sops.make_filter_image(w), meta, m, c, c, variant=v, residual=wide_r[:, :c],
+                                        out=wide_o[:, :c], **kw)
+            assert out.data_ptr() == wide_o.data_ptr() and out.stride(0) == 56
+            assert ulp_close(out, base, 2)
+            assert torch.all(wide_o[:, c:] == 3.0)                    # nothing written past the 32 channels of a row
 
 
 @pytest.mark.parametrize("c", [32, 128])
