@@ -8,6 +8,9 @@ Reference interface reproduced here (same names, argument order, shapes):
 MI355X-native additions: `BevPoolPlan` (the rank/sort/interval precompute as a cached,
 sync-free device object) and the indexed kernels that read features through the sort
 permutation instead of materialising `feats[indices]`.
+
+Host tensors: `bev_pool()` runs the reference's device-agnostic `QuickCumsum` formulation (bev_pool.py:8-34) in torch —
+BASELINE configs[0], plumbing on a box without a GPU.  It is not a fallback: GPU tensors go through the HIP library or raise.
 """
 import os
 
@@ -15,7 +18,7 @@ import torch
 
 from . import _capi
 
-__all__ = ["bev_pool", "bev_pool_ext", "QuickCumsumCuda", "BevPoolPlan"]
+__all__ = ["bev_pool", "bev_pool_ext", "QuickCumsum", "QuickCumsumCuda", "BevPoolPlan"]
 
 
 _FUSED_SCHEDULE = os.environ.get("BEVAMD_FUSED_POOL_SCHEDULE", "1") != "0"   # 0: frame-major walk over all XCDs
@@ -74,6 +77,49 @@ class _BevPoolExt:
 
 
 bev_pool_ext = _BevPoolExt()
+
+
+class QuickCumsum(torch.autograd.Function):
+    """The reference's device-agnostic formulation (bev_pool.py:8-34), the only form of the op it can run without its
+    extension: rows sorted by rank in, one row per rank out — prefix sum over the rows, keep the LAST row of every run of equal
+    ranks, difference of consecutive kept prefix sums.  Pure torch; this is what `bev_pool()` runs for HOST tensors (BASELINE
+    configs[0]: plumbing on a box without a GPU).  GPU tensors never come here: they go through the HIP library or fail.
+
+    One deviation, on purpose: the prefix sum is carried in float64 (a 300 k-row fp32 prefix sum differenced back loses ~1e-3
+    of a cell's value) and the interval sums are rounded to the input dtype at the end."""
+
+    @staticmethod
+    def forward(ctx, x, geom_feats, ranks):
+        last_of_run = torch.ones(x.shape[0], device=x.device, dtype=torch.bool)
+        last_of_run[:-1] = ranks[1:] != ranks[:-1]
+        prefix = x.to(torch.float64).cumsum(0)[last_of_run]
+        sums = prefix.clone()
+        sums[1:] -= prefix[:-1]
+        geom_out = geom_feats[last_of_run]
+        ctx.save_for_backward(last_of_run)
+        ctx.mark_non_differentiable(geom_out)
+        return sums.to(x.dtype), geom_out
+
+    @staticmethod
+    def backward(ctx, grad_sums, grad_geom):
+        (last_of_run,) = ctx.saved_tensors
+        # row i belongs to the interval that closes at the first kept row >= i: count the kept rows strictly before i
+        interval_of_row = torch.cumsum(last_of_run, 0) - last_of_run.to(torch.int64)
+        return grad_sums[interval_of_row], None, None
+
+
+def _bev_pool_host(feats, coords, B, D, H, W):
+    """`bev_pool()` for host tensors: rank -> argsort -> QuickCumsum -> dense scatter (bev_pool.py:83-97 with the device-agnostic
+    reduction in place of the extension call).  -> [B, C, D, H, W], differentiable w.r.t. feats."""
+    coords = coords.long()
+    ranks = coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B) + coords[:, 2] * B + coords[:, 3]
+    order = ranks.argsort(stable=True)
+    feats, coords, ranks = feats[order], coords[order], ranks[order]
+    out = feats.new_zeros((B, D, H, W, feats.shape[1]))
+    if feats.shape[0]:
+        sums, cells = QuickCumsum.apply(feats, coords, ranks)
+        out = out.index_put((cells[:, 3], cells[:, 2], cells[:, 0], cells[:, 1]), sums)
+    return out.permute(0, 4, 1, 2, 3).contiguous()
 
 
 class QuickCumsumCuda(torch.autograd.Function):
@@ -360,6 +406,12 @@ def bev_pool(feats, coords, B, D, H, W, plan=None, channels_last_view=False):
     """
     assert feats.shape[0] == coords.shape[0]
     B, D, H, W = int(B), int(D), int(H), int(W)
+    if not feats.is_cuda and not coords.is_cuda:
+        # host tensors: the reference's device-agnostic QuickCumsum pipeline in torch (BASELINE configs[0]); never a fallback for
+        # GPU tensors — those need the HIP library
+        if plan is not None:
+            raise RuntimeError("bev_pool: a BevPoolPlan is a GPU object; host tensors take the torch QuickCumsum route")
+        return _bev_pool_host(feats, coords, B, D, H, W)
     if plan is None:
         plan = BevPoolPlan.from_coords(coords, B, D, H, W)
     x = plan.forward(feats)

@@ -2,7 +2,7 @@
 
 hipcc cross-compiles without a GPU.  The library has a plain C ABI
 (include/bevfusion_amd.h) and links only against the HIP runtime: no torch,
-no pybind.  Objects are rebuilt only when their sources are newer.
+no pybind.  Objects are rebuilt only when their sources (the unit and the headers its depfile lists) are newer.
 
     python -m bevfusion_amd.build [--force] [--verbose] [--profiling]
 
@@ -49,11 +49,26 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(obj, src):
+    """Prerequisites of `obj`: what hipcc's own depfile of the last build lists (the headers this unit really includes), every
+    header of csrc/ when there is none yet."""
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(dep):
+        return [src] + _headers()
+    with open(dep) as fh:
+        words = fh.read().replace("\\\n", " ").split()
+    files = [w for w in words[1:] if w.startswith(CSRC)]
+    if any(not os.path.exists(f) for f in files):
+        return None          # a header was removed or renamed: stale
+    return [src] + files
+
+
 def _compile_one(src, force, verbose, extra=()):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-    if not force and not _newer(obj, [src] + _headers()):
+    deps = _deps(obj, src)
+    if not force and deps is not None and not _newer(obj, deps):
         return obj, False
-    cmd = [HIPCC] + CFLAGS + list(extra) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + CFLAGS + list(extra) + ["-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

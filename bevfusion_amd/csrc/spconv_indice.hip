@@ -767,14 +767,22 @@ __global__ __launch_bounds__(256) void sp_sorted_keys_kernel(const int* __restri
   const int bx = c.x * g.in_shape[0] + c.y;
   const uint32_t key = ((uint32_t)bx * (uint32_t)g.in_shape[1] + (uint32_t)c.z) * (uint32_t)g.in_shape[2] + (uint32_t)c.w;
   keys[i] = key;
+  // a coordinate outside the grid breaks the promise just like an unsorted row does (the key arithmetic above wraps)
+  bool bad = c.x < 0 || c.x >= g.batch || c.y < 0 || c.y >= g.in_shape[0] || c.z < 0 || c.z >= g.in_shape[1] || c.w < 0 ||
+             c.w >= g.in_shape[2];
   int prev = -1;
   if (i > 0) {
     const int4 p = ((const int4*)indices)[i - 1];
     prev = p.x * g.in_shape[0] + p.y;
     const uint32_t pk = ((uint32_t)prev * (uint32_t)g.in_shape[1] + (uint32_t)p.z) * (uint32_t)g.in_shape[2] + (uint32_t)p.w;
-    if (pk >= key && status) atomicOr(status, 2);
+    bad = bad || pk >= key;
   }
-  const int top = bx < nplanes ? bx : nplanes;   // a coordinate outside the grid cannot run past the directory
+  if (bad && status) atomicOr(status, 2);
+  // Directory writes stay inside [0, nplanes] whatever the coordinates hold.  With a broken promise some entries may stay
+  // unwritten (prev > top): readers clamp what they load (sp_slab_from_sorted_kernel), so the result is wrong (and flagged:
+  // status bit 1), never a fault.
+  prev = prev < -1 ? -1 : prev > nplanes ? nplanes : prev;
+  const int top = bx < -1 ? -1 : bx < nplanes ? bx : nplanes;
   for (int j = prev + 1; j <= top; ++j) xstart[j] = i;
   if (i == n - 1)
     for (int j = top + 1; j <= nplanes; ++j) xstart[j] = n;
@@ -800,7 +808,7 @@ template <int BM, bool SUBM>
 __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __restrict__ out_indices, int m_cap,
                                                                  const int* __restrict__ m_dev, ConvGeom g,
                                                                  const uint32_t* __restrict__ in_keys,
-                                                                 const int* __restrict__ in_xstart,
+                                                                 const int* __restrict__ in_xstart, int in_n_cap,
                                                                  int2* __restrict__ hdr, uint16_t* __restrict__ slots,
                                                                  int* __restrict__ status) {
   int m = m_dev ? *m_dev : m_cap;
@@ -823,10 +831,14 @@ __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __re
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
     const int x = x0 + kx;
-    if (!(win && x >= 0 && x < X)) continue;
+    if (!(win && x >= 0 && x < X && c.x >= 0 && c.x < g.batch)) continue;
     const int bx = c.x * X + x;
+    // Clamped to the key array: a directory built from rows that were NOT in linear order (status bit 1 of the index) may hold
+    // anything in the entries it never wrote; the search below must not leave in_keys[0, in_n_cap).
     int q = in_xstart[bx];
-    const int hi = in_xstart[bx + 1];
+    int hi = in_xstart[bx + 1];
+    q = q < 0 ? 0 : q;
+    hi = hi > in_n_cap ? in_n_cap : hi;
     if (q >= hi) continue;
     const uint32_t plane = (uint32_t)bx * (uint32_t)Y * (uint32_t)Z;
     const uint32_t kmax = plane + (uint32_t)(yhi * Z + zhi);
@@ -1171,7 +1183,7 @@ int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, cons
   const int* xstart = (const int*)((const char*)in_index + align_up((size_t)(in_n_cap > 0 ? in_n_cap : 1) * 4, 256));
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;
 #define BEVAMD_GO(BM, SUBM) \
-  sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, (int2*)hdr, (uint16_t*)slots, status)
+  sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, in_n_cap, (int2*)hdr, (uint16_t*)slots, status)
   if (block_rows == 64) { if (subm) BEVAMD_GO(64, true); else BEVAMD_GO(64, false); }
   else if (block_rows == 128) { if (subm) BEVAMD_GO(128, true); else BEVAMD_GO(128, false); }
   else { if (subm) BEVAMD_GO(256, true); else BEVAMD_GO(256, false); }

@@ -77,8 +77,8 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // (`raw`), through bias add, folded BatchNorm, residual add and ReLU — each a stored 16-bit tensor in the unfused reference
 // pipeline, so each rounds once.  fp16 runs on packed halves: the adds are v_pk_add_f16 (the reference's own half add: one
 // rounding from the exact sum), BatchNorm is an fp32 fma rounded to half (kept opaque so that no v_fma_mix fuses the two
-// roundings), ReLU clears the halves whose sign bit is set (integer: a NaN with a clear sign bit — what the hardware's own
-// invalid operations produce — stays a NaN, as in the reference).  4-5 VALU instructions per channel instead of 14: measured
+// roundings), ReLU clears the halves that are negative and not a NaN (integer test; NaNs of either sign pass through, as in the
+// reference's torch ReLU).  4-5 VALU instructions per channel instead of 14: measured
 // 25-50 us of the 170-190 us 32-channel layers went into this tail.  bf16 has no packed arithmetic and keeps fp32 steps.
 template <int DT>
 __device__ __forceinline__ unsigned finish_pair(unsigned raw, bool has_bias, unsigned bias, bool has_scale, float s0, float s1, float h0, float h1,
@@ -94,8 +94,12 @@ __device__ __forceinline__ unsigned finish_pair(unsigned raw, bool has_bias, uns
     }
     if (has_res) y = y + __builtin_bit_cast(f16x2, res);
     if (relu) {
+      // a half is cleared when it is negative and NOT a NaN: as a signed integer that is b <= -1024 (0xFC00 = -inf; the negative
+      // NaNs are -1023 .. -1), i.e. the saturating b + 1023 is negative.  torch's ReLU keeps NaNs of either sign, so does this.
       const s16x2 b = __builtin_bit_cast(s16x2, y);
-      y = __builtin_bit_cast(f16x2, (s16x2)(b & ~(b >> 15)));
+      s16x2 m = __builtin_elementwise_add_sat(b, (s16x2){1023, 1023}) >> 15;
+      asm volatile("" : "+v"(m));   // keeps v_pk_add_i16 clamp + v_pk_ashrrev_i16 (hipcc otherwise splits the halves into compares)
+      y = __builtin_bit_cast(f16x2, (s16x2)(b & ~m));
     }
     return __builtin_bit_cast(unsigned, y);
   } else {
@@ -108,7 +112,7 @@ __device__ __forceinline__ unsigned finish_pair(unsigned raw, bool has_bias, uns
       if (has_scale) x = round_to_storage<DT>(__builtin_fmaf(x, sv[e], hv[e]));
       if (has_res) x = round_to_storage<DT>(x + Num<DT>::to_f32((T)(res >> (16 * e))));
       const unsigned h = (unsigned)Num<DT>::from_f32(x);
-      o |= (relu && (h & 0x8000u) ? 0u : h) << (16 * e);   // sign bit set -> +0: the fp16 path's rule
+      o |= (relu && (h - 0x8000u) <= 0x7F80u ? 0u : h) << (16 * e);   // negative and not a NaN (0x8000 .. 0xFF80) -> +0
     }
     return o;
   }

@@ -66,8 +66,9 @@ class Level:
     Buffers are allocated by the caller's (current-stream) allocator; `run_encoder` joins the two streams before it
     returns, so their reuse stays ordered."""
 
-    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False, status_pool=None):
+    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False, status_pool=None, allow_slab=True):
         self.indices = indices
+        self.allow_slab = bool(allow_slab)   # False: every layer of this chain of levels stays on the gather kernels
         # device status words of the products built for this chain of levels: slices of ONE zeroed tensor (a separate
         # torch.zeros(1) per product put ten 5-us fill kernels in front of the first convolution); [pool, next free]
         self._status_pool = status_pool
@@ -275,7 +276,8 @@ class Level:
                                               _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.ptr(nbr), cap,
                                               self._stream_ptr())
         _capi.check(rc, "spconv_downsample")
-        out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream, status_pool=self._status_pool)
+        out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream, status_pool=self._status_pool,
+                    allow_slab=self.allow_slab)
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
         out.linear_order = True
         out.ready = self._mark()    # behind the downsample: indices, count, rank index and this conv's nbr are final
@@ -472,11 +474,12 @@ _GATHER_SLOTS = os.environ.get("BEVAMD_SPCONV_GATHER_SLOTS", "0") == "1"
 def _gather_reads_slots(conv, lvl):
     """Strided 3x3x3 layers left on the gather kernels (32 -> 64, 64 -> 128: their input ranges are too long to stage) read slot
     metadata built by sorted-key search from the input level instead of an int32 table that has to be cleared and scattered."""
-    return (_GATHER_SLOTS and _SORTED and not conv.subm and tuple(conv.kernel_size) == (3, 3, 3) and lvl.linear_order)
+    return (_GATHER_SLOTS and _SORTED and lvl.allow_slab and not conv.subm and tuple(conv.kernel_size) == (3, 3, 3)
+            and lvl.linear_order)
 
 
 def _slab_variant_for(conv, lvl, cin, cout):
-    if os.environ.get("BEVAMD_SPCONV_SLAB", "1") == "0":
+    if os.environ.get("BEVAMD_SPCONV_SLAB", "1") == "0" or not lvl.allow_slab:
         return None
     if tuple(conv.kernel_size) != (3, 3, 3) or not lvl.linear_order:
         return None
@@ -576,7 +579,7 @@ def encoder_supported(enc, voxel_features):
 
 
 @torch.no_grad()
-def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None):
+def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None, allow_slab=True):
     """Everything of `run_encoder` that depends on voxel COORDINATES only — hash index, every level's active set, neighbour
     tables, slab metadata — issued on the current stream (and finished there: the geometry stream, if any, is joined back).
     Returns the level-1 `Level` holding the products; pass it to `SparseEncoder.forward(..., geometry=level)` /
@@ -595,7 +598,8 @@ def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None):
     pool = [torch.zeros(_STATUS_WORDS, dtype=torch.int32, device=dev), 0] if _STATUS_POOL else None   # zeroed BEFORE the fork: ordered ahead of both streams
     if g is not None:
         g.wait_stream(main)
-    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool)
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool,
+                allow_slab=allow_slab)
     try:
         prefetch_geometry(enc, lvl)
     finally:
@@ -603,6 +607,10 @@ def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None):
             main.wait_stream(g)
     # the products are complete on `main` from here on: later consumers need no per-product event
     _drop_events(lvl)
+    redo = _first_call_check(enc, lvl)
+    if redo is not None:
+        lvl = prepare_geometry(enc, coors, batch_size, num_voxels=num_voxels, **dict(dict(coors_order=coors_order, allow_slab=allow_slab), **redo))
+        enc.__dict__["_bevamd_geometry_checked"] = False   # the clean re-run does not vouch for the caller's next input
     return lvl
 
 
@@ -620,6 +628,34 @@ def _drop_events(lvl):
         for out, _ in lvl._down.values():
             nxt = out
         lvl = nxt
+
+
+def _first_call_check(enc, lvl):
+    """The device-side status words of a rulebook chain (bit 0: a slab range did not fit its 16-bit slots, neighbours were
+    dropped; bit 1: rows promised as coors_order="linear" were not in ascending linear index / inside the grid) are invisible to
+    a sync-free caller.  Kernels stay inside their buffers either way, but the convolutions would run on a wrong rulebook.
+    The FIRST eager call of an encoder therefore reads them back (one host sync, never under graph capture; later calls trust
+    the data, BEVAMD_SPCONV_CHECK=1 checks every call).  Returns None (all clear) or the keyword overrides the caller re-runs
+    with: the order-free route (hash index + gather kernels at level 1) for a broken promise, gather kernels throughout for an
+    overflowing range (dense synthetic grids; LiDAR sweeps are two orders of magnitude below the limit)."""
+    if enc.__dict__.get("_bevamd_geometry_checked") or torch.cuda.is_current_stream_capturing():
+        return None
+    bits = geometry_status(lvl)
+    if not bits:
+        enc.__dict__["_bevamd_geometry_checked"] = True   # stays unset after a failure: keep checking until a call is clean
+        return None
+    import warnings
+
+    redo = {}
+    if bits & 2:
+        warnings.warn("SparseEncoder: coors_order='linear' was promised but the voxel rows are not in ascending linear index "
+                      "(or leave the grid); falling back to the order-free rulebook route for this call", RuntimeWarning)
+        redo["coors_order"] = None
+    if bits & 1:
+        warnings.warn("SparseEncoder: a staged-rows range exceeded its 16-bit slots (an input plane denser than the slab kernels "
+                      "admit); falling back to the gather kernels for this call", RuntimeWarning)
+        redo["allow_slab"] = False
+    return redo
 
 
 def _is_linear(coors_order):
@@ -650,7 +686,7 @@ def geometry_status(lvl):
     return bits
 
 
-def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometry=None, coors_order=None):
+def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometry=None, coors_order=None, allow_slab=True):
     """SparseEncoder.forward on the fused path.  voxel_features [N, C_in] (any float dtype), coors [N, 4] int32
     (batch, x, y, z); `num_voxels` (optional int32 device tensor [1]): live row count when the inputs are
     capacity-padded buffers straight from the voxelizer (`voxelize_batch(..., sync=False)`); `geometry`: the Level returned
@@ -687,7 +723,9 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
     pool = [torch.zeros(_STATUS_WORDS, dtype=torch.int32, device=dev), 0] if _STATUS_POOL else None   # zeroed BEFORE the fork: ordered ahead of both streams
     if g is not None:
         g.wait_stream(main)       # fork: coordinates / count are final, recycled buffers are quiescent
-    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool)
+    lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool,
+                allow_slab=allow_slab)
+    redo = None
     try:
         if g is not None:
             prefetch_geometry(enc, lvl)
@@ -696,15 +734,20 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
         x = _sequential(enc.encoder_layers, x)
         x = _sequential(enc.conv_out, x)
         out = dense_bev(x)
-        if _CHECK:
+        redo = _first_call_check(enc, lvl)
+        if redo is None and _CHECK:
             bits = geometry_status(lvl)
             if bits:
                 raise RuntimeError(f"SparseEncoder fused path: geometry status {bits:#x} (1: slab range overflow, 2: coordinates "
                                    "passed with coors_order='linear' are not in ascending linear index)")
-        return out
     finally:
         if g is not None:
             main.wait_stream(g)   # join: whatever follows on this stream is ordered behind the geometry kernels
+    if redo is not None:
+        out = run_encoder(enc, voxel_features, coors, batch_size, num_voxels=num_voxels,
+                          **dict(dict(coors_order=coors_order, allow_slab=allow_slab), **redo))
+        enc.__dict__["_bevamd_geometry_checked"] = False   # the clean re-run does not vouch for the caller's next input
+    return out
 
 
 def prefetch_geometry(enc, lvl):

@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from . import _capi
-from .bev_pool import BevPoolPlan
+from .bev_pool import BevPoolPlan, bev_pool
 from .registry import register_everywhere
 
 __all__ = ["BaseTransform", "BaseDepthTransform", "LSSTransform", "DepthLSSTransform", "gen_dx_bx"]
@@ -251,6 +251,9 @@ class BaseTransform(nn.Module):
                 (geom_feats,) = _fp32(geom_feats)
             B, N, D, H, W, C = x.shape
         Nprime = B * N * D * H * W
+        on_host = not (factored.depth if factored is not None else x).is_cuda
+        if on_host:
+            return self._bev_pool_host(geom_feats, factored.materialize() if factored is not None else x)
         plan = self._cached_plan(geom_feats, Nprime, B)
         if factored is not None:
             ctx_cl = factored.ctx.float().permute(0, 1, 3, 4, 2).contiguous()     # [B, N, fH, fW, C] (5 MB)
@@ -261,6 +264,21 @@ class BaseTransform(nn.Module):
         # collapse Z (reference: torch.cat(x.unbind(dim=2), 1))
         if out.shape[2] == 1:
             return out[:, :, 0]                     # channels-last view, no copy
+        return torch.cat(out.unbind(dim=2), 1)
+
+    def _bev_pool_host(self, geom_feats, x):
+        """Host tensors (BASELINE configs[0], a box without a GPU): base.py:141-176 step by step in torch — cell index by
+        truncation, batch column, range mask — and `bev_pool()`'s torch QuickCumsum route.  No plan, no cache."""
+        if geom_feats is None:
+            raise RuntimeError("bev_pool on host tensors needs the geometry (cache_geometry plans are GPU objects)")
+        B, N, D, H, W, C = x.shape
+        Nprime = B * N * D * H * W
+        cell = ((geom_feats - (self.bx - self.dx / 2.0)) / self.dx).long().view(Nprime, 3)
+        batch_ix = torch.arange(B, dtype=torch.long).repeat_interleave(Nprime // B).view(Nprime, 1)
+        cell = torch.cat((cell, batch_ix), 1)
+        inside = ((cell[:, :3] >= 0) & (cell[:, :3] < self.nx.view(1, 3))).all(1)
+        nx, ny, nz = (int(v) for v in self.nx)
+        out = bev_pool(x.reshape(Nprime, C)[inside], cell[inside], B, nz, nx, ny)   # [B, C, nz, nx, ny]
         return torch.cat(out.unbind(dim=2), 1)
 
     def _split_mats(self, camera2ego, lidar2ego, camera_intrinsics, camera2lidar, img_aug_matrix, lidar_aug_matrix):

@@ -360,6 +360,41 @@ def test_encoder_key_ordered_path_is_bit_identical_to_first_appearance_path(dev,
     assert fused.geometry_status(lvl_bad) & 2
 
 
+def test_broken_linear_promise_is_memory_safe_and_the_encoder_falls_back(dev):
+    """first-appearance rows (and rows whose coordinates leave the grid) passed off as coors_order="linear".  The
+    sorted-key SEARCH runs on the broken index (clamped reads: no fault), the status bit is raised, and the encoder's first
+    eager call notices, warns and re-runs on the order-free route: same output as the honest first-appearance call."""
+    B = 2
+    pts = [torch.from_numpy(synth.lidar_points(seed=80 + b, sweeps=2)).to(dev) for b in range(B)]
+    vs, pr, mp, mv = CFG["voxel_size"], CFG["point_cloud_range"], CFG["max_num_points"], CFG["max_voxels"][1]
+    f0, c0, _, t0 = voxelize_batch_device(pts, vs, pr, mp, mv)
+    n = int(t0.item())
+    shape = list(CFG["sparse_shape"])
+    nd = t0.reshape(-1)[:1].int().contiguous()
+    for corrupt in (False, True):
+        c = c0.clone()
+        if corrupt:   # coordinates outside the grid / negative batch index in a few rows
+            c[5, 1], c[n // 2, 0], c[n - 1, 1], c[7, 3] = shape[0] + 40000, -3, -7, 1 << 20
+        lvl_bad = fused.Level(c, c.shape[0], nd, B, shape, linear_order=True)
+        lvl_bad.ensure_sorted()
+        for rows in (128, 256):
+            lvl_bad.subm_slab(rows)                      # the search itself, on the unsorted directory
+        lvl_bad.down_slab([3, 3, 3], [2, 2, 2], [1, 1, 1], 128)
+        torch.cuda.synchronize()                         # a fault would surface here
+        assert fused.geometry_status(lvl_bad) & 2
+    enc = flagship_encoder(dev)
+    with torch.no_grad():
+        ref = enc(f0, c0, B, num_voxels=t0)
+        enc2 = flagship_encoder(dev)
+        with pytest.warns(RuntimeWarning, match="not in ascending linear index"):
+            got = enc2(f0, c0, B, num_voxels=t0, coors_order="linear")
+        with pytest.warns(RuntimeWarning, match="not in ascending linear index"):
+            lvl = enc2.prepare_geometry(c0, B, num_voxels=t0, coors_order="linear")
+        assert not lvl.linear_order
+        prepared = enc2(f0, c0, B, num_voxels=t0, geometry=lvl)
+    assert torch.equal(got, ref) and torch.equal(prepared, ref)
+
+
 def test_encoder_key_ordered_path_replays_from_a_graph(dev):
     B = 2
     pts = [torch.from_numpy(synth.lidar_points(seed=90 + b, sweeps=2)).to(dev) for b in range(B)]
