@@ -34,6 +34,11 @@ _SIGNATURES = {
     "bevamd_bev_pool_fused_schedule_workspace_bytes": (Z, [I]),
     "bevamd_bev_pool_fused_schedule": (I, [P, P, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
     "bevamd_bev_pool_fused_forward_scheduled": (I, [P, P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_fused_columns_supported": (I, [I, I, I, I]),
+    "bevamd_bev_pool_fused_columns_workspace_bytes": (Z, [I, I]),
+    "bevamd_bev_pool_fused_columns_count": (I, [P, I, I, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
+    "bevamd_bev_pool_fused_columns_build": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
+    "bevamd_bev_pool_fused_forward_columns": (I, [P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_cell_of_point": (I, [P, P, I, P, P]),
     "bevamd_bev_pool_fused_backward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),

@@ -22,6 +22,12 @@ __all__ = ["bev_pool", "bev_pool_ext", "QuickCumsum", "QuickCumsumCuda", "BevPoo
 
 
 _FUSED_SCHEDULE = os.environ.get("BEVAMD_FUSED_POOL_SCHEDULE", "1") != "0"   # 0: frame-major walk over all XCDs
+# fused pooling formulation: "columns" (default; csrc/bev_pool_fused_cols.hip: one partial row per run of an image column, then a
+# per-cell reduce) falls back to the cell-centric kernels when the shape or the plan does not suit it; "cells" forces those
+_FUSED_MODE = os.environ.get("BEVAMD_FUSED_POOL_MODE", "columns")
+# a column plan is used while it has at most this fraction of the kept points as runs (flagship rig: 1 run per 28 points;
+# a camera rolled by 90 degrees: 1 per point -> the cell-centric kernel does the same work without the second pass)
+_FUSED_COLUMNS_MAX_RUN_FRACTION = float(os.environ.get("BEVAMD_FUSED_COLUMNS_MAX_RUN_FRACTION", "0.25"))
 _BWD_POINTS = os.environ.get("BEVAMD_BEV_POOL_BWD_POINTS", "1") != "0"   # 0: the row-parallel backward (sorted-row order)
 
 
@@ -170,6 +176,7 @@ class BevPoolPlan:
         self.interval_starts = self.interval_lengths = self.n_intervals_dev = self.geom_sorted = None
         self._cell_of_point = None   # rank per frustum point in point order (built on first fused backward)
         self._fused_sched = {}       # (depth_bins, fh, fw) -> (perm, xcd_start): camera-sector walk of the fused pooling
+        self._fused_cols = {}        # (depth_bins, fh, fw) -> _ColumnPlan: column formulation of the fused pooling
         if want_intervals:
             cap = max(min(self.n, self.ncells), 1)
             self.interval_starts = torch.empty(cap, dtype=torch.int32, device=device)
@@ -259,10 +266,12 @@ class BevPoolPlan:
         _capi.check(rc, "bev_pool_forward_cells")
         return out
 
-    def launch_fused(self, depth, ctx, depth_bins, fh, fw, out=None):
-        """Fused depth (x) context -> BEV (csrc/bev_pool_fused.hip): out[cell] = sum_p depth[p] * ctx[pixel(p)] without the
-        [N', C] volume.  depth: fp32, `self.n` elements in frustum-point order ([cams, D, fH, fW] flattened);
-        ctx [cams*fH*fW, C] channels-last fp32 / bf16.  Forward only."""
+    def launch_fused(self, depth, ctx, depth_bins, fh, fw, out=None, mode=None):
+        """Fused depth (x) context -> BEV: out[cell] = sum_p depth[p] * ctx[pixel(p)] without the [N', C] volume.  depth: fp32,
+        `self.n` elements in frustum-point order ([cams, D, fH, fW] flattened); ctx [cams*fH*fW, C] channels-last fp32 / bf16.
+        Forward only.  mode: None = BEVAMD_FUSED_POOL_MODE ("columns": csrc/bev_pool_fused_cols.hip when the shape and the plan
+        suit it, else the cell-centric kernels of csrc/bev_pool_fused.hip), "cells" = cell-centric, "columns!" = the column
+        formulation or an error (tests).  Calls on ONE plan share the partial-row scratch: issue them on one stream."""
         lib = _capi.load()
         depth = depth.contiguous()
         ctx = ctx.contiguous()
@@ -281,7 +290,31 @@ class BevPoolPlan:
             raise RuntimeError("ctx rows x depth_bins must equal the number of frustum points of the plan")
         if out is None:
             out = torch.empty((self.B, self.D, self.H, self.W, c), dtype=torch.float32, device=ctx.device)
-        sched = self.fused_schedule(depth_bins, fh, fw) if _FUSED_SCHEDULE and self.n > 0 else None
+        capturing = torch.cuda.is_current_stream_capturing()
+        mode = mode or _FUSED_MODE
+        cols = None
+        if mode in ("columns", "columns!") and self.n > 0:
+            cols = self.fused_columns(depth_bins, fh, fw, c, build=not capturing, force=mode == "columns!")
+        if mode == "columns!" and cols is None:
+            raise RuntimeError("bev_pool fused: the column formulation does not support this shape (c % 4, fh <= 32, fw % 4) "
+                               "or its plan is not built yet (graph capture)")
+        if cols is not None:
+            with torch.cuda.device(ctx.device):
+                partial = cols.partial_rows(c)
+                rc = lib.bevamd_bev_pool_fused_forward_columns(
+                    _capi.ptr(depth), _capi.ptr(ctx), is_bf16, _capi.ptr(cols.keep), _capi.ptr(cols.end), _capi.ptr(cols.run_first),
+                    _capi.ptr(cols.slot_of_run), _capi.ptr(cols.prow_start), _capi.ptr(partial), _capi.ptr(out), self.n, cols.nruns,
+                    c, int(depth_bins), int(fh), int(fw), self.B, self.D, self.H, self.W, _capi.stream_ptr(ctx.device))
+            _capi.check(rc, "bev_pool_fused_forward_columns")
+            return out
+        # cell-centric kernels: the camera-sector schedule needs whole frames of depth_bins*fh*fw points per camera and is built
+        # with a sort — not while a graph is being captured (the sort would be replayed and its buffers would live in the graph's
+        # pool): the unscheduled kernel computes the same bits
+        per_frame_ok = self.n % (int(depth_bins) * int(fh) * int(fw) * self.B) == 0
+        key = (int(depth_bins), int(fh), int(fw))
+        sched = None
+        if _FUSED_SCHEDULE and self.n > 0 and per_frame_ok and (not capturing or key in self._fused_sched):
+            sched = self.fused_schedule(depth_bins, fh, fw)
         with torch.cuda.device(ctx.device):
             if sched is not None:
                 rc = lib.bevamd_bev_pool_fused_forward_scheduled(
@@ -313,6 +346,33 @@ class BevPoolPlan:
             _capi.check(rc, "bev_pool_fused_schedule")
             self._fused_sched[key] = (perm, cuts)
         return self._fused_sched[key]
+
+    def fused_columns(self, depth_bins, fh, fw, c=80, build=True, force=False):
+        """The column plan of the fused pooling for this plan and frustum shape (`_ColumnPlan`), or None when the shape is not
+        supported or the plan is long-tailed (about as many runs as points).  Built once on the device and cached — static per
+        calibration like the plan itself; building reads ONE uint32 back (the run count sizes the buffers), so it is never done
+        under graph capture (`build=False` returns what is cached): call `prepare_fused()` before capturing."""
+        key = (int(depth_bins), int(fh), int(fw))
+        lib = _capi.load()
+        if not (self.n > 0 and self.n % (key[0] * key[1] * key[2]) == 0 and lib.bevamd_bev_pool_fused_columns_supported(int(c), *key)):
+            return None
+        if key not in self._fused_cols:
+            if not build:
+                return None
+            self._fused_cols[key] = _ColumnPlan.build(self, *key)
+        cols = self._fused_cols[key]
+        # `force` (tests): also for long-tailed plans — about as many runs as points, where the second pass buys nothing
+        if not force and cols.nruns > _FUSED_COLUMNS_MAX_RUN_FRACTION * max(cols.n_kept, 1):
+            return None
+        return cols
+
+    def prepare_fused(self, depth_bins, fh, fw, c=80):
+        """Build whatever `launch_fused` would build lazily for this frustum shape (column plan, or the camera-sector schedule of the
+        cell-centric kernel) — call once before capturing `launch_fused` into a HIP graph."""
+        if _FUSED_MODE == "columns" and self.fused_columns(depth_bins, fh, fw, c) is not None:
+            return
+        if _FUSED_SCHEDULE and self.n > 0 and self.n % (int(depth_bins) * int(fh) * int(fw) * self.B) == 0:
+            self.fused_schedule(depth_bins, fh, fw)
 
     def cell_of_point(self):
         if self._cell_of_point is None:
@@ -365,6 +425,53 @@ class BevPoolPlan:
                 self.n, c, self.B, self.D, self.H, self.W, _capi.stream_ptr(out_grad.device))
         _capi.check(rc, "bev_pool_backward_rows")
         return x_grad
+
+
+class _ColumnPlan:
+    """Column formulation of the fused pooling (csrc/bev_pool_fused_cols.hip), static per (plan, frustum shape): row masks per
+    image column, the slot of every run in the (frame, cell)-sorted partial-row buffer, the CSR of that buffer over frame-major
+    cells, and the buffer itself (scratch, reused by every call)."""
+
+    def __init__(self):
+        self.keep = self.end = self.run_first = self.slot_of_run = self.prow_start = None
+        self.nruns = self.n_kept = 0
+        self._partial = None
+
+    @classmethod
+    def build(cls, plan, depth_bins, fh, fw):
+        lib = _capi.load()
+        dev = plan.device
+        self = cls()
+        ncols = plan.n // fh
+        cop = plan.cell_of_point()
+        self.keep = torch.empty(ncols, dtype=torch.int32, device=dev)
+        self.end = torch.empty(ncols, dtype=torch.int32, device=dev)
+        self.run_first = torch.empty(ncols, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.prow_start = torch.empty(plan.ncells + 1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            wsb = lib.bevamd_bev_pool_fused_columns_workspace_bytes(ncols, 0)
+            ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
+            rc = lib.bevamd_bev_pool_fused_columns_count(_capi.ptr(cop), plan.n, depth_bins, fh, fw, plan.B, plan.D, plan.H, plan.W,
+                                                         _capi.ptr(self.keep), _capi.ptr(self.end), _capi.ptr(self.run_first),
+                                                         _capi.ptr(total), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+            _capi.check(rc, "bev_pool_fused_columns_count")
+            self.nruns = int(total.item())                      # the one read-back of the plan (sizes slot_of_run / the partial rows)
+            self.n_kept = plan.n_kept()
+            self.slot_of_run = torch.empty(max(self.nruns, 1), dtype=torch.int32, device=dev)
+            wsb = lib.bevamd_bev_pool_fused_columns_workspace_bytes(ncols, self.nruns)
+            ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
+            rc = lib.bevamd_bev_pool_fused_columns_build(_capi.ptr(cop), _capi.ptr(self.end), _capi.ptr(self.run_first), plan.n,
+                                                         self.nruns, depth_bins, fh, fw, plan.B, plan.D, plan.H, plan.W,
+                                                         _capi.ptr(self.slot_of_run), _capi.ptr(self.prow_start), _capi.ptr(ws), wsb,
+                                                         _capi.stream_ptr(dev))
+            _capi.check(rc, "bev_pool_fused_columns_build")
+        return self
+
+    def partial_rows(self, c):
+        if self._partial is None or self._partial.shape[1] != c:
+            self._partial = torch.empty((max(self.nruns, 1), c), dtype=torch.float32, device=self.keep.device)
+        return self._partial
 
 
 class _PlannedBevPool(torch.autograd.Function):

@@ -1,0 +1,452 @@
+// Fused depth (x) context -> BEV by image COLUMNS, for gfx950 (round 4).
+//
+// Same op as bev_pool_fused.hip —  out[cell, c] = sum over the frustum points p of the cell of depth[p] * ctx[pixel(p), c]
+// (models/vtransforms/depth_lss.py:92-97 + base.py:141-176 without the [N', C] volume) — evaluated the other way round.
+// The cell-centric kernel walks every cell's points through the sort permutation: one 4-byte depth gather (a 64-byte sector)
+// and one 320-byte context row from L2 per POINT, 14.5 M of them per 8 frames: 2.85 GB of HBM-side traffic for 0.43 GB of
+// algorithmic bytes (profiles/r03_pmc_infer_per_kernel.txt), 577 us.
+//
+// The BEV grid has ONE z cell, so the fH frustum points of an image column (camera, depth bin d, feature column w) — one ray
+// direction in the ground plane, fH elevations — fall into one BEV cell, or a few when the camera is pitched / rolled or the
+// image augmentation rotates: maximal runs of consecutive rows h with the same cell.  Per plan (static per calibration):
+//   keep[col], end[col]   32-bit row masks of column col = (cam * D + d) * fW + w: row kept by the range mask / row closes a run
+//   run_first[col]        number of runs before this column; slot_of_run[run] = position of the run among all runs sorted by
+//                         (frame, cell) — stable, so the rows of a cell stay in (camera, d, w, h) order: a FIXED summation order
+//   prow_start[cell]      CSR of the sorted runs over the frame-major cells
+// Pass 1 (bev_fused_cols_kernel): a workgroup stages the context rows of 4 image columns x all fH rows (1280 contiguous bytes
+// per row: coalesced, each context element read ONCE per depth half) and the depth distribution of those columns (range mask
+// folded in as zeros) in LDS and forms  partial[run, :] = sum_{h in run} depth * ctx  in registers — a [D x fH] x [fH x C]
+// product per column, 16 FMAs per two LDS reads — writing one 4*C-byte row per RUN (~20-30x fewer than points).
+// Pass 2 (bev_fused_reduce_kernel): every BEV cell sums its consecutive partial rows and is stored once, empty cells as zeros.
+// Algorithmic-side traffic per 8 flagship frames: depth 64 MB + context 2 x 43 MB + partial rows 2 x ~190 MB + output 332 MB.
+//
+// Summation order differs from the reference's (it adds a cell's points one by one in (camera, d, h, w) order; here rows of a
+// run first, then runs): fp32 throughout, <= 1e-4 against float64 (tests/test_gpu_bev_pool.py), deterministic.
+// Long-tailed plans (a camera rolled by 90 degrees: as many runs as points) keep the cell-centric kernel: the host decides from
+// the run count.
+#include "common.h"
+
+namespace bevamd {
+
+struct ColDims {
+  int BN, D, fH, fW, C;   // cameras of the whole batch, depth bins, feature rows / columns, channels
+  int DH, ndh, nwb;       // depth bins per tile (multiple of 4), tiles along d, tiles along w (4 columns each)
+};
+
+constexpr int COL_WB = 4;            // image columns per tile: one float4 of depth along w, 4*C*4 contiguous context bytes per row
+constexpr int COL_THREADS = 320;     // 16 items of 20 lanes at C = 80
+constexpr int COL_DEP_PITCH = COL_WB * 4 + 4;   // floats per (d-group, h) row of the depth tile: +4 keeps b128 writes conflict-free
+
+// ---- plan ---------------------------------------------------------------------------------------------------------------
+// one thread per image column: row masks + run count
+__global__ __launch_bounds__(256) void bev_fused_col_masks_kernel(const uint32_t* __restrict__ cell_of_point, uint32_t ncells,
+                                                                  int ncols, int fH, int fW, uint32_t* __restrict__ keep,
+                                                                  uint32_t* __restrict__ endm, uint32_t* __restrict__ nruns) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncols) return;
+  const int w = col % fW;
+  const size_t base = (size_t)(col / fW) * fH * fW + w;    // (cam * D + d) * fH * fW + w
+  uint32_t k = 0, e = 0;
+  uint32_t cur = cell_of_point[base];
+  for (int h = 0; h < fH; ++h) {
+    const uint32_t nxt = h + 1 < fH ? cell_of_point[base + (size_t)(h + 1) * fW] : 0xFFFFFFFFu;
+    if (cur < ncells) {
+      k |= 1u << h;
+      if (nxt != cur) e |= 1u << h;
+    }
+    cur = nxt;
+  }
+  keep[col] = k;
+  endm[col] = e;
+  nruns[col] = (uint32_t)__popc(e);
+}
+
+// frame-major cell key of a rank (rank = local * B + b, bev_pool.py:86-91)
+__device__ __forceinline__ uint32_t frame_major(uint32_t rank, uint32_t B, uint32_t per_frame) {
+  return (rank % B) * per_frame + rank / B;
+}
+
+// one thread per column: (key, run id) of its runs
+__global__ __launch_bounds__(256) void bev_fused_run_keys_kernel(const uint32_t* __restrict__ cell_of_point,
+                                                                 const uint32_t* __restrict__ endm,
+                                                                 const uint32_t* __restrict__ run_first, int ncols, int fH, int fW,
+                                                                 uint32_t B, uint32_t per_frame, uint32_t* __restrict__ keys,
+                                                                 uint32_t* __restrict__ vals) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncols) return;
+  uint32_t e = endm[col];
+  if (!e) return;
+  const int w = col % fW;
+  const size_t base = (size_t)(col / fW) * fH * fW + w;
+  uint32_t run = run_first[col];
+  while (e) {
+    const int h = __ffs((int)e) - 1;
+    e &= e - 1;
+    keys[run] = frame_major(cell_of_point[base + (size_t)h * fW], B, per_frame);
+    vals[run] = run;
+    ++run;
+  }
+}
+
+__global__ __launch_bounds__(256) void bev_fused_slot_of_run_kernel(const uint32_t* __restrict__ perm, uint32_t nruns,
+                                                                    uint32_t* __restrict__ slot_of_run) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < nruns) slot_of_run[perm[i]] = i;
+}
+
+// prow_start[c] = lower_bound(sorted keys, c), c in [0, ncells]
+__global__ __launch_bounds__(256) void bev_fused_prow_start_kernel(const uint32_t* __restrict__ keys, uint32_t nruns,
+                                                                   uint32_t ncells, uint32_t* __restrict__ prow_start) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c > ncells) return;
+  uint32_t lo = 0, hi = nruns;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  prow_start[c] = lo;
+}
+
+// ---- pass 1 ---------------------------------------------------------------------------------------------------------------
+struct alignas(16) CU4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ void fma4(float4& a, float d, const float4& c) {
+  a.x = fmaf(d, c.x, a.x); a.y = fmaf(d, c.y, a.y); a.z = fmaf(d, c.z, a.z); a.w = fmaf(d, c.w, a.w);
+}
+
+template <bool CTX_BF16>
+__global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
+    const float* __restrict__ depth, const void* __restrict__ ctx_, const uint32_t* __restrict__ keep,
+    const uint32_t* __restrict__ endm, const uint32_t* __restrict__ run_first, const uint32_t* __restrict__ slot_of_run,
+    float* __restrict__ partial, ColDims s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int C = s.C, fH = s.fH, lpr = C >> 2;
+  float* s_ctx = lds;                                        // [fH][4][C]
+  float* s_dep = lds + (size_t)fH * COL_WB * C;              // [DH / 4][fH][COL_DEP_PITCH]: (w, d % 4) -> w * 4 + d % 4
+  // tile: XCD x = blockIdx.x % 8 owns a contiguous eighth of the tiles, i.e. whole cameras — the depth lines a 4-column tile
+  // touches (16 of every 352 bytes) are shared with the neighbouring column tiles, which then run on the same L2
+  const int tiles_per_cam = s.nwb * s.ndh;
+  const int total = s.BN * tiles_per_cam, per = (total + 7) >> 3;
+  const int t = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per || t >= total) return;
+  const int bn = t / tiles_per_cam, rem = t - bn * tiles_per_cam;
+  const int wb = rem / s.ndh, dh = rem - wb * s.ndh;
+  const int w0 = wb * COL_WB, d0 = dh * s.DH;
+  const int tid = threadIdx.x;
+
+  // Staging: every global load of a batch is issued before the first LDS write (indices clamped instead of branched around, so
+  // that hipcc keeps the loads of a batch in flight together: branches made it wait for each load in turn).
+  // context rows: fH rows of 4 * C contiguous floats
+  {
+    const int per_row = COL_WB * lpr;                        // float4 per row
+    const int nvec = fH * per_row;
+    for (int i0 = 0; i0 < nvec; i0 += 4 * COL_THREADS) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * COL_THREADS + tid;
+        i = i < nvec ? i : nvec - 1;
+        const int h = i / per_row, j = i - h * per_row;
+        const size_t row = ((size_t)bn * fH + h) * s.fW + w0;   // context pixel row (cam, h, w0)
+        if constexpr (CTX_BF16) {
+          const uint2 q = ((const uint2*)ctx_)[row * lpr + j];  // 4 channels = 8 bytes of bf16
+          v[u] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16),
+                             __uint_as_float(q.y & 0xFFFF0000u));
+        } else {
+          v[u] = ((const float4*)ctx_)[row * lpr + j];
+        }
+      }
+      // (opaque uses: without them hipcc sinks each load into the guarded store below and waits for them one by one)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * COL_THREADS + tid;
+        if (i < nvec) ((float4*)s_ctx)[i] = v[u];
+      }
+    }
+  }
+  // depth tile with the range mask folded in: thread -> (d-group of 4 bins, h); 4 float4 loads along w, 4 float4 stores along d
+  {
+    const int ndg = s.DH >> 2, npair = ndg * fH;
+    for (int i0 = 0; i0 < npair; i0 += COL_THREADS) {
+      int i = i0 + tid;
+      const bool live = i < npair;
+      i = live ? i : npair - 1;
+      const int dg = i / fH, h = i - dg * fH;
+      float4 v[4];
+      CU4 k[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d = d0 + dg * 4 + j;
+        const size_t cam_d = (size_t)bn * s.D + (d < s.D ? d : s.D - 1);
+        k[j] = *(const CU4*)(keep + cam_d * s.fW + w0);
+        v[j] = *(const float4*)(depth + (cam_d * fH + h) * s.fW + w0);
+      }
+      float m[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = d0 + dg * 4 + j < s.D;
+        m[j][0] = in && ((k[j].x >> h) & 1u) ? v[j].x : 0.f;
+        m[j][1] = in && ((k[j].y >> h) & 1u) ? v[j].y : 0.f;
+        m[j][2] = in && ((k[j].z >> h) & 1u) ? v[j].z : 0.f;
+        m[j][3] = in && ((k[j].w >> h) & 1u) ? v[j].w : 0.f;
+      }
+      if (live) {
+        float4* dst = (float4*)(s_dep + ((size_t)dg * fH + h) * COL_DEP_PITCH);
+#pragma unroll
+        for (int wl = 0; wl < 4; ++wl) dst[wl] = make_float4(m[0][wl], m[1][wl], m[2][wl], m[3][wl]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // items: (column wl, d-group dg) x lpr lanes; a lane owns 4 channels of the 4 depth bins of its item
+  const int items_per_pass = COL_THREADS / lpr;
+  const int item0 = tid / lpr, cv = tid - item0 * lpr;
+  if (item0 >= items_per_pass) return;
+  const int n_items = COL_WB * (s.DH >> 2);
+  for (int item = item0; item < n_items; item += items_per_pass) {
+    const int wl = item & (COL_WB - 1), dg = item >> 2;
+    uint32_t en[4], rf[4], eany = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = d0 + dg * 4 + j;
+      en[j] = 0; rf[j] = 0;
+      if (d < s.D) {
+        const size_t col = ((size_t)bn * s.D + d) * s.fW + w0 + wl;
+        en[j] = endm[col];
+        rf[j] = run_first[col];
+      }
+      eany |= en[j];
+    }
+    if (!eany) continue;
+    float4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* cx = (const float4*)s_ctx + (size_t)wl * lpr + cv;           // + h * 4 * lpr
+    const float4* dp = (const float4*)(s_dep + (size_t)dg * fH * COL_DEP_PITCH) + wl;   // + h * (COL_DEP_PITCH / 4)
+    int h = 0;
+    while (eany) {
+      const int e = __ffs((int)eany) - 1;      // next row that closes a run of one of the 4 bins; rows after the last one hold no kept point
+      eany &= eany - 1;
+      // rows h .. e: four at a time with their eight LDS reads issued together (one exposed LDS round trip per four rows)
+      for (; h + 3 <= e; h += 4) {
+        float4 c[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          c[u] = cx[(size_t)(h + u) * COL_WB * lpr];
+          dv[u] = dp[(size_t)(h + u) * (COL_DEP_PITCH / 4)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          fma4(acc[0], dv[u].x, c[u]); fma4(acc[1], dv[u].y, c[u]); fma4(acc[2], dv[u].z, c[u]); fma4(acc[3], dv[u].w, c[u]);
+        }
+      }
+      for (; h <= e; ++h) {
+        const float4 c = cx[(size_t)h * COL_WB * lpr];
+        const float4 dv = dp[(size_t)h * (COL_DEP_PITCH / 4)];
+        fma4(acc[0], dv.x, c); fma4(acc[1], dv.y, c); fma4(acc[2], dv.z, c); fma4(acc[3], dv.w, c);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if ((en[j] >> e) & 1u) {
+          const uint32_t slot = slot_of_run[rf[j]];
+          ++rf[j];
+          ((float4*)partial)[(size_t)slot * lpr + cv] = acc[j];
+          acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  }
+}
+
+// ---- pass 2 ---------------------------------------------------------------------------------------------------------------
+// lpr lanes per cell, rpi cells per wave; a cell's partial rows are consecutive and are added in order
+__global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __restrict__ partial,
+                                                               const uint32_t* __restrict__ prow_start, uint32_t ncells,
+                                                               float* __restrict__ out, int lpr, int rpi, int B, int D, int H, int W,
+                                                               int C) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr, cv = lane - slot * lpr;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t cell = wave * (uint32_t)rpi + (uint32_t)slot;     // frame-major: b * (D*H*W) + (x * W + y) * D + z
+  if (slot >= rpi || cell >= ncells) return;
+  const uint32_t start = prow_start[cell];
+  const int len = (int)(prow_start[cell + 1] - start);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* p = partial + (size_t)start * lpr + cv;
+  for (int r = 0; r < len; r += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = r + u < len ? p[(size_t)(r + u) * lpr] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  const uint32_t per_frame = ncells / (uint32_t)B;
+  const uint32_t b = cell / per_frame;
+  uint32_t local = cell - b * per_frame;
+  const uint32_t gz = local % (uint32_t)D; local /= (uint32_t)D;
+  const uint32_t gy = local % (uint32_t)W;
+  const uint32_t gx = local / (uint32_t)W;
+  // out[b, z, x, y, :] (bev_pool_cuda.cu:33-35)
+  float4* o = (float4*)(out + ((((size_t)b * D + gz) * H + gx) * W + gy) * (size_t)C) + cv;
+  *o = acc;
+}
+
+static int cols_shape(int c, int depth_bins, int fh, int fw, ColDims& s, size_t& lds_bytes) {
+  if (c <= 0 || (c & 3) || (c >> 2) > COL_THREADS || fh <= 0 || fh > 32 || fw <= 0 || (fw % COL_WB) || depth_bins <= 0) return 0;
+  s.D = depth_bins; s.fH = fh; s.fW = fw; s.C = c;
+  const int dpad = (depth_bins + 3) / 4 * 4;
+  s.DH = dpad < 60 ? dpad : 60;
+  s.ndh = (depth_bins + s.DH - 1) / s.DH;
+  s.nwb = fw / COL_WB;
+  lds_bytes = ((size_t)fh * COL_WB * c + (size_t)(s.DH / 4) * fh * COL_DEP_PITCH) * sizeof(float);
+  return lds_bytes <= 150 * 1024;
+}
+
+}  // namespace bevamd
+
+using namespace bevamd;
+
+extern "C" {
+
+/* 1 if the column formulation of the fused pooling supports this shape (c % 4 == 0, fh <= 32, fw % 4 == 0, LDS tile fits);
+ * otherwise the caller stays on bevamd_bev_pool_fused_forward[_scheduled]. */
+int bevamd_bev_pool_fused_columns_supported(int c, int depth_bins, int fh, int fw) {
+  ColDims s;
+  size_t lds;
+  return cols_shape(c, depth_bins, fh, fw, s, lds);
+}
+
+/* Column plan, step 1 (static per plan): row masks keep / end [cams * depth_bins * fw] and run_first (exclusive scan of the
+ * per-column run counts) from cell_of_point [n] (bevamd_bev_pool_cell_of_point), n = cams * depth_bins * fh * fw; total_runs
+ * (device uint32) receives the number of runs.  The caller reads it back once (plan time, not per frame) to size step 2.
+ * ws: bevamd_bev_pool_fused_columns_workspace_bytes(n / fh, 0). */
+size_t bevamd_bev_pool_fused_columns_workspace_bytes(int ncols, int nruns) {
+  if (ncols < 0 || nruns < 0) return 0;
+  const size_t a = scan_workspace_bytes((size_t)(ncols > 0 ? ncols : 1));
+  const size_t r = (size_t)(nruns > 0 ? nruns : 1);
+  return align_up(a, 256) + 4 * align_up(r * 4, 256) + align_up(radix_sort_workspace_bytes(r), 256);
+}
+
+int bevamd_bev_pool_fused_columns_count(const uint32_t* cell_of_point, int n, int depth_bins, int fh, int fw, int b, int d, int h,
+                                        int w, uint32_t* keep, uint32_t* endm, uint32_t* run_first, uint32_t* total_runs,
+                                        void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(n > 0 && depth_bins > 0 && fh > 0 && fh <= 32 && fw > 0 && b > 0 && d > 0 && h > 0 && w > 0,
+                 "bev_pool_fused_columns_count: bad sizes (fh <= 32)");
+  const long long per_cam = (long long)depth_bins * fh * fw;
+  BEVAMD_REQUIRE(n % per_cam == 0, "bev_pool_fused_columns_count: n=%d is not a multiple of depth_bins*fh*fw=%lld", n, per_cam);
+  BEVAMD_REQUIRE((unsigned long long)b * d * h * w < 0xFFFFFFF0ull, "bev_pool_fused_columns_count: b*d*h*w too large");
+  BEVAMD_REQUIRE(cell_of_point && keep && endm && run_first && total_runs, "bev_pool_fused_columns_count: null buffer");
+  const int ncols = n / fh;
+  if (!ws || ws_bytes < scan_workspace_bytes((size_t)ncols)) {
+    set_error("bev_pool_fused_columns_count: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  bev_fused_col_masks_kernel<<<dim3(cdiv(ncols, 256)), dim3(256), 0, stream>>>(cell_of_point, ncells, ncols, fh, fw, keep, endm,
+                                                                               run_first);
+  BEVAMD_LAUNCH_CHECK("bev_fused_col_masks");
+  return exclusive_scan_u32(run_first, run_first, (size_t)ncols, total_runs, ws, ws_bytes, stream);
+}
+
+/* Column plan, step 2: slot_of_run [nruns] (position of every run in the (frame, cell)-sorted order; stable: runs of a cell
+ * stay in (camera, d, w, h) order) and prow_start [b*d*h*w + 1] (CSR of the sorted runs over FRAME-MAJOR cells:
+ * cell = frame * d*h*w + (x * w + y) * d + z).  nruns = the value step 1 left in total_runs.
+ * ws: bevamd_bev_pool_fused_columns_workspace_bytes(n / fh, nruns). */
+int bevamd_bev_pool_fused_columns_build(const uint32_t* cell_of_point, const uint32_t* endm, const uint32_t* run_first, int n,
+                                        int nruns, int depth_bins, int fh, int fw, int b, int d, int h, int w,
+                                        uint32_t* slot_of_run, uint32_t* prow_start, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(n > 0 && nruns >= 0 && depth_bins > 0 && fh > 0 && fh <= 32 && fw > 0 && b > 0 && d > 0 && h > 0 && w > 0,
+                 "bev_pool_fused_columns_build: bad sizes");
+  BEVAMD_REQUIRE(n % ((long long)depth_bins * fh * fw) == 0, "bev_pool_fused_columns_build: n is not a multiple of depth_bins*fh*fw");
+  BEVAMD_REQUIRE((unsigned long long)b * d * h * w < 0xFFFFFFF0ull, "bev_pool_fused_columns_build: b*d*h*w too large");
+  BEVAMD_REQUIRE(cell_of_point && endm && run_first && prow_start && (nruns == 0 || slot_of_run), "bev_pool_fused_columns_build: null buffer");
+  const int ncols = n / fh;
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  if (!ws || ws_bytes < bevamd_bev_pool_fused_columns_workspace_bytes(ncols, nruns)) {
+    set_error("bev_pool_fused_columns_build: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  Carver cv(ws, ws_bytes);
+  cv.take<char>(align_up(scan_workspace_bytes((size_t)ncols), 256));
+  const size_t r = (size_t)(nruns > 0 ? nruns : 1);
+  uint32_t* keys_a = cv.take<uint32_t>(r);
+  uint32_t* vals_a = cv.take<uint32_t>(r);
+  uint32_t* keys_b = cv.take<uint32_t>(r);
+  uint32_t* vals_b = cv.take<uint32_t>(r);
+  void* sws = cv.base + cv.off;
+  const size_t sws_bytes = ws_bytes - cv.off;
+  const uint32_t* sorted_keys = keys_b;
+  if (nruns > 0) {
+    bev_fused_run_keys_kernel<<<dim3(cdiv(ncols, 256)), dim3(256), 0, stream>>>(cell_of_point, endm, run_first, ncols, fh, fw,
+                                                                                (uint32_t)b, ncells / (uint32_t)b, keys_a, vals_a);
+    BEVAMD_LAUNCH_CHECK("bev_fused_run_keys");
+    int rc = radix_sort_pairs_u32(keys_a, vals_a, keys_b, vals_b, (size_t)nruns, bits_for((uint64_t)ncells + 1), sws, sws_bytes, stream);
+    if (rc) return rc;
+    bev_fused_slot_of_run_kernel<<<dim3(cdiv(nruns, 256)), dim3(256), 0, stream>>>(vals_b, (uint32_t)nruns, slot_of_run);
+    BEVAMD_LAUNCH_CHECK("bev_fused_slot_of_run");
+  }
+  bev_fused_prow_start_kernel<<<dim3(cdiv((long long)ncells + 1, 256)), dim3(256), 0, stream>>>(sorted_keys, (uint32_t)nruns, ncells,
+                                                                                               prow_start);
+  BEVAMD_LAUNCH_CHECK("bev_fused_prow_start");
+  return BEVAMD_OK;
+}
+
+/* out [b, d, h, w, c] fp32 (every cell written once) = the fused pooling of bevamd_bev_pool_fused_forward, through the column
+ * plan: pass 1 writes partial [nruns, c] fp32 (caller-owned scratch, reusable across calls), pass 2 reduces it per cell.
+ * depth [n] fp32, ctx [cams*fh*fw, c] channels-last fp32 (ctx_is_bf16 = 0) or bf16 bits (1). */
+int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, int ctx_is_bf16, const uint32_t* keep,
+                                          const uint32_t* endm, const uint32_t* run_first, const uint32_t* slot_of_run,
+                                          const uint32_t* prow_start, float* partial, float* out, int n, int nruns, int c,
+                                          int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(n > 0 && nruns >= 0 && b > 0 && d > 0 && h > 0 && w > 0, "bev_pool_fused_forward_columns: bad sizes");
+  ColDims s;
+  size_t lds_bytes = 0;
+  BEVAMD_REQUIRE(cols_shape(c, depth_bins, fh, fw, s, lds_bytes),
+                 "bev_pool_fused_forward_columns: unsupported shape (c %% 4 == 0, fh <= 32, fw %% 4 == 0): c=%d fh=%d fw=%d", c, fh, fw);
+  const long long per_cam = (long long)depth_bins * fh * fw;
+  BEVAMD_REQUIRE(n % per_cam == 0, "bev_pool_fused_forward_columns: n=%d is not a multiple of depth_bins*fh*fw=%lld", n, per_cam);
+  BEVAMD_REQUIRE((unsigned long long)b * d * h * w < 0xFFFFFFF0ull, "bev_pool_fused_forward_columns: b*d*h*w too large");
+  BEVAMD_REQUIRE(depth && ctx && keep && endm && run_first && prow_start && out && (nruns == 0 || (slot_of_run && partial)),
+                 "bev_pool_fused_forward_columns: null buffer");
+  BEVAMD_REQUIRE((((uintptr_t)depth | (uintptr_t)ctx | (uintptr_t)out | (uintptr_t)partial | (uintptr_t)keep) & 15) == 0,
+                 "bev_pool_fused_forward_columns: buffers must be 16-byte aligned");
+  s.BN = (int)(n / per_cam);
+  const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
+  if (nruns > 0) {
+    if (lds_bytes > 65536) {
+      // the opt-in to > 64 KiB of dynamic LDS is a per-device function attribute: remembered per (flavour, device)
+      static int raised[2][64] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+      dev = dev >= 0 && dev < 64 ? dev : 0;
+      int& flag = raised[ctx_is_bf16 ? 1 : 0][dev];
+      if (!flag) {
+        const void* k = ctx_is_bf16 ? (const void*)&bev_fused_cols_kernel<true> : (const void*)&bev_fused_cols_kernel<false>;
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        flag = 1;
+      }
+    }
+    const int total = s.BN * s.nwb * s.ndh;
+    const dim3 grid(((total + 7) / 8) * 8), block(COL_THREADS);
+    if (ctx_is_bf16)
+      bev_fused_cols_kernel<true><<<grid, block, lds_bytes, stream>>>(depth, ctx, keep, endm, run_first, slot_of_run, partial, s);
+    else
+      bev_fused_cols_kernel<false><<<grid, block, lds_bytes, stream>>>(depth, ctx, keep, endm, run_first, slot_of_run, partial, s);
+    BEVAMD_LAUNCH_CHECK("bev_fused_cols");
+  }
+  const int lpr = c / 4, rpi = 64 / lpr > 0 ? 64 / lpr : 0;
+  BEVAMD_REQUIRE(rpi > 0, "bev_pool_fused_forward_columns: c=%d needs more than 64 lanes per row", c);
+  bev_fused_reduce_kernel<<<dim3(cdiv(cdiv(ncells, rpi), 4)), dim3(256), 0, stream>>>((const float4*)partial, prow_start, ncells, out,
+                                                                                     lpr, rpi, b, d, h, w, c);
+  BEVAMD_LAUNCH_CHECK("bev_fused_reduce");
+  return BEVAMD_OK;
+}
+
+}  // extern "C"

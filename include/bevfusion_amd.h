@@ -149,6 +149,30 @@ int bevamd_bev_pool_fused_forward_scheduled(const float* depth, const void* ctx,
                                             float* out, int n, int c, int depth_bins, int fh, int fw, int b, int d, int h, int w,
                                             void* stream);
 
+/* The same op by image COLUMNS (round 4; csrc/bev_pool_fused_cols.hip).  The BEV grid has one z cell, so the fh frustum points
+ * of an image column (camera, depth bin, feature column) fall into one cell or a few consecutive RUNS of rows.  Pass 1 loads
+ * each context row and depth value once, coalesced, and forms one partial row per run (sum over the run's rows of
+ * depth * ctx) — 20-30x fewer rows than points; pass 2 sums every cell's consecutive partial rows and writes every cell once.
+ * Same result as bevamd_bev_pool_fused_forward up to fp32 summation order (<= 1e-4 against float64), deterministic.
+ * Plan (static per calibration, built from cell_of_point of bevamd_bev_pool_cell_of_point):
+ *   _columns_count : keep / end [cams*depth_bins*fw] row masks (bit h: row kept by the range mask / row closes a run),
+ *                    run_first [cams*depth_bins*fw] (runs before the column), total_runs (device uint32);
+ *   _columns_build : slot_of_run [nruns] (position of a run in the stable (frame, cell) order), prow_start [b*d*h*w + 1]
+ *                    (CSR over frame-major cells).  nruns = *total_runs read back once by the caller (plan time).
+ * Shapes: c % 4 == 0, fh <= 32, fw % 4 == 0 (bevamd_bev_pool_fused_columns_supported); plans with about as many runs as points
+ * (a camera rolled by 90 degrees) should stay on the cell-centric kernels above. */
+int bevamd_bev_pool_fused_columns_supported(int c, int depth_bins, int fh, int fw);
+size_t bevamd_bev_pool_fused_columns_workspace_bytes(int ncols, int nruns);
+int bevamd_bev_pool_fused_columns_count(const uint32_t* cell_of_point, int n, int depth_bins, int fh, int fw, int b, int d, int h,
+                                        int w, uint32_t* keep, uint32_t* end, uint32_t* run_first, uint32_t* total_runs,
+                                        void* ws, size_t ws_bytes, void* stream);
+int bevamd_bev_pool_fused_columns_build(const uint32_t* cell_of_point, const uint32_t* end, const uint32_t* run_first, int n,
+                                        int nruns, int depth_bins, int fh, int fw, int b, int d, int h, int w,
+                                        uint32_t* slot_of_run, uint32_t* prow_start, void* ws, size_t ws_bytes, void* stream);
+int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, int ctx_is_bf16, const uint32_t* keep,
+                                          const uint32_t* end, const uint32_t* run_first, const uint32_t* slot_of_run,
+                                          const uint32_t* prow_start, float* partial, float* out, int n, int nruns, int c,
+                                          int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream);
 
 /* Backward of the fused op (fp32 context): d_depth [n] = sum_c out_grad[cell(p), c] * ctx[pixel(p), c] (0 for dropped
  * points), d_ctx [cams*fh*fw, c] = sum over the depth bins of a pixel of depth[p] * out_grad[cell(p), :]; both fully

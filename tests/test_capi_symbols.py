@@ -53,13 +53,22 @@ def test_invalid_arguments_are_rejected_before_any_gpu_work():
     assert "bad sizes" in _capi.last_error()
 
 
-def test_product_op_refuses_cpu_tensors():
+def test_hip_entry_points_refuse_cpu_tensors():
+    """The HIP ops have no CPU path: the extension mirror, the plan and QuickCumsumCuda raise on host tensors.  (`bev_pool()`
+    itself routes HOST tensors to the reference's device-agnostic torch QuickCumsum — BASELINE configs[0],
+    tests/test_cpu_plumbing.py — which is a separate algorithm for host data, never a fallback for GPU tensors.)"""
     import torch
 
-    from bevfusion_amd.bev_pool import bev_pool
+    from bevfusion_amd.bev_pool import BevPoolPlan, QuickCumsumCuda, bev_pool_ext
 
+    x, c = torch.zeros(4, 8), torch.zeros(4, 4, dtype=torch.int32)
+    iv = torch.zeros(1, dtype=torch.int32)
     with pytest.raises(RuntimeError, match="GPU tensor"):
-        bev_pool(torch.zeros(4, 8), torch.zeros(4, 4, dtype=torch.long), 1, 1, 2, 2)
+        bev_pool_ext.bev_pool_forward(x, c, iv, iv, 1, 1, 2, 2)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        BevPoolPlan.from_coords(c, 1, 1, 2, 2)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        QuickCumsumCuda.apply(x, c, torch.zeros(4, dtype=torch.long), 1, 1, 2, 2)
 
 
 def test_host_side_tables_of_the_slab_kernels():

@@ -1,0 +1,240 @@
+"""Column formulation of the fused depth (x) context -> BEV pooling (csrc/bev_pool_fused_cols.hip, round 4) through the C ABI.
+
+Reference op: models/vtransforms/depth_lss.py:92-97 (outer product) + base.py:141-176 (range mask, bev_pool).  Bar: <= 1e-4 abs
+against a float64 segment sum of the explicit outer product (BASELINE.json north_star), and agreement with the cell-centric
+kernels on the same plan.  Covered: the plan (row masks, run numbering, frame-major CSR) against numpy; random cells (every row
+its own run: the long-tailed worst case, forced), camera geometry with pitched / rolled cameras and rotated / flipped image
+augmentation (a few runs per column), several frames, depth halves (D > 60), bf16 context, empty plans, whole-column drops,
+graph capture."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from bevfusion_amd import _capi, synth
+from bevfusion_amd.bev_pool import BevPoolPlan
+
+pytestmark = pytest.mark.gpu
+
+
+def float64_reference(depth, ctx, coords, cams, D, fh, fw, B, Dz, H, W):
+    n = cams * D * fh * fw
+    p = np.arange(n)
+    pix = (p // (D * fh * fw)) * fh * fw + (p % (D * fh * fw)) % (fh * fw)
+    rows = depth.reshape(-1, 1).astype(np.float64) * ctx.astype(np.float64)[pix]
+    ok = ((coords[:, 0] >= 0) & (coords[:, 0] < H) & (coords[:, 1] >= 0) & (coords[:, 1] < W) & (coords[:, 2] >= 0)
+          & (coords[:, 2] < Dz))
+    want = np.zeros((B, Dz, H, W, ctx.shape[1]))
+    np.add.at(want, (coords[ok, 3], coords[ok, 2], coords[ok, 0], coords[ok, 1]), rows[ok])
+    return want, ok
+
+
+@pytest.mark.parametrize("cams,D,fh,fw,c,dtype", [(2, 7, 4, 8, 80, torch.float32), (3, 5, 3, 4, 16, torch.float32),
+                                                   (1, 9, 32, 12, 64, torch.bfloat16), (6, 61, 5, 8, 8, torch.float32),
+                                                   (2, 118, 6, 4, 80, torch.float32), (1, 3, 1, 4, 256, torch.float32)])
+def test_random_cells_every_row_its_own_run(dev, cams, D, fh, fw, c, dtype):
+    """Random cell per point: runs are single rows (plus hot cells and dropped points) — the column plan's worst case, forced."""
+    rng = np.random.default_rng(cams * 1000 + D * 10 + fh)
+    B, Dz, H, W = 1, 2, 9, 11
+    n = cams * D * fh * fw
+    coords = np.stack([rng.integers(-1, H + 1, n), rng.integers(-1, W + 1, n), rng.integers(0, Dz, n), np.zeros(n, np.int64)], 1)
+    coords[: n // 3, 0], coords[: n // 3, 1], coords[: n // 3, 2] = 4, 5, 1          # a hot cell: long runs in the first columns
+    depth = rng.random(n).astype(np.float32)
+    ctx = torch.from_numpy(rng.standard_normal((cams * fh * fw, c)).astype(np.float32)).to(dtype)
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)
+    got = plan.launch_fused(torch.from_numpy(depth).to(dev), ctx.to(dev), D, fh, fw, mode="columns!").cpu().numpy()
+    want, ok = float64_reference(depth, ctx.float().numpy(), coords, cams, D, fh, fw, B, Dz, H, W)
+    assert np.max(np.abs(got - want)) <= 1e-4
+    cells = plan.launch_fused(torch.from_numpy(depth).to(dev), ctx.to(dev), D, fh, fw, mode="cells").cpu().numpy()
+    assert np.max(np.abs(got - cells)) <= 1e-4
+    # auto mode keeps the cell-centric kernel for such a plan (as many runs as points): same bits as "cells"
+    auto = plan.launch_fused(torch.from_numpy(depth).to(dev), ctx.to(dev), D, fh, fw).cpu().numpy()
+    cols = plan.fused_columns(D, fh, fw, c, force=True)
+    if cols.nruns > 0.25 * max(cols.n_kept, 1):
+        assert np.array_equal(auto, cells)
+
+
+def test_column_plan_against_numpy(dev):
+    """keep / end masks, run numbering, slot_of_run (stable order by frame-major cell) and the CSR, on two frames."""
+    rng = np.random.default_rng(5)
+    B, cams_per, D, fh, fw = 2, 2, 5, 7, 4
+    Dz, H, W = 1, 6, 5
+    cams = B * cams_per
+    n = cams * D * fh * fw
+    # column-structured cells: a few cells per column, with dropped stretches
+    coords = np.zeros((n, 4), np.int64)
+    idx = np.arange(n).reshape(cams, D, fh, fw)
+    for cam in range(cams):
+        for d in range(D):
+            for w in range(fw):
+                cuts = np.sort(rng.integers(0, fh + 1, 2))
+                cell = rng.integers(-1, H + 1, 3), rng.integers(0, W, 3)
+                for h in range(fh):
+                    seg = int(h >= cuts[0]) + int(h >= cuts[1])
+                    coords[idx[cam, d, h, w]] = (cell[0][seg], cell[1][seg], 0, cam // cams_per)
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)
+    cols = plan.fused_columns(D, fh, fw, 80, force=True)
+    ok = (coords[:, 0] >= 0) & (coords[:, 0] < H)
+    rank = coords[:, 0] * (W * Dz * B) + coords[:, 1] * (Dz * B) + coords[:, 2] * B + coords[:, 3]
+    per_frame = Dz * H * W
+    fkey = (rank % B) * per_frame + rank // B
+    keep = np.zeros(cams * D * fw, np.uint32)
+    end = np.zeros(cams * D * fw, np.uint32)
+    run_keys = []
+    for cam in range(cams):
+        for d in range(D):
+            for w in range(fw):
+                col = (cam * D + d) * fw + w
+                for h in range(fh):
+                    p = idx[cam, d, h, w]
+                    if not ok[p]:
+                        continue
+                    keep[col] |= 1 << h
+                    nxt = idx[cam, d, h + 1, w] if h + 1 < fh else None
+                    if nxt is None or not ok[nxt] or rank[nxt] != rank[p]:
+                        end[col] |= 1 << h
+                        run_keys.append(fkey[p])
+    run_keys = np.array(run_keys)
+    assert np.array_equal(cols.keep.cpu().numpy().view(np.uint32), keep)
+    assert np.array_equal(cols.end.cpu().numpy().view(np.uint32), end)
+    nr = np.array([bin(int(e)).count("1") for e in end])
+    assert np.array_equal(cols.run_first.cpu().numpy(), np.concatenate([[0], np.cumsum(nr)[:-1]]))
+    assert cols.nruns == run_keys.shape[0] == int(nr.sum())
+    order = np.argsort(run_keys, kind="stable")
+    slot = np.empty_like(order)
+    slot[order] = np.arange(order.shape[0])
+    assert np.array_equal(cols.slot_of_run.cpu().numpy()[: cols.nruns], slot)
+    start = np.searchsorted(run_keys[order], np.arange(B * per_frame + 1), side="left")
+    assert np.array_equal(cols.prow_start.cpu().numpy(), start)
+
+
+def rigged_geometry(B, n_cam, D, fh, fw, seed, pitch_deg=1.5, roll_deg=1.0, rot_deg=5.4, flip=True):
+    """[B, n_cam, D, fh, fw, 3] lidar-frame frustum points (float64 restatement of base.py:92-135) of a rig whose cameras are
+    pitched / rolled a little (as mounted cameras are) and whose image augmentation rotates and flips (training-time
+    augmentation, transforms_3d.py:85-118): a column's rows then cross a few BEV cells."""
+    rng = np.random.default_rng(seed)
+    cfg = synth.CL_CONFIG
+    iH, iW = cfg["image_size"]
+    rig = synth.camera_rig(n_cam)
+    ds = np.arange(1.0, 1.0 + 0.5 * D, 0.5)[:D]
+    xs, ys = np.linspace(0, iW - 1, fw), np.linspace(0, iH - 1, fh)
+    fr = np.stack(np.broadcast_arrays(xs[None, None, :], ys[None, :, None], ds[:, None, None]), -1)     # [D, fh, fw, 3]
+    out = np.empty((B, n_cam, D, fh, fw, 3))
+    for b in range(B):
+        for n in range(n_cam):
+            a = math.radians(rng.uniform(-rot_deg, rot_deg))
+            s = 0.48 * rng.uniform(0.9, 1.1)
+            post_rot = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]]) * np.array([s, s, 1.0])
+            if flip and rng.random() < 0.5:
+                post_rot = np.diag([-1.0, 1.0, 1.0]) @ post_rot
+            post_tran = np.array([rng.uniform(-40, 0) + (iW if post_rot[0, 0] < 0 else 0), rng.uniform(-190, -160), 0.0])
+            pr, rr = math.radians(rng.uniform(-pitch_deg, pitch_deg)), math.radians(rng.uniform(-roll_deg, roll_deg))
+            rx = np.array([[1, 0, 0], [0, math.cos(pr), -math.sin(pr)], [0, math.sin(pr), math.cos(pr)]])
+            rz = np.array([[math.cos(rr), -math.sin(rr), 0], [math.sin(rr), math.cos(rr), 0], [0, 0, 1]])
+            c2l = rig["camera2lidar_rots"][n].astype(np.float64) @ rx @ rz
+            pts = (fr - post_tran) @ np.linalg.inv(post_rot).T
+            pts = np.concatenate([pts[..., :2] * pts[..., 2:3], pts[..., 2:3]], -1)
+            pts = pts @ (c2l @ np.linalg.inv(rig["intrins"][n].astype(np.float64))).T + rig["camera2lidar_trans"][n]
+            out[b, n] = pts
+    return out.astype(np.float32)
+
+
+@pytest.mark.parametrize("B,n_cam,D,fh,fw,c,dtype,aug", [(1, 6, 118, 32, 88, 80, torch.float32, True),
+                                                         (2, 3, 40, 32, 44, 80, torch.float32, True),
+                                                         (1, 2, 118, 16, 88, 64, torch.bfloat16, True),
+                                                         (3, 1, 59, 32, 88, 80, torch.float32, False)])
+def test_camera_geometry_with_pitched_cameras_and_rotated_augmentation(dev, B, n_cam, D, fh, fw, c, dtype, aug):
+    cfg = synth.CL_CONFIG
+    geom = rigged_geometry(B, n_cam, D, fh, fw, seed=B * 10 + n_cam, rot_deg=5.4 if aug else 0.0, flip=aug)
+    dx, bx, nx = synth.gen_dx_bx(cfg["xbound"], cfg["ybound"], cfg["zbound"])
+    origin = (bx - dx / np.float32(2.0)).astype(np.float32)
+    H, W, Dz = (int(v) for v in nx)
+    g = torch.from_numpy(geom.reshape(-1, 3)).to(dev)
+    plan = BevPoolPlan.from_geometry(g, B, origin, dx, nx)
+    rng = np.random.default_rng(3)
+    cams = B * n_cam
+    depth = torch.softmax(torch.from_numpy(rng.standard_normal((cams, D, fh, fw)).astype(np.float32)), 1).numpy()
+    ctx = torch.from_numpy((rng.standard_normal((cams * fh * fw, c)) * 0.5).astype(np.float32)).to(dtype)
+    cols = plan.fused_columns(D, fh, fw, c)
+    assert cols is not None, "a camera rig must take the column formulation in auto mode"
+    n_kept = plan.n_kept()
+    assert cols.nruns < 0.25 * n_kept                     # a few runs per column, ~fh points per run
+    got = plan.launch_fused(torch.from_numpy(depth).reshape(-1).to(dev), ctx.to(dev), D, fh, fw)
+    # float64 reference with the reference's own cell arithmetic (fp32 subtract / divide / truncation, base.py:149-169)
+    cell = ((geom.reshape(-1, 3) - origin) / dx).astype(np.int64)
+    bidx = np.repeat(np.arange(B), geom.reshape(-1, 3).shape[0] // B)
+    coords = np.concatenate([cell, bidx[:, None]], 1)
+    want, ok = float64_reference(depth, ctx.float().numpy(), coords, cams, D, fh, fw, B, Dz, H, W)
+    assert int(ok.sum()) == n_kept
+    err = float(np.max(np.abs(got.cpu().numpy() - want)))
+    assert err <= 1e-4, err
+    cells = plan.launch_fused(torch.from_numpy(depth).reshape(-1).to(dev), ctx.to(dev), D, fh, fw, mode="cells")
+    assert float((got - cells).abs().max()) <= 1e-4
+    # deterministic: a second launch gives the same bits
+    again = plan.launch_fused(torch.from_numpy(depth).reshape(-1).to(dev), ctx.to(dev), D, fh, fw)
+    assert torch.equal(got, again)
+
+
+def test_empty_plans_and_dropped_columns(dev):
+    B, Dz, H, W = 1, 1, 4, 4
+    cams, D, fh, fw, c = 1, 4, 3, 4, 8
+    n = cams * D * fh * fw
+    coords = np.full((n, 4), -5, np.int64)
+    coords[:, 2:] = 0
+    depth = torch.rand(n, device=dev)
+    ctx = torch.randn(cams * fh * fw, c, device=dev)
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)       # nothing survives the range mask
+    out = plan.launch_fused(depth, ctx, D, fh, fw, mode="columns!")
+    assert plan.fused_columns(D, fh, fw, c, force=True).nruns == 0 and not out.any()
+    coords[:, :2] = 1
+    coords[np.arange(n) % fw != 2, 0] = -1                                                 # only image column w = 2 survives
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)
+    out = plan.launch_fused(depth, ctx, D, fh, fw, mode="columns!")
+    want, _ = float64_reference(depth.cpu().numpy(), ctx.cpu().numpy(), coords, cams, D, fh, fw, B, Dz, H, W)
+    assert np.max(np.abs(out.cpu().numpy() - want)) <= 1e-5
+    assert plan.fused_columns(D, fh, fw, c, force=True).nruns == D
+
+
+def test_unsupported_shapes_fall_back_or_raise(dev):
+    lib = _capi.load()
+    assert lib.bevamd_bev_pool_fused_columns_supported(80, 118, 32, 88) == 1
+    assert lib.bevamd_bev_pool_fused_columns_supported(80, 118, 33, 88) == 0      # more rows than mask bits
+    assert lib.bevamd_bev_pool_fused_columns_supported(80, 118, 32, 86) == 0      # fw % 4
+    assert lib.bevamd_bev_pool_fused_columns_supported(6, 118, 32, 88) == 0       # c % 4
+    n = 2 * 3 * 2 * 5
+    plan = BevPoolPlan.from_coords(torch.zeros((n, 4), dtype=torch.int64, device=dev), 1, 1, 2, 2)
+    depth, ctx = torch.rand(n, device=dev), torch.randn(2 * 2 * 5, 8, device=dev)
+    with pytest.raises(RuntimeError, match="column formulation"):
+        plan.launch_fused(depth, ctx, 3, 2, 5, mode="columns!")
+    out = plan.launch_fused(depth, ctx, 3, 2, 5)                                   # auto: the cell-centric kernel
+    assert torch.allclose(out[0, 0, 0, 0], (depth.view(2, 3, 10, 1) * ctx.view(2, 1, 10, 8)).sum((0, 1, 2)), atol=1e-4)
+
+
+def test_column_path_replays_from_a_graph(dev):
+    B, n_cam, D, fh, fw, c = 1, 2, 24, 32, 44, 80
+    cfg = synth.CL_CONFIG
+    geom = rigged_geometry(B, n_cam, D, fh, fw, seed=4)
+    dx, bx, nx = synth.gen_dx_bx(cfg["xbound"], cfg["ybound"], cfg["zbound"])
+    origin = (bx - dx / np.float32(2.0)).astype(np.float32)
+    plan = BevPoolPlan.from_geometry(torch.from_numpy(geom.reshape(-1, 3)).to(dev), B, origin, dx, nx)
+    depth = torch.rand(B * n_cam * D * fh * fw, device=dev)
+    ctx = torch.randn(B * n_cam * fh * fw, c, device=dev)
+    plan.prepare_fused(D, fh, fw, c)
+    H, W, Dz = (int(v) for v in nx)
+    out = torch.empty((B, Dz, H, W, c), device=dev)
+    ref = plan.launch_fused(depth, ctx, D, fh, fw).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.launch_fused(depth, ctx, D, fh, fw, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan.launch_fused(depth, ctx, D, fh, fw, out=out, mode="columns!")
+    out.zero_()
+    graph.replay()
+    assert torch.equal(out, ref)
+    depth.mul_(0.5)
+    graph.replay()
+    assert float((out - ref * 0.5).abs().max()) <= 1e-5

@@ -1,4 +1,5 @@
-"""Fused depth (x) context pooling: scheduled vs frame-major walk, B flagship frames: tools/time_fused_pool.py [B]"""
+"""Fused depth (x) context pooling, B flagship frames: column formulation (pass 1 + pass 2) vs the cell-centric kernels
+(camera-sector schedule / frame-major walk).  tools/time_fused_pool.py [B]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,16 +17,17 @@ g = torch.Generator(device=dev).manual_seed(1)
 depth = torch.softmax(torch.randn((B * ncam, dbins, fh, fw), generator=g, device=dev), 1).reshape(-1)
 ctx = torch.randn((B * ncam * fh * fw, C), generator=g, device=dev)
 outs = {}
-for name, flag in (("frame-major", False), ("scheduled", True)):
+for name, mode, flag in (("cells frame-major", "cells", False), ("cells scheduled", "cells", True), ("columns", "columns!", True)):
     bp._FUSED_SCHEDULE = flag
-    for _ in range(3): o = plan.launch_fused(depth, ctx, dbins, fh, fw)
+    for _ in range(3): o = plan.launch_fused(depth, ctx, dbins, fh, fw, mode=mode)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(30): o = plan.launch_fused(depth, ctx, dbins, fh, fw)
+    for _ in range(30): o = plan.launch_fused(depth, ctx, dbins, fh, fw, mode=mode)
     b.record(); b.synchronize()
     outs[name] = o.clone()
     print(f"{name}: {a.elapsed_time(b)/30*1e3:.1f} us per {B} frames = {a.elapsed_time(b)/30*1e3/B:.1f} us/frame")
-print("bit-identical:", torch.equal(outs["frame-major"], outs["scheduled"]))
-perm, cuts = plan.fused_schedule(dbins, fh, fw)
-print("chunk boundaries:", cuts.tolist())
+print("cells variants bit-identical:", torch.equal(outs["cells frame-major"], outs["cells scheduled"]))
+print("columns vs cells max |diff|:", float((outs["columns"] - outs["cells scheduled"]).abs().max()), "max |out|:", float(outs["columns"].abs().max()))
+cols = plan.fused_columns(dbins, fh, fw, C, force=True)
+print(f"runs {cols.nruns} for {cols.n_kept} kept points ({cols.n_kept / max(cols.nruns, 1):.1f} points per run); partial rows {cols.nruns * C * 4 / 1e6:.1f} MB")
