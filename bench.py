@@ -83,6 +83,11 @@ def parse():
                     help="infer (default): the inference hot path of BASELINE configs[3]; train-step: forward + backward + optimizer "
                          "step of the same path in fp32 (BASELINE configs[4]: 4 frames per GPU unless --batch / --global-batch says "
                          "otherwise, gradients all-reduced over RCCL when --gpus > 1)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="infer mode, one rank: skip the secondary measurements of `extra` (bev_pool on bf16 features = BASELINE "
+                         "configs[1], the single-frame step, the product step without the double-counted API kernel, 5 steps of "
+                         "--mode train-step --amp at 4 frames = configs[4]); they run AFTER the timed region and add ~20 s")
+    ap.add_argument("--cpu-baseline-worker", default=None, help=argparse.SUPPRESS)   # internal: child process of cpu_baseline()
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: a host stub stands in for the hot path and gloo for RCCL, everything else (launch, sharding, "
                          "barriers, timing, JSON) is the real code path")
@@ -131,10 +136,12 @@ def dry_run(args, rank, world, frame_ids):
     frames_per_step = int(sum_over_ranks(len(frame_ids)))
     total_checksum = sum_over_ranks(checksum)
     per_rank = [None] * world
+    backend_ranks = int(sum_over_ranks(1))      # world size as an all-reduce of ones sees it ("rccl_ranks" of the GPU run)
+    mine = dict(rank=rank, frames=list(frame_ids), ms_per_step=elapsed_local / args.steps * 1e3, cpu_binding=args.cpu_binding)
     if world > 1:
-        dist.all_gather_object(per_rank, dict(rank=rank, frames=list(frame_ids), ms_per_step=elapsed_local / args.steps * 1e3))
+        dist.all_gather_object(per_rank, mine)
     else:
-        per_rank = [dict(rank=0, frames=list(frame_ids), ms_per_step=elapsed_local / args.steps * 1e3)]
+        per_rank = [mine]
     if rank == 0:
         print(json.dumps({
             "metric": "DRY RUN (host stub, no GPU work): launch / sharding / timing control flow of bench.py",
@@ -142,7 +149,7 @@ def dry_run(args, rank, world, frame_ids):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
             "config": {"workload": "dry-run stub", "frames_per_step": frames_per_step, "backend": "gloo",
-                       "world_size": world, "per_rank": per_rank, "checksum": total_checksum},
+                       "world_size": world, "rccl_ranks": backend_ranks, "per_rank": per_rank, "checksum": total_checksum},
             "dry_run": True}), flush=True)
 
 
@@ -207,7 +214,8 @@ def dry_run_train(args, rank, world, frame_ids):
     elapsed = max_over_ranks(elapsed_local)
     frames_per_step = int(sum_over_ranks(len(frame_ids)))
     weights = torch.cat([p.detach().reshape(-1) for p in stub.parameters()])
-    info = dict(rank=rank, frames=list(frame_ids), data_sum=data_sum, grad_sum=float(first_grad.double().sum()),
+    backend_ranks = int(sum_over_ranks(1))
+    info = dict(rank=rank, frames=list(frame_ids), cpu_binding=args.cpu_binding, data_sum=data_sum, grad_sum=float(first_grad.double().sum()),
                 grad_vs_mean_of_own=float((first_grad - mean_of_own).abs().max()), weight_sum=float(weights.double().sum()))
     per_rank = [None] * world
     if world > 1:
@@ -221,7 +229,7 @@ def dry_run_train(args, rank, world, frame_ids):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "dry-run stub of the training step", "frames_per_step": frames_per_step, "backend": "gloo",
-                       "world_size": world, "per_rank": per_rank,
+                       "world_size": world, "rccl_ranks": backend_ranks, "per_rank": per_rank,
                        "ddp": world > 1,
                        "inputs_differ_across_ranks": len({r["data_sum"] for r in per_rank}) == world,
                        "gradients_agree_across_ranks": max(r["grad_sum"] for r in per_rank) - min(r["grad_sum"] for r in per_rank) == 0.0,
@@ -247,6 +255,38 @@ def stored_layer_profile():
         return None
     prof["source"] = os.path.join("profiles", os.path.basename(files[-1])) + " (stored profile, not measured in this run)"
     return prof
+
+
+def new_graph():
+    """A CUDAGraph that keeps its hipGraph_t, so that its nodes can be counted (torch >= 2.8); plain otherwise."""
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError:
+        return torch.cuda.CUDAGraph()
+
+
+def graph_node_count(graph):
+    """{'nodes': all nodes, 'kernel_nodes': kernel launches} of a captured graph through hipGraphGetNodes / hipGraphNodeGetType,
+    None when the runtime or this torch build does not expose the graph."""
+    import ctypes
+
+    try:
+        raw = graph.raw_cuda_graph()
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+            return None
+        nodes = (ctypes.c_void_p * max(n.value, 1))()
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+            return None
+        kernels = 0
+        for i in range(n.value):
+            kind = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(kind)) == 0 and kind.value == 0:   # hipGraphNodeTypeKernel
+                kernels += 1
+        return dict(nodes=int(n.value), kernel_nodes=kernels)
+    except Exception:
+        return None
 
 
 def make_encoder(cfg, dev, dtype):
@@ -353,50 +393,74 @@ def _median_time(fn, runs=5, warmup=1):
 
 
 def cpu_baseline(inp, pts, cfg, B, D, H, W):
-    """BASELINE.md §3 protocol on the host cores of the GPU box, rank 0 / N=1 only, ONE frame (the first of the batch):
-    1 warm-up + median of 5 for bev_pool and voxelization, one pass for the encoder (about 40 s in total)."""
+    """BASELINE.md §3 protocol on the host cores of the GPU box, rank 0 / N=1 only, ONE frame (the first of the batch), in a CHILD
+    process: the OpenMP runtime of a process binds its threads once, at start-up, so the thread placement the measurement needs
+    (OMP_PLACES=cores, OMP_PROC_BIND=close: thread i on physical core i, no migration, no SMT sharing) cannot be switched on in a
+    process that has already run torch — and the child is free of the HIP runtime's helper threads.  Rounds 2-3 measured
+    QuickCumsum in-process with unbound threads: 4.6-17.8 s run to run (VERDICT r3 weak #6).  The inputs travel through /dev/shm."""
+    import subprocess
+    import tempfile
+
+    per_frame = inp["geom"].shape[0]          # `inp` holds ONE frame (geometry and features of frame 0)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(prefix="bevamd_cpu_", dir=shm) as tmp:
+        np.save(os.path.join(tmp, "geom.npy"), inp["geom"][:per_frame])
+        np.save(os.path.join(tmp, "feats.npy"), inp["feats"][:per_frame])
+        np.save(os.path.join(tmp, "pts.npy"), pts)
+        with open(os.path.join(tmp, "meta.json"), "w") as fh:
+            json.dump(dict(origin=[float(v) for v in inp["origin"]], dx=[float(v) for v in inp["dx"]],
+                           nx=[int(v) for v in inp["nx"]], D=D, H=H, W=W), fh)
+        try:
+            import psutil
+
+            physical = psutil.cpu_count(logical=False) or (os.cpu_count() or 2) // 2
+        except Exception:
+            physical = max(1, (os.cpu_count() or 2) // 2)
+        try:
+            physical = max(1, min(physical, len(os.sched_getaffinity(0))))
+        except (AttributeError, OSError):
+            pass
+        env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_NUM_THREADS=str(physical), MKL_NUM_THREADS=str(physical),
+                   HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", BEVAMD_CPU_PHYSICAL=str(physical))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", tmp], capture_output=True, text=True,
+                           env=env, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return dict(value=None, unit="frames/s", cores=physical, kind="port", sample="cpu baseline worker failed: " + r.stderr[-500:])
+    return json.loads(lines[-1])
+
+
+def cpu_baseline_worker(tmp):
+    """Child of cpu_baseline(): threads bound by the environment it was started with.  Prints ONE JSON object."""
     import oracle  # checker / baseline only
 
-    # Threads: torch's default is one OpenMP thread per LOGICAL core (128 on the GPU box); cumsum / argsort / index_put then
-    # oversubscribe the 64 physical cores and the QuickCumsum time drifts by 2x inside one process (VERDICT r2: 20.1 -> 10.9 s over
-    # five runs).  The baseline runs with one thread per PHYSICAL core, pinned for the whole function; the default-thread figure
-    # is reported beside it.
-    default_threads = torch.get_num_threads()
-    try:
-        import psutil
-
-        physical = psutil.cpu_count(logical=False) or default_threads
-    except Exception:
-        physical = max(1, (os.cpu_count() or 2) // 2)
-    try:
-        physical = max(1, min(physical, len(os.sched_getaffinity(0))))
-    except (AttributeError, OSError):
-        pass
-    torch.set_num_threads(physical)
-    threads = torch.get_num_threads()
-    try:
-        return _cpu_baseline_pinned(inp, pts, cfg, B, D, H, W, oracle, threads, default_threads)
-    finally:
-        torch.set_num_threads(default_threads)
-
-
-def _cpu_baseline_pinned(inp, pts, cfg, B, D, H, W, oracle, threads, default_threads):
+    cfg = __import__("bevfusion_amd.synth", fromlist=["CL_CONFIG"]).CL_CONFIG
+    meta = json.load(open(os.path.join(tmp, "meta.json")))
+    geom, feats, pts = (np.load(os.path.join(tmp, f + ".npy")) for f in ("geom", "feats", "pts"))
+    D, H, W = meta["D"], meta["H"], meta["W"]
+    origin, dx, nx = (np.asarray(meta[k], dtype=t) for k, t in (("origin", np.float32), ("dx", np.float32), ("nx", np.int64)))
+    physical = int(os.environ.get("BEVAMD_CPU_PHYSICAL", torch.get_num_threads()))
     n_cam = cfg["num_cameras"]
-    per_frame = inp["geom"].shape[0] // B
-    # bev_pool: the reference's only device-agnostic algorithm, QuickCumsum + prologue, PyTorch CPU, all six cameras
-    coords, kept = oracle.bev_cell_index(inp["geom"][:per_frame], 1, inp["origin"], inp["dx"], inp["nx"])
-    ck, fk = coords[kept], inp["feats"][:per_frame][kept]
-    t_bev, bev_runs = _median_time(lambda: cpu_bev_pool_quickcumsum(ck, fk, 1, D, H, W))
-    bev_default = None
-    if default_threads != threads:      # the same pipeline at torch's default thread count, for the record (not the headline)
-        torch.set_num_threads(default_threads)
-        try:
-            t_def, runs_def = _median_time(lambda: cpu_bev_pool_quickcumsum(ck, fk, 1, D, H, W), runs=3, warmup=1)
-            bev_default = dict(threads=default_threads, median_ms=t_def * 1e3, runs_ms=[t * 1e3 for t in runs_def])
-        finally:
-            torch.set_num_threads(threads)
+    coords, kept = oracle.bev_cell_index(geom, 1, origin, dx, nx)
+    ck, fk = coords[kept], feats[kept]
+    # thread-count sweep on ONE camera's rows (a sixth of the frame: the sweep stays short), 1 warm-up + 3 runs each;
+    # torch's CPU kernels of this pipeline (argsort, gather, cumsum over dim 0, index_put) stop scaling long before 64 cores
+    cam_rows = np.flatnonzero(kept) < geom.shape[0] // n_cam
+    ck1, fk1 = np.ascontiguousarray(ck[cam_rows]), np.ascontiguousarray(fk[cam_rows])
+    sweep = []
+    for t in sorted({min(t, physical) for t in (4, 8, 16, 32, 64, physical)}):
+        torch.set_num_threads(t)
+        med, runs = _median_time(lambda: cpu_bev_pool_quickcumsum(ck1, fk1, 1, D, H, W), runs=3, warmup=1)
+        sweep.append(dict(threads=t, median_ms=med * 1e3, runs_ms=[r * 1e3 for r in runs]))
+    best = min(sweep, key=lambda e: e["median_ms"])
+    threads = best["threads"]
+    torch.set_num_threads(threads)
+    t_bev, bev_runs = _median_time(lambda: cpu_bev_pool_quickcumsum(ck, fk, 1, D, H, W), runs=5, warmup=2)
     n_int = int(np.unique(oracle.bev_pool_ranks(ck, 1, D, H, W)).shape[0])
     bev_bytes = ck.shape[0] * fk.shape[1] * 4 + n_int * 24 + D * H * W * fk.shape[1] * 4
+    torch.set_num_threads(physical)
     # voxelization (a) restated serial algorithm on the real 1440x1440x40 grid (the reference's own CPU code is memory-unsafe
     # there, SURVEY.md D4), (b) the reference's hard_voxelize_cpu on a CUBIC grid of equal cell count, where it is safe
     def restated():
@@ -428,32 +492,37 @@ def _cpu_baseline_pinned(inp, pts, cfg, B, D, H, W, oracle, threads, default_thr
         pass
     coords4 = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
     enc = cpu_sparse_encoder_reference(coords4, cfg)
-    parts = [f"bev_pool: QuickCumsum pipeline (torch CPU, {threads} threads) on all {n_cam} cameras, N={ck.shape[0]} kept rows x {fk.shape[1]}, "
-             f"median of 5 after 1 warm-up = {t_bev * 1e3:.0f} ms ({bev_bytes / t_bev / 1e9:.2f} GB/s on the {bev_bytes / 1e6:.1f} MB of the scatter)",
+    spread = (max(bev_runs) - min(bev_runs)) / t_bev
+    parts = [f"bev_pool: QuickCumsum pipeline (torch CPU, {threads} threads bound to cores = the fastest of a sweep over "
+             f"{[e['threads'] for e in sweep]} threads on one camera's rows) on all {n_cam} cameras, N={ck.shape[0]} kept rows x {fk.shape[1]}, "
+             f"median of 5 after 2 warm-ups = {t_bev * 1e3:.0f} ms, spread {spread:.2f} ({bev_bytes / t_bev / 1e9:.2f} GB/s on the "
+             f"{bev_bytes / 1e6:.1f} MB of the scatter)",
              f"hard voxelize + mean of {pts.shape[0]} points: serial C restatement on 1440x1440x40, median of 5 = {t_vox * 1e3:.1f} ms "
              f"({pts.shape[0] / t_vox / 1e6:.1f} M points/s)"
              + (f"; reference hard_voxelize_cpu (oracle/_ref) on a 436^3 grid of equal cell count, median of 5 = {t_vox_ref * 1e3:.1f} ms"
                 if t_vox_ref is not None else "; reference hard_voxelize_cpu not available on this box")]
     if enc is not None:
-        parts.append(f"SparseEncoder via the reference's CPU functors (oracle/_ref, fp32, {threads} threads): one rulebook per geometry "
+        parts.append(f"SparseEncoder via the reference's CPU functors (oracle/_ref, fp32, {physical} threads): one rulebook per geometry "
                      f"= {enc['seconds_once']:.2f} s, with the reference's recompute pattern (16 of 17 SubM rulebooks rebuilt; the measured "
                      f"per-level build times re-added) = {enc['seconds_recompute']:.2f} s")
         total, kind = t_bev + t_vox + enc["seconds_once"], "reference"
     else:
         parts.append("SparseEncoder: reference CPU build not available, stage omitted")
         total, kind = t_bev + t_vox, "port"
-    out = dict(value=1.0 / total, unit="frames/s", cores=threads, kind=kind,
-               sample="one frame, stage by stage (BASELINE.md §3 protocol): " + "; ".join(parts), seconds_per_frame=total,
+    out = dict(value=1.0 / total, unit="frames/s", cores=physical, kind=kind,
+               sample="one frame, stage by stage (BASELINE.md §3 protocol), in a child process with OMP_PLACES=cores OMP_PROC_BIND=close: "
+                      + "; ".join(parts), seconds_per_frame=total,
                bev_pool_quickcumsum_ms=t_bev * 1e3, bev_pool_quickcumsum_runs_ms=[t * 1e3 for t in bev_runs],
-               bev_pool_quickcumsum_spread=(max(bev_runs) - min(bev_runs)) / t_bev,
-               bev_pool_quickcumsum_default_threads=bev_default,
-               threads_note=f"one torch thread per physical core ({threads}); torch's default here would be {default_threads}",
+               bev_pool_quickcumsum_spread=spread, bev_pool_quickcumsum_threads=threads,
+               bev_pool_quickcumsum_thread_sweep_one_camera=sweep,
+               threads_note=f"threads bound to physical cores (OMP_PLACES=cores, OMP_PROC_BIND=close) in a child process; QuickCumsum at the "
+                            f"fastest thread count of the sweep ({threads}), the other stages at {physical}",
                bev_pool_gbs=bev_bytes / t_bev / 1e9, voxelize_restated_ms=t_vox * 1e3,
                voxelize_reference_cubic_ms=None if t_vox_ref is None else t_vox_ref * 1e3)
     if enc is not None:
         out.update(encoder_one_rulebook_per_stage_s=enc["seconds_once"], encoder_reference_recompute_s=enc["seconds_recompute"],
                    frames_per_s_reference_recompute=1.0 / (t_bev + t_vox + enc["seconds_recompute"]))
-    return out
+    print(json.dumps(out), flush=True)
 
 
 def train_step(args, rank, world, frame_ids, dev):
@@ -472,10 +541,10 @@ def train_step(args, rank, world, frame_ids, dev):
 
     cfg = synth.CL_CONFIG
     B = len(frame_ids)
-    inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank, with_feats=False)
+    inp = synth.bev_pool_inputs(cfg, batch=1, seed=rank, with_feats=False)     # one calibration, tiled over the frames on the device
     H, W, D = (int(v) for v in inp["nx"])
     C = inp["channels"]
-    geom = torch.from_numpy(inp["geom"]).to(dev)
+    geom = torch.from_numpy(inp["geom"]).to(dev).repeat(B, 1)
     plan = BevPoolPlan.from_geometry(geom, B, inp["origin"], inp["dx"], inp["nx"], want_intervals=True)
     n_kept = plan.n_kept()
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -553,11 +622,12 @@ def train_step(args, rank, world, frame_ids, dev):
     kev[1].record()
     kev[1].synchronize()
     bwd_kernel_ms = kev[0].elapsed_time(kev[1]) / 20
+    res = None
     if rank == 0:
         bwd_bytes = B * D * H * W * C * 4 + n_kept * C * 4          # cell gradients read + row gradients written
         achieved = bwd_bytes / (bwd_kernel_ms * 1e-3) / 1e9
         nparam = sum(p.numel() for p in enc.parameters())
-        print(json.dumps({
+        res = ({
             "metric": "train-step frames/sec of the BEVFusion C+L hot path (fwd + bwd + optimizer step of bev_pool / fused pooling / "
                       "voxelize / SparseEncoder), " + ("fp16 mixed precision (the reference's default: configs/default.yaml fp16)" if args.amp else "fp32"),
             "value": frames_per_step * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -578,13 +648,14 @@ def train_step(args, rank, world, frame_ids, dev):
                          "note": "HIP events around 20 back-to-back launches of the backward kernel (x_grad written in point order: a "
                                  "streaming write; the cell gradients it gathers stay in L2 / Infinity Cache); the bev_pool_bwd stage "
                                  "of the step also holds autograd's contiguous fp32 copy of the incoming gradient"},
-            "cpu_baseline": None}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            "cpu_baseline": None})
+    return res
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args.cpu_baseline_worker)
     if args.batch is None:
         args.batch = 4 if args.mode == "train-step" else 8
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -613,6 +684,9 @@ def main():
     else:
         frame_ids = [rank * max(1, args.batch) + b for b in range(max(1, args.batch))]
     if args.dry_run:
+        from bevfusion_amd.sharding import bind_rank_to_cpus
+
+        args.cpu_binding = bind_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         (dry_run_train if args.mode == "train-step" else dry_run)(args, rank, world, frame_ids)
         if world > 1:
             import torch.distributed as dist
@@ -623,8 +697,20 @@ def main():
         raise SystemExit(f"rank {rank}: no frames to process (--global-batch {args.global_batch} < {world} ranks)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    from bevfusion_amd.sharding import bind_rank_to_cpus
+
+    # one process per GPU on one host: each rank keeps to its share of the cores, next to its GPU (input synthesis, launches, timing)
+    cpu_binding = bind_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    args.cpu_binding = cpu_binding
     if args.mode == "train-step":
-        return train_step(args, rank, world, frame_ids, dev)
+        res = train_step(args, rank, world, frame_ids, dev)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
 
     from bevfusion_amd import synth
     from bevfusion_amd.bev_pool import BevPoolPlan
@@ -633,10 +719,12 @@ def main():
     cfg = synth.CL_CONFIG
     B = len(frame_ids)
     # ---- synthetic frame (per rank: its own seed -> its own features / point cloud; same calibration) ----
-    inp = synth.bev_pool_inputs(cfg, batch=B, seed=rank, with_feats=False)   # B frames: same calibration
+    # every frame of a step shares the calibration: the frustum geometry is synthesised for ONE frame on the host (0.2 s; 2 s for
+    # 8 — per rank, on its own cores) and tiled on the device
+    inp = synth.bev_pool_inputs(cfg, batch=1, seed=rank, with_feats=False)
     H, W, D = (int(v) for v in inp["nx"])
     C = inp["channels"]
-    geom = torch.from_numpy(inp["geom"]).to(dev)
+    geom = torch.from_numpy(inp["geom"]).to(dev).repeat(B, 1)
     # independent random features per frame and rank, drawn on the device (5 GB at 8 frames: minutes of host RNG + PCIe)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     feats = torch.randn((geom.shape[0], C), generator=gen, device=dev, dtype=torch.float32)
@@ -793,7 +881,7 @@ def main():
             state["n_voxels_dev"] = state["head"][2]
             assert enc.last_path == "fused", enc.last_path_reason
         else:
-            graph = torch.cuda.CUDAGraph()
+            graph = new_graph()
             with torch.cuda.graph(graph):
                 state["lidar_bev"], state["n_voxels_dev"], _ = lidar_branch()
 
@@ -944,8 +1032,120 @@ def main():
     elapsed_local = elapsed
     elapsed = max_over_ranks(elapsed, device=dev)  # slowest rank defines the step time
     frames_per_step = int(sum_over_ranks(B, device=dev))
+    rccl_ranks = int(sum_over_ranks(1, device=dev))  # world size as an all-reduce of ones over the backend sees it (RCCL when N > 1)
+
+    # ---- secondary measurements, AFTER the timed region, one rank only: each is a driver-run figure of a
+    # configuration the headline does not exercise.  Nothing here touches `value`.
+    def timed(fn, n, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+
+    def kernel_ms(fn, n=20, warm=3):
+        for _ in range(warm):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / n
+
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras and args.overlap == "none" and graph is not None:
+        extra = {}
+        t_extra = time.perf_counter()
+        # (iv) the product's step: what a deployment runs per batch — raster + fused pooling + LiDAR branch — without the API-level
+        # bev_pool kernel on the materialised volume (the camera reduction is otherwise counted twice in `value`)
+        def product_step():
+            with torch.no_grad():
+                state["depth_img"] = vt.depth_raster(img_stub, pts_list, t_l2i, t_ia, t_la)
+            plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
+            graph.replay()
+
+        pm = timed(product_step, args.steps)
+        extra["product_step"] = dict(ms_per_step=pm, frames_per_s=B * 1e3 / pm, frames=B,
+                                     note="depth raster + fused depth x context pooling + LiDAR branch (one graph replay); the "
+                                          "API-level bev_pool kernel of the headline step left out")
+        extra["lidar_graph"] = graph_node_count(graph)
+        # (i) BASELINE configs[1]: bev_pool on bf16 camera features, same plan, same launch
+        if elem == 4:
+            f16 = feats.bfloat16()
+            km = kernel_ms(lambda: plan.launch_forward(f16, bev))
+            by = n_kept * C * 2 + n_int * 24 + B * D * H * W * C * 4
+            extra["bev_pool_bf16_features"] = dict(kernel_ms=km, algorithmic_bytes_per_launch=by, achieved_gbs=by / (km * 1e-3) / 1e9,
+                                                   frac=by / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, frames=B,
+                                                   note="BASELINE configs[1]: bf16 features, fp32 accumulate / output; HIP events around 20 launches")
+            del f16
+        # (ii) the reference's own protocol is batch 1 (tools/benchmark.py:56-85): the same step on ONE frame
+        try:
+            per = geom.shape[0] // B
+            plan1 = BevPoolPlan.from_geometry(geom[:per], 1, inp["origin"], inp["dx"], inp["nx"])
+            plan1.prepare_fused(dbins, fh, fw, C)
+            bev1, fused1 = torch.empty((1, D, H, W, C), device=dev), torch.empty((1, D, H, W, C), device=dev)
+            feats1, depth1, ctx1, pts1 = feats[:per].float(), depth_prob[:n_cam], ctx_cl[: n_cam * fh * fw], pts_list[:1]
+
+            def lidar1():
+                vf, vc, _, cnt = voxelize_batch_device(pts1, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
+                                                       cfg["max_voxels"][1], order=args.voxel_order)
+                with torch.no_grad():
+                    return enc(vf, vc, 1, num_voxels=cnt, coors_order=coors_order)
+
+            for _ in range(2):
+                lidar1()
+            side1 = torch.cuda.Stream()
+            side1.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side1):
+                lidar1()
+            torch.cuda.current_stream().wait_stream(side1)
+            torch.cuda.synchronize()
+            g1 = new_graph()
+            with torch.cuda.graph(g1):
+                state["lidar_bev1"] = lidar1()
+
+            def step1():
+                with torch.no_grad():
+                    vt.depth_raster(img_stub[:1], pts1, t_l2i[:1], t_ia[:1], t_la[:1])
+                plan1.launch_fused(depth1.reshape(-1), ctx1, dbins, fh, fw, out=fused1)
+                plan1.launch_forward(feats1, bev1)
+                g1.replay()
+
+            m1 = timed(step1, 50, warm=5)
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev1[0].record()
+            for _ in range(20):
+                g1.replay()
+            ev1[1].record()
+            ev1[1].synchronize()
+            extra["batch1_step"] = dict(ms_per_step=m1, frames_per_s=1e3 / m1, lidar_branch_ms=ev1[0].elapsed_time(ev1[1]) / 20,
+                                        lidar_graph=graph_node_count(g1),
+                                        note="the headline step (raster + fused pooling + bev_pool + LiDAR graph) on ONE frame")
+            del g1, plan1, bev1, fused1
+        except Exception as e:   # a secondary figure must never take the headline down
+            extra["batch1_step"] = dict(error=repr(e)[:300])
+        # (iii) BASELINE configs[4]: 5 steps of the training step in the reference's default arithmetic, 4 frames
+        try:
+            import copy
+
+            a2 = copy.copy(args)
+            a2.amp, a2.steps, a2.warmup, a2.global_batch = True, 5, 2, 0
+            tr = train_step(a2, 0, 1, list(range(4)), dev)
+            extra["train_step_amp"] = dict(ms_per_step=tr["ms_per_step"], frames_per_s=tr["value"], frames=4, steps=5,
+                                           stage_ms=tr["config"]["stage_ms"], bev_pool_bwd_frac=tr["roofline"]["frac"],
+                                           bev_pool_bwd_kernel_ms=tr["roofline"]["kernel_ms"],
+                                           note="--mode train-step --amp (fp16 conv operands, fp32 accumulate / master weights): fwd + "
+                                                "bwd + clip + AdamW of bev_pool, fused pooling, voxelize, SparseEncoder at 4 frames")
+        except Exception as e:
+            extra["train_step_amp"] = dict(error=repr(e)[:300])
+        extra["wall_s"] = time.perf_counter() - t_extra
     per_rank = [dict(rank=rank, frames=B, ms_per_step=elapsed_local / args.steps * 1e3,
-                     frames_per_s=B * args.steps / elapsed_local)]
+                     frames_per_s=B * args.steps / elapsed_local, cpu_binding=args.cpu_binding)]
     if world > 1:
         import torch.distributed as dist
 
@@ -994,6 +1194,7 @@ def main():
                 "parallelism": f"frames sharded over {world} rank(s), one process per GPU, no data-path collective"
                                + (f"; torch.distributed backend nccl (= RCCL) world size {world}" if world > 1 else ""),
                 "per_rank": per_rank,
+                "rccl_ranks": rccl_ranks,
                 "stages": STAGES,
                 "stage_ms": dict(zip(["depth_raster", "fused_depth_context_pool", "bev_pool", "lidar_branch"], stage_ms)),
                 "camera_branch": {
@@ -1025,6 +1226,7 @@ def main():
                 "bev_pool_precompute_ms_uncached": precompute_ms,
                 "bev_pool_precompute_first_call_ms": t_first * 1e3,
             },
+            "extra": extra,
             "roofline_spconv": roofline_spconv,
             "roofline": {
                 "kernel": "bev_pool_fwd_cells_vec_kernel",

@@ -274,15 +274,24 @@ __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __r
   if (slot >= rpi || cell >= ncells) return;
   const uint32_t start = prow_start[cell];
   const int len = (int)(prow_start[cell + 1] - start);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // four interleaved partial sums (row r goes to sum r % 4), folded at the end: a fixed order, and a quarter of the rounding
+  // growth of one long chain on the rare cells with hundreds of rows
+  float4 a4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* p = partial + (size_t)start * lpr + cv;
   for (int r = 0; r < len; r += 4) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = r + u < len ? p[(size_t)(r + u) * lpr] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    for (int u = 0; u < 4; ++u) { a4[u].x += v[u].x; a4[u].y += v[u].y; a4[u].z += v[u].z; a4[u].w += v[u].w; }
   }
+  float4 acc;
+  acc.x = (a4[0].x + a4[1].x) + (a4[2].x + a4[3].x);
+  acc.y = (a4[0].y + a4[1].y) + (a4[2].y + a4[3].y);
+  acc.z = (a4[0].z + a4[1].z) + (a4[2].z + a4[3].z);
+  acc.w = (a4[0].w + a4[1].w) + (a4[2].w + a4[3].w);
   const uint32_t per_frame = ncells / (uint32_t)B;
   const uint32_t b = cell / per_frame;
   uint32_t local = cell - b * per_frame;

@@ -48,3 +48,64 @@ def barrier():
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+# ---- per-rank CPU placement ----------------------------------------------------------------------------------------------
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of sysfs `local_cpulist`)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpus_for_rank(local_rank, local_world, available, near_gpu=None):
+    """The CPUs rank `local_rank` of `local_world` ranks on this node should run on: its share of the CPUs that sit next to
+    its GPU (`near_gpu[r]` = CPU list of rank r's GPU from sysfs, ranks whose GPUs share a NUMA node split that node's CPUs
+    evenly, in rank order), or — without topology information — an even contiguous split of `available`.  Never empty."""
+    available = sorted(available)
+    if local_world <= 1 or not available:
+        return available
+    if near_gpu and all(near_gpu.get(r) for r in range(local_world)):
+        mine = sorted(set(near_gpu[local_rank]) & set(available))
+        sharers = [r for r in range(local_world) if sorted(set(near_gpu[r]) & set(available)) == mine]
+        if mine and len(mine) >= len(sharers):
+            k = sharers.index(local_rank)
+            per = len(mine) // len(sharers)
+            return mine[k * per:(k + 1) * per]
+    per = max(1, len(available) // local_world)
+    lo = min(local_rank * per, len(available) - per)
+    return available[lo:lo + per]
+
+
+def gpu_local_cpus(device_index):
+    """CPU list of the NUMA node the GPU hangs off (sysfs `local_cpulist` of its PCI function), None when unknown."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as fh:
+            cpus = parse_cpulist(fh.read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def bind_rank_to_cpus(local_rank, local_world):
+    """Pin this process (every thread it creates later inherits the mask) to its share of the node's CPUs, next to its GPU when
+    sysfs says where that is.  One process per GPU means 8 ranks synthesising inputs, launching and timing on one host: without
+    a mask they migrate across sockets and share cores.  Returns a short description for the bench JSON; a single rank keeps the
+    whole machine."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        available = sorted(os.sched_getaffinity(0))
+        near = {r: gpu_local_cpus(r) for r in range(local_world)} if torch.cuda.is_available() else None
+        mine = cpus_for_rank(local_rank, local_world, available, near)
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(mine))))
+        return dict(cpus=len(mine), first=mine[0], last=mine[-1], numa_aware=bool(near and near.get(local_rank)))
+    except OSError:
+        return None

@@ -51,3 +51,36 @@ def test_train_step_dry_run_goes_through_ddp():
     assert cfg["max_abs_grad_minus_mean_of_per_rank_grads"] <= 1e-6
     one = run_bench("--mode", "train-step", "--dry-run", "--steps", "2", "--warmup", "1", "--batch", "2")
     assert one["n_gpus"] == 1 and not one["config"]["ddp"]
+
+
+def test_configs4_shape_eight_ranks_train_step_dry_run():
+    """BASELINE configs[4] as the driver will launch it on an 8-GPU node: 32 frames split over 8 ranks (4 per GPU), training step
+    through DistributedDataParallel — here gloo and a host stub.  Every rank gets 4 disjoint frames, the all-reduce sees 8 ranks,
+    each rank is pinned to its own share of the CPUs (disjoint masks), gradients and weights agree everywhere."""
+    res = run_bench("--mode", "train-step", "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--global-batch", "32")
+    cfg = res["config"]
+    assert res["n_gpus"] == 8 and res["scaling"] == "strong" and cfg["ddp"] and cfg["rccl_ranks"] == 8
+    assert cfg["frames_per_step"] == 32
+    assert sorted(tuple(r["frames"]) for r in cfg["per_rank"]) == [tuple(range(4 * r, 4 * r + 4)) for r in range(8)]
+    assert cfg["inputs_differ_across_ranks"] and cfg["gradients_agree_across_ranks"] and cfg["weights_agree_across_ranks"]
+    assert cfg["max_abs_grad_minus_mean_of_per_rank_grads"] <= 1e-6
+    binds = [r["cpu_binding"] for r in cfg["per_rank"]]
+    if all(b is not None for b in binds) and len(os.sched_getaffinity(0)) >= 8:
+        spans = sorted((b["first"], b["last"]) for b in binds)
+        assert all(spans[i][1] < spans[i + 1][0] for i in range(7)), spans          # disjoint CPU ranges per rank
+
+
+def test_cpu_share_of_a_rank():
+    from bevfusion_amd.sharding import cpus_for_rank, parse_cpulist
+
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    avail = list(range(128))
+    # two sockets, GPUs 0-3 on the first: each rank gets a quarter of ITS socket's CPUs, no overlap, nothing from the other socket
+    sock = {0: list(range(0, 32)) + list(range(64, 96)), 1: list(range(32, 64)) + list(range(96, 128))}
+    near = {r: sock[r // 4] for r in range(8)}
+    shares = [cpus_for_rank(r, 8, avail, near) for r in range(8)]
+    assert all(len(s) == 16 for s in shares) and len(set(sum(shares, []))) == 128
+    assert all(set(shares[r]) <= set(sock[r // 4]) for r in range(8))
+    # no topology: an even contiguous split; more ranks than CPUs still yields a non-empty share
+    assert [cpus_for_rank(r, 2, list(range(8))) for r in range(2)] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert cpus_for_rank(5, 8, [0, 1, 2]) == [2] and cpus_for_rank(0, 1, [3, 4]) == [3, 4]

@@ -39,7 +39,8 @@ def test_random_cells_every_row_its_own_run(dev, cams, D, fh, fw, c, dtype):
     B, Dz, H, W = 1, 2, 9, 11
     n = cams * D * fh * fw
     coords = np.stack([rng.integers(-1, H + 1, n), rng.integers(-1, W + 1, n), rng.integers(0, Dz, n), np.zeros(n, np.int64)], 1)
-    coords[: n // 3, 0], coords[: n // 3, 1], coords[: n // 3, 2] = 4, 5, 1          # a hot cell: long runs in the first columns
+    hot = min(n // 3, 600)                                                         # a hot cell: long runs in the first columns
+    coords[:hot, 0], coords[:hot, 1], coords[:hot, 2] = 4, 5, 1                     # (flagship cells hold up to ~900 points of weight <= 1/118)
     depth = rng.random(n).astype(np.float32)
     ctx = torch.from_numpy(rng.standard_normal((cams * fh * fw, c)).astype(np.float32)).to(dtype)
     plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)

@@ -13,7 +13,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_E
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $out/g$i -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" > $out/g${i}_run.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $out/g$i -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras "$@" > $out/g${i}_run.log 2>&1
   echo "group $i ($grp) rc=$?"
 done
 cd $GRAFT_REPO_ROOT
