@@ -187,6 +187,39 @@ __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out
   }
 }
 
+// The same table with ONE thread per output row walking all K offsets: the row's coordinates are read once (not K times) and the
+// index words its K cells live in are shared with the neighbouring rows of the workgroup (rank index: 8 bytes per 32 cells).  The
+// table column nbr[k][.] is written coalesced across the rows; every entry is written, so nothing has to be cleared first.
+template <int KIND>
+__global__ __launch_bounds__(256) void sp_nbr_rows_kernel(const int* __restrict__ out_indices, int m_cap,
+                                                          const int* __restrict__ m_dev, ConvGeom g, IndexRef ix,
+                                                          int* __restrict__ nbr, int nbr_stride) {
+  int m = m_dev ? *m_dev : m_cap;
+  if (m > m_cap) m = m_cap;
+  int lo, hi;
+  xcd_chunk(m, lo, hi);
+  for (int o = lo + threadIdx.x; o < hi; o += 256) {
+    const int4 c = ((const int4*)out_indices)[o];
+    int k = 0;
+    for (int kx = 0; kx < g.ksize[0]; ++kx) {
+      int ix_ = 0;
+      const bool okx = axis_out_to_in(g, 0, c.y, kx, ix_);
+      for (int ky = 0; ky < g.ksize[1]; ++ky) {
+        int iy = 0;
+        const bool oky = okx && axis_out_to_in(g, 1, c.z, ky, iy);
+        for (int kz = 0; kz < g.ksize[2]; ++kz, ++k) {
+          int iz = 0, r = -1;
+          if (oky && axis_out_to_in(g, 2, c.w, kz, iz)) {
+            const uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
+            r = index_lookup<KIND>(ix, (uint32_t)c.x, key);
+          }
+          nbr[(size_t)k * nbr_stride + o] = r;
+        }
+      }
+    }
+  }
+}
+
 // Strided convolution, neighbour table from the INPUT side: each input row knows the <= prod(ceil(k/s))
 // (output cell, offset) pairs it feeds; the output row is the rank of that cell.  ~10x fewer lookups than
 // probing all K offsets of every output row (most of which have no input).  nbr must be pre-filled with -1.
@@ -693,6 +726,11 @@ static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const 
     if (kind == INDEX_HASH) sp_nbr_subm_sym_kernel<INDEX_HASH><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
     else sp_nbr_subm_sym_kernel<INDEX_RANK><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
     BEVAMD_LAUNCH_CHECK("sp_nbr_subm_sym");
+    return BEVAMD_OK;
+  }
+  if (kind == INDEX_RANK && !g.transpose) {   // neighbouring rows share index words: one thread per row, all offsets
+    sp_nbr_rows_kernel<INDEX_RANK><<<dim3(stride_grid(m_cap)), dim3(256), 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
+    BEVAMD_LAUNCH_CHECK("sp_nbr_rows");
     return BEVAMD_OK;
   }
   dim3 grid(stride_grid(m_cap), g.K), block(256);

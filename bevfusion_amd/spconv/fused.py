@@ -266,7 +266,12 @@ class Level:
         out_indices = torch.empty((cap, 4), dtype=torch.int32, device=dev)
         num_out = torch.empty(1, dtype=torch.int32, device=dev)
         K = ksize[0] * ksize[1] * ksize[2]
-        nbr = torch.empty((K, cap), dtype=torch.int32, device=dev) if want_nbr else None
+        # The table of a strided layer that stays on the gather kernels: from the INPUT side inside bevamd_spconv_downsample (a
+        # -1 fill of 27 * cap words, then every input scatters into the <= 8 outputs it feeds), or — when this (input) level owns a
+        # rank index — from the OUTPUT side afterwards: every output row looks its 27 input cells up (8-byte loads that
+        # neighbouring rows share) and writes its column of the table once, coalesced, no fill (_DOWN_NBR_FROM_OUTPUTS)
+        from_outputs = want_nbr and _DOWN_NBR_FROM_OUTPUTS and self.index_kind == INDEX_RANK
+        nbr = torch.empty((K, cap), dtype=torch.int32, device=dev) if want_nbr and not from_outputs else None
         with torch.cuda.device(dev):
             nbytes = lib.bevamd_spconv_rank_index_bytes(self.batch, _capi.ints(out_shape))
             index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -280,6 +285,8 @@ class Level:
                     allow_slab=self.allow_slab)
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
         out.linear_order = True
+        if from_outputs:
+            nbr = self._neighbors(out_indices, cap, num_out, out_shape, list(ksize), list(stride), list(padding), False)
         out.ready = self._mark()    # behind the downsample: indices, count, rank index and this conv's nbr are final
         self._down[key] = (out, nbr)
         if wait:
@@ -461,6 +468,8 @@ def _narrow_variant_for(conv, lvl, cin, cout):
     return variant if ops.slab_block_rows(cin, variant) else None
 
 
+# neighbour table of the strided gather layers from the output side (rank-index lookups, no fill); 0 = from the input side
+_DOWN_NBR_FROM_OUTPUTS = os.environ.get("BEVAMD_SPCONV_DOWN_NBR", "outputs") != "inputs"
 _STATUS_WORDS = 64
 _STATUS_POOL = os.environ.get("BEVAMD_SPCONV_STATUS_POOL", "1") != "0"
 _PAD_CAST = os.environ.get("BEVAMD_SPCONV_PAD_CAST", "1") != "0"
