@@ -24,6 +24,8 @@
 // run first, then runs): fp32 throughout, <= 1e-4 against float64 (tests/test_gpu_bev_pool.py), deterministic.
 // Long-tailed plans (a camera rolled by 90 degrees: as many runs as points) keep the cell-centric kernel: the host decides from
 // the run count.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace bevamd {
@@ -262,24 +264,15 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
 }
 
 // ---- pass 2 ---------------------------------------------------------------------------------------------------------------
-// lpr lanes per cell, rpi cells per wave; a cell's partial rows are consecutive and are added in order
-__global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __restrict__ partial,
-                                                               const uint32_t* __restrict__ prow_start, uint32_t ncells,
-                                                               float* __restrict__ out, int lpr, int rpi, int B, int D, int H, int W,
-                                                               int C) {
-  const int lane = threadIdx.x & 63;
-  const int slot = lane / lpr, cv = lane - slot * lpr;
-  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const uint32_t cell = wave * (uint32_t)rpi + (uint32_t)slot;     // frame-major: b * (D*H*W) + (x * W + y) * D + z
-  if (slot >= rpi || cell >= ncells) return;
-  const uint32_t start = prow_start[cell];
-  const int len = (int)(prow_start[cell + 1] - start);
+// lpr lanes per cell, rpi cells per wave instruction, TWO cell groups per wave in flight (two thirds of the cells are empty and the
+// rest hold one or two rows: the kernel is a chain of short dependent loads — CSR bounds, rows, store — so each lane keeps two
+// independent chains going); a cell's partial rows are consecutive and are added in a fixed order
+__device__ __forceinline__ float4 reduce_rows(const float4* __restrict__ p, int len, int lpr) {
   // four interleaved partial sums (row r goes to sum r % 4), folded at the end: a fixed order, and a quarter of the rounding
   // growth of one long chain on the rare cells with hundreds of rows
   float4 a4[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) a4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* p = partial + (size_t)start * lpr + cv;
   for (int r = 0; r < len; r += 4) {
     float4 v[4];
 #pragma unroll
@@ -292,22 +285,63 @@ __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __r
   acc.y = (a4[0].y + a4[1].y) + (a4[2].y + a4[3].y);
   acc.z = (a4[0].z + a4[1].z) + (a4[2].z + a4[3].z);
   acc.w = (a4[0].w + a4[1].w) + (a4[2].w + a4[3].w);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __restrict__ partial,
+                                                               const uint32_t* __restrict__ prow_start, uint32_t ncells,
+                                                               float* __restrict__ out, int lpr, int rpi, int B, int D, int H, int W,
+                                                               int C) {
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / lpr, cv = lane - slot * lpr;
+  if (slot >= rpi) return;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  // frame-major cells: b * (D*H*W) + (x * W + y) * D + z; this wave owns 2 * rpi consecutive cells
+  const uint32_t c0 = wave * (uint32_t)(2 * rpi) + (uint32_t)slot, c1 = c0 + (uint32_t)rpi;
+  const bool ok0 = c0 < ncells, ok1 = c1 < ncells;
+  if (!ok0) return;
+  const uint32_t s0 = prow_start[c0], e0 = prow_start[c0 + 1];
+  const uint32_t s1 = ok1 ? prow_start[c1] : 0u, e1 = ok1 ? prow_start[c1 + 1] : 0u;
+  const int len0 = (int)(e0 - s0), len1 = (int)(e1 - s1);
+  float4 acc0, acc1;
+  if (len0 <= 2 && len1 <= 2) {   // the common case: both cells' rows requested together
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p0 = partial + (size_t)s0 * lpr + cv;
+    const float4* p1 = partial + (size_t)s1 * lpr + cv;
+    const float4 a = len0 > 0 ? p0[0] : z, b = len0 > 1 ? p0[lpr] : z;
+    const float4 c = len1 > 0 ? p1[0] : z, d = len1 > 1 ? p1[lpr] : z;
+    // same association as reduce_rows for <= 2 rows: (a + b) + (0 + 0)
+    acc0 = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    acc1 = make_float4(c.x + d.x, c.y + d.y, c.z + d.z, c.w + d.w);
+  } else {
+    acc0 = reduce_rows(partial + (size_t)s0 * lpr + cv, len0, lpr);
+    acc1 = reduce_rows(partial + (size_t)s1 * lpr + cv, len1, lpr);
+  }
   const uint32_t per_frame = ncells / (uint32_t)B;
-  const uint32_t b = cell / per_frame;
-  uint32_t local = cell - b * per_frame;
-  const uint32_t gz = local % (uint32_t)D; local /= (uint32_t)D;
-  const uint32_t gy = local % (uint32_t)W;
-  const uint32_t gx = local / (uint32_t)W;
-  // out[b, z, x, y, :] (bev_pool_cuda.cu:33-35)
-  float4* o = (float4*)(out + ((((size_t)b * D + gz) * H + gx) * W + gy) * (size_t)C) + cv;
-  *o = acc;
+  auto store = [&](uint32_t cell, const float4& acc) {
+    const uint32_t b = cell / per_frame;
+    uint32_t local = cell - b * per_frame;
+    const uint32_t gz = local % (uint32_t)D; local /= (uint32_t)D;
+    const uint32_t gy = local % (uint32_t)W;
+    const uint32_t gx = local / (uint32_t)W;
+    // out[b, z, x, y, :] (bev_pool_cuda.cu:33-35)
+    *((float4*)(out + ((((size_t)b * D + gz) * H + gx) * W + gy) * (size_t)C) + cv) = acc;
+  };
+  store(c0, acc0);
+  if (ok1) store(c1, acc1);
 }
 
 static int cols_shape(int c, int depth_bins, int fh, int fw, ColDims& s, size_t& lds_bytes) {
   if (c <= 0 || (c & 3) || (c >> 2) > COL_THREADS || fh <= 0 || fh > 32 || fw <= 0 || (fw % COL_WB) || depth_bins <= 0) return 0;
   s.D = depth_bins; s.fH = fh; s.fW = fw; s.C = c;
   const int dpad = (depth_bins + 3) / 4 * 4;
-  s.DH = dpad < 60 ? dpad : 60;
+  static int dh_max = 0;   // depth bins per tile (tuning: BEVAMD_FUSED_COLS_DH, a multiple of 4; 60 = two tiles for the 118 bins)
+  if (dh_max == 0) {
+    const char* e = getenv("BEVAMD_FUSED_COLS_DH");
+    dh_max = e ? atoi(e) / 4 * 4 : 60;
+    if (dh_max < 4 || dh_max > 128) dh_max = 60;
+  }
+  s.DH = dpad < dh_max ? dpad : dh_max;
   s.ndh = (depth_bins + s.DH - 1) / s.DH;
   s.nwb = fw / COL_WB;
   lds_bytes = ((size_t)fh * COL_WB * c + (size_t)(s.DH / 4) * fh * COL_DEP_PITCH) * sizeof(float);
@@ -452,7 +486,7 @@ int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, i
   }
   const int lpr = c / 4, rpi = 64 / lpr > 0 ? 64 / lpr : 0;
   BEVAMD_REQUIRE(rpi > 0, "bev_pool_fused_forward_columns: c=%d needs more than 64 lanes per row", c);
-  bev_fused_reduce_kernel<<<dim3(cdiv(cdiv(ncells, rpi), 4)), dim3(256), 0, stream>>>((const float4*)partial, prow_start, ncells, out,
+  bev_fused_reduce_kernel<<<dim3(cdiv(cdiv(ncells, 2 * rpi), 4)), dim3(256), 0, stream>>>((const float4*)partial, prow_start, ncells, out,
                                                                                      lpr, rpi, b, d, h, w, c);
   BEVAMD_LAUNCH_CHECK("bev_fused_reduce");
   return BEVAMD_OK;
