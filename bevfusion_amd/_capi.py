@@ -43,6 +43,11 @@ _SIGNATURES = {
     "bevamd_bev_pool_fused_backward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_points": (I, [P, P, P, I, I, I, I, I, I, P]),
+    # training-mode BatchNorm over sparse rows
+    "bevamd_sparse_bn_workspace_bytes": (Z, [I]),
+    "bevamd_sparse_bn_stats": (I, [P, I, LL, I, LL, c_float, c_float, P, P, P, P, P, Z, P]),
+    "bevamd_sparse_bn_apply": (I, [P, I, LL, I, LL, P, P, P, P, P, LL, I, P, LL, P]),
+    "bevamd_sparse_bn_backward": (I, [P, LL, P, LL, P, LL, I, LL, I, I, P, P, P, P, P, P, LL, P, LL, P, Z, P]),
     # view-transform glue
     "bevamd_depth_raster_workspace_bytes": (Z, [I, I, I]),
     "bevamd_depth_raster": (I, [P, I, I, P, P, P, P, I, I, I, P, P, Z, P]),

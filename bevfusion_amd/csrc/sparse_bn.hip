@@ -1,0 +1,401 @@
+// Training-mode BatchNorm1d over sparse feature rows [N, C], with the ReLU and the residual add of the sparse blocks folded in
+// (gfx950).  Reference behaviour kept: ops/sparse_block.py:88-107 (conv - bn - relu - conv - bn - (+identity) - relu),
+// models/backbones/sparse_encoder.py:39 (BN1d, eps 1e-3, momentum 0.01) on torch.nn.BatchNorm1d semantics: batch statistics
+// (biased variance) normalise, running_mean / running_var (unbiased) move by `momentum`.
+//
+// torch runs four kernels per BatchNorm (collect_statistics, transform_input, backward_reduce, backward_elemt: 99 + 35 + 115 +
+// 39 us per layer at 4 frames, profiles/r03_train_step_amp_kernel_trace_stats.txt) plus separate ReLU / add / threshold_backward
+// launches: ~6 of the 31.8 ms of the --amp training step.  Here: two launches forward, two backward, each a streaming pass:
+//   bn_stats      per-channel sum / sum of squares of a row slab per workgroup (fp32), the LAST workgroup to finish adds the
+//                 slab partials up in a fixed order (fp64) -> mean, 1/sqrt(var + eps), running statistics.  Deterministic.
+//   bn_apply      y = ((x - mean) * invstd * w + b -> storage type) [+ residual -> storage type] [ReLU]
+//   bn_bwd_reduce dz = ReLU'(y) * dy;  sum dz, sum dz * xhat per channel (same last-workgroup scheme) = d bias, d weight
+//   bn_bwd_apply  dx = w * invstd * (dz - mean(dz) - xhat * mean(dz * xhat));  d residual = dz
+// Rows are 16-bit (fp16 / bf16: 8 channels per lane) or fp32 (4 per lane); statistics and parameters are fp32.
+#include "common.h"
+
+namespace bevamd {
+namespace bn {
+
+constexpr int THREADS = 256;
+constexpr int MAX_C = 256;
+
+template <int DT> struct Row;          // DT 0: fp32 (4 channels per 16-byte vector), 1: fp16, 2: bf16 (8 per vector)
+template <> struct Row<0> {
+  static constexpr int VEC = 4;
+  typedef float4 V;
+  __device__ static void unpack(const V& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+  __device__ static V pack(const float (&f)[4]) { return make_float4(f[0], f[1], f[2], f[3]); }
+  __device__ static float round(float x) { return x; }
+};
+struct alignas(16) H8 { uint32_t w[4]; };
+template <> struct Row<1> {
+  static constexpr int VEC = 8;
+  typedef H8 V;
+  __device__ static void unpack(const V& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = (float)__builtin_bit_cast(_Float16, (unsigned short)(v.w[i] & 0xFFFFu));
+      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(v.w[i] >> 16));
+    }
+  }
+  __device__ static V pack(const float (&f)[8]) {
+    V v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v.w[i] = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f[2 * i]) |
+               ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f[2 * i + 1]) << 16);
+    return v;
+  }
+  __device__ static float round(float x) { return (float)(_Float16)x; }
+};
+template <> struct Row<2> {
+  static constexpr int VEC = 8;
+  typedef H8 V;
+  __device__ static void unpack(const V& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(v.w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(v.w[i] & 0xFFFF0000u);
+    }
+  }
+  __device__ static unsigned short bf(float x) {   // round to nearest even, NaN kept
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  }
+  __device__ static V pack(const float (&f)[8]) {
+    V v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.w[i] = (uint32_t)bf(f[2 * i]) | ((uint32_t)bf(f[2 * i + 1]) << 16);
+    return v;
+  }
+  __device__ static float round(float x) { return __uint_as_float((uint32_t)bf(x) << 16); }
+};
+
+// rows [lo, hi) of workgroup b when n rows are dealt out as gridDim.x contiguous slabs
+__device__ __forceinline__ void slab_of(long long n, long long& lo, long long& hi) {
+  const long long per = (n + gridDim.x - 1) / gridDim.x;
+  lo = (long long)blockIdx.x * per;
+  hi = lo + per < n ? lo + per : n;
+}
+
+// Per-channel totals of two quantities over all workgroups: every workgroup leaves its slab's sums in part[g][2][C]; the last one
+// to arrive (ticket counter, reset for the next launch) adds them up in slab order in fp64 and hands (A, B) per channel to `fin`.
+template <typename Fin>
+__device__ __forceinline__ void finish_totals(const float* sa, const float* sb, int C, float* __restrict__ part,
+                                              unsigned* __restrict__ ticket, Fin fin) {
+  // sa / sb: this workgroup's sums in LDS, [C] each
+  __shared__ bool last;
+  __shared__ double red[2][THREADS];
+  const int G = (int)gridDim.x;
+  float* mine = part + (size_t)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < C; c += THREADS) {
+    __hip_atomic_store(mine + c, sa[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + C + c, sb[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == (unsigned)G - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // thread -> (channel c, share s of the slabs): nshare = THREADS / C' threads per channel, fixed assignment -> fixed order
+  const int Cp = C <= THREADS ? C : THREADS;
+  const int nshare = THREADS / Cp;
+  for (int c0 = 0; c0 < C; c0 += Cp) {
+    const int c = c0 + (int)threadIdx.x % Cp, s = (int)threadIdx.x / Cp;
+    double a = 0.0, b = 0.0;
+    if (c < C && s < nshare)
+      for (int g = s; g < G; g += nshare) {
+        a += (double)__hip_atomic_load(part + (size_t)g * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += (double)__hip_atomic_load(part + (size_t)g * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < Cp && c < C) {
+      double ta = 0.0, tb = 0.0;
+      for (int s2 = 0; s2 < nshare; ++s2) { ta += red[0][s2 * Cp + threadIdx.x]; tb += red[1][s2 * Cp + threadIdx.x]; }
+      fin(c, ta, tb);
+    }
+    __syncthreads();
+  }
+}
+
+// this workgroup's per-channel sums of (p, q) over its rows -> LDS sa / sb [C]; `rowfn(row, cv, p[VEC], q[VEC])` supplies the terms
+template <int VEC, typename RowFn>
+__device__ __forceinline__ void slab_sums(long long n, int C, float* sa, float* sb, RowFn rowfn) {
+  extern __shared__ float dyn[];   // [rows in flight][2][C]
+  const int lpr = C / VEC, rif = THREADS / lpr;
+  const int r_in = (int)threadIdx.x / lpr, cv = (int)threadIdx.x - r_in * lpr;
+  long long lo, hi;
+  slab_of(n, lo, hi);
+  float p[VEC], q[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) p[j] = q[j] = 0.f;
+  if (r_in < rif)
+    for (long long r = lo + r_in; r < hi; r += rif) rowfn(r, cv, p, q);
+  if (r_in < rif) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      dyn[((size_t)r_in * 2 + 0) * C + cv * VEC + j] = p[j];
+      dyn[((size_t)r_in * 2 + 1) * C + cv * VEC + j] = q[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += THREADS) {   // column sums in row order: deterministic
+    float t = 0.f;
+    for (int r = 0; r < rif; ++r) t += dyn[(size_t)r * 2 * C + c];
+    (c < C ? sa : sb)[c < C ? c : c - C] = t;
+  }
+  __syncthreads();
+}
+
+template <int DT>
+__global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restrict__ x_, long long n, int C, long long stride,
+                                                           float eps, float momentum, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ part,
+                                                           unsigned* __restrict__ ticket) {
+  typedef Row<DT> R;
+  typedef typename R::V V;
+  __shared__ float sa[MAX_C], sb[MAX_C];
+  const char* x = (const char*)x_;
+  const size_t esz = DT == 0 ? 4 : 2;
+  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
+    float f[R::VEC];
+    R::unpack(*(const V*)(x + ((size_t)r * stride + (size_t)cv * R::VEC) * esz), f);
+#pragma unroll
+    for (int j = 0; j < R::VEC; ++j) { p[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+  });
+  finish_totals(sa, sb, C, part, ticket, [&](int c, double s, double ss) {
+    const double m = s / (double)n;
+    double var = ss / (double)n - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+    if (running_var) {
+      const double unbiased = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+  });
+}
+
+template <int DT>
+__global__ __launch_bounds__(THREADS) void bn_apply_kernel(const void* __restrict__ x_, long long n, int C, long long stride,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ weight, const float* __restrict__ bias,
+                                                           const void* __restrict__ res_, long long res_stride, int relu,
+                                                           void* __restrict__ y_, long long y_stride) {
+  typedef Row<DT> R;
+  typedef typename R::V V;
+  const size_t esz = DT == 0 ? 4 : 2;
+  const int lpr = C / R::VEC;
+  const long long total = n * lpr;
+  for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * THREADS) {
+    const long long r = i / lpr;
+    const int cv = (int)(i - r * lpr), c0 = cv * R::VEC;
+    float f[R::VEC], g[R::VEC];
+    R::unpack(*(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz), f);
+    if (res_) R::unpack(*(const V*)((const char*)res_ + ((size_t)r * res_stride + c0) * esz), g);
+#pragma unroll
+    for (int j = 0; j < R::VEC; ++j) {
+      const float w = weight ? weight[c0 + j] : 1.f, b = bias ? bias[c0 + j] : 0.f;
+      // torch's transform_input: (x - mean) * invstd * w + b in fp32, rounded to the storage type; the add and the ReLU of the
+      // block are separate 16-bit tensors in the unfused pipeline, so each rounds once
+      float v = R::round((f[j] - mean[c0 + j]) * invstd[c0 + j] * w + b);
+      if (res_) v = R::round(v + g[j]);
+      if (relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+      f[j] = v;
+    }
+    *(V*)((char*)y_ + ((size_t)r * y_stride + c0) * esz) = R::pack(f);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const void* __restrict__ dy_, long long dy_stride,
+                                                                const void* __restrict__ y_, long long y_stride,
+                                                                const void* __restrict__ x_, long long stride, long long n, int C,
+                                                                int relu, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ sum_dz,
+                                                                float* __restrict__ sum_dz_xhat, float* __restrict__ part,
+                                                                unsigned* __restrict__ ticket) {
+  typedef Row<DT> R;
+  typedef typename R::V V;
+  __shared__ float sa[MAX_C], sb[MAX_C];
+  const size_t esz = DT == 0 ? 4 : 2;
+  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
+    const int c0 = cv * R::VEC;
+    float d[R::VEC], f[R::VEC], o[R::VEC];
+    R::unpack(*(const V*)((const char*)dy_ + ((size_t)r * dy_stride + c0) * esz), d);
+    R::unpack(*(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz), f);
+    if (relu) R::unpack(*(const V*)((const char*)y_ + ((size_t)r * y_stride + c0) * esz), o);
+#pragma unroll
+    for (int j = 0; j < R::VEC; ++j) {
+      const float dz = relu && o[j] <= 0.f ? 0.f : d[j];   // torch's threshold_backward: zero where y <= 0
+      p[j] += dz;
+      q[j] = fmaf(dz, (f[j] - mean[c0 + j]) * invstd[c0 + j], q[j]);
+    }
+  });
+  finish_totals(sa, sb, C, part, ticket, [&](int c, double a, double b) {
+    sum_dz[c] = (float)a;
+    sum_dz_xhat[c] = (float)b;
+  });
+}
+
+template <int DT>
+__global__ __launch_bounds__(THREADS) void bn_bwd_apply_kernel(const void* __restrict__ dy_, long long dy_stride,
+                                                               const void* __restrict__ y_, long long y_stride,
+                                                               const void* __restrict__ x_, long long stride, long long n, int C,
+                                                               int relu, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ weight,
+                                                               const float* __restrict__ sum_dz,
+                                                               const float* __restrict__ sum_dz_xhat, void* __restrict__ dx_,
+                                                               long long dx_stride, void* __restrict__ dres_,
+                                                               long long dres_stride) {
+  typedef Row<DT> R;
+  typedef typename R::V V;
+  const size_t esz = DT == 0 ? 4 : 2;
+  const int lpr = C / R::VEC;
+  const long long total = n * lpr;
+  const float inv_n = 1.f / (float)n;
+  for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * THREADS) {
+    const long long r = i / lpr;
+    const int cv = (int)(i - r * lpr), c0 = cv * R::VEC;
+    float d[R::VEC], f[R::VEC], o[R::VEC];
+    R::unpack(*(const V*)((const char*)dy_ + ((size_t)r * dy_stride + c0) * esz), d);
+    R::unpack(*(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz), f);
+    if (relu) R::unpack(*(const V*)((const char*)y_ + ((size_t)r * y_stride + c0) * esz), o);
+#pragma unroll
+    for (int j = 0; j < R::VEC; ++j) {
+      const float dz = relu && o[j] <= 0.f ? 0.f : d[j];   // torch's threshold_backward: zero where y <= 0
+      d[j] = dz;
+      const float w = weight ? weight[c0 + j] : 1.f;
+      const float xhat = (f[j] - mean[c0 + j]) * invstd[c0 + j];
+      f[j] = w * invstd[c0 + j] * (dz - sum_dz[c0 + j] * inv_n - xhat * (sum_dz_xhat[c0 + j] * inv_n));
+    }
+    *(V*)((char*)dx_ + ((size_t)r * dx_stride + c0) * esz) = R::pack(f);
+    if (dres_) *(V*)((char*)dres_ + ((size_t)r * dres_stride + c0) * esz) = R::pack(d);
+  }
+}
+
+static int check_shape(const char* who, long long n, int c, int dtype) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if (n < 0 || c <= 0 || c > MAX_C || dtype < 0 || dtype > 2 || c % vec != 0 || THREADS % (c / vec) != 0) {
+    set_error("%s: unsupported shape (n >= 0, 0 < c <= %d, c a multiple of %d with c / %d dividing %d): n=%lld c=%d dtype=%d", who,
+              MAX_C, vec, vec, THREADS, n, c, dtype);
+    return BEVAMD_ERR_INVALID_ARG;
+  }
+  return BEVAMD_OK;
+}
+
+static unsigned reduce_grid(long long n, int c, int dtype) {
+  const int vec = dtype == 0 ? 4 : 8, rif = THREADS / (c / vec);
+  long long g = n / ((long long)rif * 16);     // >= 16 trips per workgroup
+  return (unsigned)(g < 1 ? 1 : g > 1024 ? 1024 : g);
+}
+
+static unsigned apply_grid(long long n, int c, int dtype) {
+  const int vec = dtype == 0 ? 4 : 8;
+  long long g = (n * (c / vec) + THREADS * 4 - 1) / (THREADS * 4);
+  return (unsigned)(g < 1 ? 1 : g > 8192 ? 8192 : g);
+}
+
+}  // namespace bn
+}  // namespace bevamd
+
+using namespace bevamd;
+using namespace bevamd::bn;
+
+extern "C" {
+
+/* Scratch of the two reducing kernels: slab partials (fp32) + one ticket word (must be ZERO before the first launch that uses
+ * it; every launch leaves it zero again).  bytes: bevamd_sparse_bn_workspace_bytes(c). */
+size_t bevamd_sparse_bn_workspace_bytes(int c) { return c > 0 ? align_up((size_t)1024 * 2 * c * sizeof(float), 256) + 256 : 0; }
+
+/* Training-mode statistics of x [n, c] (row pitch `stride` elements; dtype 0 fp32 | 1 fp16 | 2 bf16): mean [c], invstd [c] =
+ * 1 / sqrt(biased var + eps) (fp32), and — when given — running_mean / running_var updated in place with `momentum` (unbiased
+ * variance), as torch.nn.BatchNorm1d does in train().  ws: see bevamd_sparse_bn_workspace_bytes. */
+int bevamd_sparse_bn_stats(const void* x, int dtype, long long n, int c, long long stride, float eps, float momentum, float* mean,
+                           float* invstd, float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape("sparse_bn_stats", n, c, dtype);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n > 0 && x && mean && invstd && stride >= c, "sparse_bn_stats: null buffer / no rows / bad pitch");
+  if (!ws || ws_bytes < bevamd_sparse_bn_workspace_bytes(c)) {
+    set_error("sparse_bn_stats: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  float* part = (float*)ws;
+  unsigned* ticket = (unsigned*)((char*)ws + align_up((size_t)1024 * 2 * c * sizeof(float), 256));
+  const unsigned g = reduce_grid(n, c, dtype);
+  const int vec = dtype == 0 ? 4 : 8;
+  const size_t lds = (size_t)(THREADS / (c / vec)) * 2 * c * sizeof(float);
+#define BEVAMD_GO(DT) bn_stats_kernel<DT><<<dim3(g), dim3(THREADS), lds, stream>>>(x, n, c, stride, eps, momentum, mean, invstd, running_mean, running_var, part, ticket)
+  if (dtype == 0) BEVAMD_GO(0); else if (dtype == 1) BEVAMD_GO(1); else BEVAMD_GO(2);
+#undef BEVAMD_GO
+  BEVAMD_LAUNCH_CHECK("bn_stats");
+  return BEVAMD_OK;
+}
+
+/* y = BatchNorm(x) with the given statistics [+ residual] [ReLU], rounded to the storage type after each of the three steps (the
+ * unfused pipeline's tensors).  weight / bias / residual optional (NULL). */
+int bevamd_sparse_bn_apply(const void* x, int dtype, long long n, int c, long long stride, const float* mean, const float* invstd,
+                           const float* weight, const float* bias, const void* residual, long long res_stride, int relu, void* y,
+                           long long y_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape("sparse_bn_apply", n, c, dtype);
+  if (rc) return rc;
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(x && y && mean && invstd && stride >= c && y_stride >= c && (!residual || res_stride >= c),
+                 "sparse_bn_apply: null buffer / bad pitch");
+  const unsigned g = apply_grid(n, c, dtype);
+#define BEVAMD_GO(DT) bn_apply_kernel<DT><<<dim3(g), dim3(THREADS), 0, stream>>>(x, n, c, stride, mean, invstd, weight, bias, residual, res_stride, relu, y, y_stride)
+  if (dtype == 0) BEVAMD_GO(0); else if (dtype == 1) BEVAMD_GO(1); else BEVAMD_GO(2);
+#undef BEVAMD_GO
+  BEVAMD_LAUNCH_CHECK("bn_apply");
+  return BEVAMD_OK;
+}
+
+/* Backward of bevamd_sparse_bn_apply: dz = dy where the forward output y was positive (relu != 0; y may be NULL otherwise);
+ * sum_dz [c] = d bias, sum_dz_xhat [c] = d weight (fp32, deterministic); dx [n, c] in the storage type; d_residual (optional) = dz. */
+int bevamd_sparse_bn_backward(const void* dy, long long dy_stride, const void* y, long long y_stride, const void* x, long long stride,
+                              int dtype, long long n, int c, int relu, const float* mean, const float* invstd, const float* weight,
+                              float* sum_dz, float* sum_dz_xhat, void* dx, long long dx_stride, void* d_residual,
+                              long long dres_stride, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_shape("sparse_bn_backward", n, c, dtype);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n > 0 && dy && x && dx && mean && invstd && sum_dz && sum_dz_xhat && (!relu || y), "sparse_bn_backward: null buffer / no rows");
+  BEVAMD_REQUIRE(stride >= c && dy_stride >= c && dx_stride >= c && (!relu || y_stride >= c) && (!d_residual || dres_stride >= c),
+                 "sparse_bn_backward: bad pitch");
+  if (!ws || ws_bytes < bevamd_sparse_bn_workspace_bytes(c)) {
+    set_error("sparse_bn_backward: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  float* part = (float*)ws;
+  unsigned* ticket = (unsigned*)((char*)ws + align_up((size_t)1024 * 2 * c * sizeof(float), 256));
+  const unsigned g = reduce_grid(n, c, dtype), ga = apply_grid(n, c, dtype);
+  const int vec = dtype == 0 ? 4 : 8;
+  const size_t lds = (size_t)(THREADS / (c / vec)) * 2 * c * sizeof(float);
+#define BEVAMD_GO(DT)                                                                                                              \
+  do {                                                                                                                             \
+    bn_bwd_reduce_kernel<DT><<<dim3(g), dim3(THREADS), lds, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean,      \
+                                                                      invstd, sum_dz, sum_dz_xhat, part, ticket);                  \
+    bn_bwd_apply_kernel<DT><<<dim3(ga), dim3(THREADS), 0, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean, invstd, \
+                                                                    weight, sum_dz, sum_dz_xhat, dx, dx_stride, d_residual,        \
+                                                                    dres_stride);                                                  \
+  } while (0)
+  if (dtype == 0) BEVAMD_GO(0); else if (dtype == 1) BEVAMD_GO(1); else BEVAMD_GO(2);
+#undef BEVAMD_GO
+  BEVAMD_LAUNCH_CHECK("bn_backward");
+  return BEVAMD_OK;
+}
+
+}  // extern "C"

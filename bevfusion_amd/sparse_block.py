@@ -36,15 +36,23 @@ class SparseBasicBlock(spconv.SparseModule):
         return getattr(self, self.norm2_name)
 
     def forward(self, x):
+        from .spconv import bn as native_bn
+
         identity = x.features
         assert x.features.dim() == 2, f"x.features.dim()={x.features.dim()}"
         out = self.conv1(x)
-        out.features = self.norm1(out.features)
-        out.features = self.relu(out.features)
+        if native_bn.usable(self.norm1, out.features):      # training on the GPU: bn + relu as one launch pair (csrc/sparse_bn.hip)
+            out.features = native_bn.bn_act(out.features, self.norm1, relu=True)
+        else:
+            out.features = self.norm1(out.features)
+            out.features = self.relu(out.features)
         out = self.conv2(out)
-        out.features = self.norm2(out.features)
         if self.downsample is not None:
             identity = self.downsample(x)
+        if native_bn.usable(self.norm2, out.features, identity):   # bn + identity + relu
+            out.features = native_bn.bn_act(out.features, self.norm2, relu=True, residual=identity)
+            return out
+        out.features = self.norm2(out.features)
         out.features = out.features + identity
         out.features = self.relu(out.features)
         return out

@@ -56,7 +56,14 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for name, module in self._modules.items():
+        from . import bn as native_bn
+
+        entries = list(self._modules.items())
+        skip = False
+        for i, (name, module) in enumerate(entries):
+            if skip:            # a ReLU that the BatchNorm in front of it already applied (one fused launch pair)
+                skip = False
+                continue
             sparse_in = isinstance(input, SparseConvTensor)
             if is_spconv_module(module):
                 assert sparse_in, f"{type(module).__name__} needs a SparseConvTensor"
@@ -64,7 +71,13 @@ class SparseSequential(SparseModule):
                 input = module(input)
             elif sparse_in:
                 if input.indices.shape[0] != 0:     # dense modules see the [N, C] feature matrix; empty sets are skipped
-                    input.features = module(input.features)
+                    if native_bn.usable(module, input.features):
+                        # training-mode BatchNorm1d [+ the ReLU that follows] on the HIP kernels (csrc/sparse_bn.hip)
+                        relu = i + 1 < len(entries) and type(entries[i + 1][1]) is nn.ReLU
+                        input.features = native_bn.bn_act(input.features, module, relu=relu)
+                        skip = relu
+                    else:
+                        input.features = module(input.features)
             else:
                 input = module(input)
         return input

@@ -592,6 +592,24 @@ size_t bevamd_radix_sort_segmented_workspace_bytes(const int* counts, int nseg);
 int bevamd_radix_sort_pairs_u32_segmented(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                                           const int* counts, int nseg, int nbits, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * training-mode BatchNorm1d over sparse feature rows (csrc/sparse_bn.hip)
+ * Replaces, on the training path of the sparse blocks, the torch.nn.BatchNorm1d / nn.ReLU / residual-add modules the
+ * reference applies to SparseConvTensor.features (ops/sparse_block.py:88-107; sparse_encoder.py:39: BN1d eps 1e-3,
+ * momentum 0.01): batch statistics in fp32, running statistics updated like torch, every tensor of the unfused pipeline rounded
+ * once.  dtype: 0 fp32 | 1 fp16 | 2 bf16 rows; statistics / parameters / parameter gradients fp32; strides in elements.
+ * ------------------------------------------------------------------------- */
+size_t bevamd_sparse_bn_workspace_bytes(int c);   /* zero it once; every launch leaves its ticket word zero again */
+int bevamd_sparse_bn_stats(const void* x, int dtype, long long n, int c, long long stride, float eps, float momentum, float* mean,
+                           float* invstd, float* running_mean, float* running_var, void* ws, size_t ws_bytes, void* stream);
+int bevamd_sparse_bn_apply(const void* x, int dtype, long long n, int c, long long stride, const float* mean, const float* invstd,
+                           const float* weight, const float* bias, const void* residual, long long res_stride, int relu, void* y,
+                           long long y_stride, void* stream);
+int bevamd_sparse_bn_backward(const void* dy, long long dy_stride, const void* y, long long y_stride, const void* x, long long stride,
+                              int dtype, long long n, int c, int relu, const float* mean, const float* invstd, const float* weight,
+                              float* sum_dz, float* sum_dz_xhat, void* dx, long long dx_stride, void* d_residual,
+                              long long dres_stride, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
