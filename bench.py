@@ -755,12 +755,14 @@ def main():
 
     state = {}
     coors_order = "linear" if args.voxel_order == "key" else None
+    # the voxelizer's mean kernel writes the encoder's 16-bit input rows itself (no pad-and-cast pass in front of the first layer)
+    enc_rows = sp_dtype if sp_dtype != torch.float32 else None
 
     def lidar_branch():
         # voxelize + mean into capacity-sized buffers, voxel count stays on the device (no host sync), then the
         # sparse encoder on its sync-free fused inference path
         vf, vc, _, cnt = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                               cfg["max_voxels"][1], order=args.voxel_order)
+                                               cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
         mid = torch.cuda.Event(enable_timing=True) if state.get("probe") else None
         if mid is not None:
             mid.record()
@@ -818,7 +820,7 @@ def main():
         """coordinates only: voxelize + mean, then the encoder's whole rulebook chain (hash, active sets, neighbour tables, slab
         metadata of every level) — SparseEncoder.prepare_geometry"""
         vf, vc, _, cnt = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                               cfg["max_voxels"][1], order=args.voxel_order)
+                                               cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
         with torch.no_grad():
             lvl = enc.prepare_geometry(vc, B, num_voxels=cnt, coors_order=coors_order)
         return vf, vc, cnt, lvl
@@ -831,7 +833,7 @@ def main():
 
     def voxel_head():
         vf, vc, _, cnt = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                               cfg["max_voxels"][1], order=args.voxel_order)
+                                               cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
         return vf, vc, cnt, None
 
     if overlap_voxel:
@@ -1093,7 +1095,7 @@ def main():
 
             def lidar1():
                 vf, vc, _, cnt = voxelize_batch_device(pts1, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                                       cfg["max_voxels"][1], order=args.voxel_order)
+                                                       cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
                 with torch.no_grad():
                     return enc(vf, vc, 1, num_voxels=cnt, coors_order=coors_order)
 

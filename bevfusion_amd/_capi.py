@@ -64,6 +64,7 @@ _SIGNATURES = {
     "bevamd_voxelize_mean_batch_workspace_bytes": (Z, [P, I]),
     "bevamd_voxelize_mean_batch": (I, [P, P, I, I, P, P, I, I, I, P, P, P, P, P, P, Z, P]),
     "bevamd_voxelize_mean_batch_ex": (I, [P, P, I, I, P, P, I, I, I, I, P, P, P, P, P, P, Z, P]),
+    "bevamd_voxelize_mean_batch_rows16": (I, [P, P, I, I, P, P, I, I, I, I, P, P, P, P, P, P, I, I, P, Z, P]),
     # spconv
     "bevamd_spconv_rulebook_workspace_bytes": (Z, [I, I, P, I]),
     "bevamd_spconv_hash_index_bytes": (Z, [I]),

@@ -138,8 +138,10 @@ __device__ __forceinline__ void slab_sums(long long n, int C, float* sa, float* 
   float p[VEC], q[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) p[j] = q[j] = 0.f;
+  // four rows per trip, their loads issued together (the callback loads all four before it touches the sums): with one load in
+  // flight per lane the reductions ran at 0.8 TB/s (first cut, profiles/r04_train_step_amp_kernel_trace_stats_a.txt)
   if (r_in < rif)
-    for (long long r = lo + r_in; r < hi; r += rif) rowfn(r, cv, p, q);
+    for (long long r = lo + r_in; r < hi; r += 4LL * rif) rowfn(r, (long long)rif, hi, cv, p, q);
   if (r_in < rif) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -167,11 +169,22 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restric
   __shared__ float sa[MAX_C], sb[MAX_C];
   const char* x = (const char*)x_;
   const size_t esz = DT == 0 ? 4 : 2;
-  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
-    float f[R::VEC];
-    R::unpack(*(const V*)(x + ((size_t)r * stride + (size_t)cv * R::VEC) * esz), f);
+  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, long long step, long long hi, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
+    V v[4];
 #pragma unroll
-    for (int j = 0; j < R::VEC; ++j) { p[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+    for (int u = 0; u < 4; ++u) {
+      const long long ru = r + u * step < hi ? r + u * step : r;
+      v[u] = *(const V*)(x + ((size_t)ru * stride + (size_t)cv * R::VEC) * esz);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * step < hi) {
+        float f[R::VEC];
+        R::unpack(v[u], f);
+#pragma unroll
+        for (int j = 0; j < R::VEC; ++j) { p[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+      }
+    }
   });
   finish_totals(sa, sb, C, part, ticket, [&](int c, double s, double ss) {
     const double m = s / (double)n;
@@ -187,6 +200,8 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restric
   });
 }
 
+// Elementwise kernels: lanes-per-row (C / VEC) divides THREADS, so a thread keeps ONE channel group for all its rows — its
+// per-channel constants load once — and walks rows `rows_per_trip` apart, four trips' loads issued together.
 template <int DT>
 __global__ __launch_bounds__(THREADS) void bn_apply_kernel(const void* __restrict__ x_, long long n, int C, long long stride,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -197,24 +212,43 @@ __global__ __launch_bounds__(THREADS) void bn_apply_kernel(const void* __restric
   typedef typename R::V V;
   const size_t esz = DT == 0 ? 4 : 2;
   const int lpr = C / R::VEC;
-  const long long total = n * lpr;
-  for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * THREADS) {
-    const long long r = i / lpr;
-    const int cv = (int)(i - r * lpr), c0 = cv * R::VEC;
-    float f[R::VEC], g[R::VEC];
-    R::unpack(*(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz), f);
-    if (res_) R::unpack(*(const V*)((const char*)res_ + ((size_t)r * res_stride + c0) * esz), g);
+  const int c0 = ((int)threadIdx.x % lpr) * R::VEC;
+  const long long step = (long long)gridDim.x * (THREADS / lpr);                      // rows per trip of the whole grid
+  float sc[R::VEC], sh[R::VEC];
 #pragma unroll
-    for (int j = 0; j < R::VEC; ++j) {
-      const float w = weight ? weight[c0 + j] : 1.f, b = bias ? bias[c0 + j] : 0.f;
-      // torch's transform_input: (x - mean) * invstd * w + b in fp32, rounded to the storage type; the add and the ReLU of the
-      // block are separate 16-bit tensors in the unfused pipeline, so each rounds once
-      float v = R::round((f[j] - mean[c0 + j]) * invstd[c0 + j] * w + b);
-      if (res_) v = R::round(v + g[j]);
-      if (relu) v = v > 0.f ? v : (v != v ? v : 0.f);
-      f[j] = v;
+  for (int j = 0; j < R::VEC; ++j) {
+    const float w = weight ? weight[c0 + j] : 1.f, b = bias ? bias[c0 + j] : 0.f;
+    sc[j] = invstd[c0 + j] * w;
+    sh[j] = b;
+  }
+  float mu[R::VEC];
+#pragma unroll
+  for (int j = 0; j < R::VEC; ++j) mu[j] = mean[c0 + j];
+  for (long long r0 = (long long)blockIdx.x * (THREADS / lpr) + (int)threadIdx.x / lpr; r0 < n; r0 += 4 * step) {
+    V vx[4], vr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long r = r0 + u * step < n ? r0 + u * step : r0;
+      vx[u] = *(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz);
+      if (res_) vr[u] = *(const V*)((const char*)res_ + ((size_t)r * res_stride + c0) * esz);
     }
-    *(V*)((char*)y_ + ((size_t)r * y_stride + c0) * esz) = R::pack(f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r0 + u * step >= n) break;
+      float f[R::VEC], g[R::VEC];
+      R::unpack(vx[u], f);
+      if (res_) R::unpack(vr[u], g);
+#pragma unroll
+      for (int j = 0; j < R::VEC; ++j) {
+        // torch's transform_input: (x - mean) * (invstd * w) + b in fp32, rounded to the storage type; the add and the ReLU of the
+        // block are separate 16-bit tensors in the unfused pipeline, so each rounds once
+        float v = R::round((f[j] - mu[j]) * sc[j] + sh[j]);
+        if (res_) v = R::round(v + g[j]);
+        if (relu) v = v > 0.f ? v : (v != v ? v : 0.f);
+        f[j] = v;
+      }
+      *(V*)((char*)y_ + ((size_t)(r0 + u * step) * y_stride + c0) * esz) = R::pack(f);
+    }
   }
 }
 
@@ -230,17 +264,33 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const void* __re
   typedef typename R::V V;
   __shared__ float sa[MAX_C], sb[MAX_C];
   const size_t esz = DT == 0 ? 4 : 2;
-  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
+  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, long long step, long long hi, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
     const int c0 = cv * R::VEC;
-    float d[R::VEC], f[R::VEC], o[R::VEC];
-    R::unpack(*(const V*)((const char*)dy_ + ((size_t)r * dy_stride + c0) * esz), d);
-    R::unpack(*(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz), f);
-    if (relu) R::unpack(*(const V*)((const char*)y_ + ((size_t)r * y_stride + c0) * esz), o);
+    float mu[R::VEC], is[R::VEC];
 #pragma unroll
-    for (int j = 0; j < R::VEC; ++j) {
-      const float dz = relu && o[j] <= 0.f ? 0.f : d[j];   // torch's threshold_backward: zero where y <= 0
-      p[j] += dz;
-      q[j] = fmaf(dz, (f[j] - mean[c0 + j]) * invstd[c0 + j], q[j]);
+    for (int j = 0; j < R::VEC; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
+    V vd[4], vx[4], vy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long ru = r + u * step < hi ? r + u * step : r;
+      vd[u] = *(const V*)((const char*)dy_ + ((size_t)ru * dy_stride + c0) * esz);
+      vx[u] = *(const V*)((const char*)x_ + ((size_t)ru * stride + c0) * esz);
+      if (relu) vy[u] = *(const V*)((const char*)y_ + ((size_t)ru * y_stride + c0) * esz);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * step < hi) {
+        float d[R::VEC], f[R::VEC], o[R::VEC];
+        R::unpack(vd[u], d);
+        R::unpack(vx[u], f);
+        if (relu) R::unpack(vy[u], o);
+#pragma unroll
+        for (int j = 0; j < R::VEC; ++j) {
+          const float dz = relu && o[j] <= 0.f ? 0.f : d[j];   // torch's threshold_backward: zero where y <= 0
+          p[j] += dz;
+          q[j] = fmaf(dz, (f[j] - mu[j]) * is[j], q[j]);
+        }
+      }
     }
   });
   finish_totals(sa, sb, C, part, ticket, [&](int c, double a, double b) {
@@ -263,25 +313,45 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_kernel(const void* __res
   typedef typename R::V V;
   const size_t esz = DT == 0 ? 4 : 2;
   const int lpr = C / R::VEC;
-  const long long total = n * lpr;
+  const int c0 = ((int)threadIdx.x % lpr) * R::VEC;
+  const long long step = (long long)gridDim.x * (THREADS / lpr);
   const float inv_n = 1.f / (float)n;
-  for (long long i = (long long)blockIdx.x * THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * THREADS) {
-    const long long r = i / lpr;
-    const int cv = (int)(i - r * lpr), c0 = cv * R::VEC;
-    float d[R::VEC], f[R::VEC], o[R::VEC];
-    R::unpack(*(const V*)((const char*)dy_ + ((size_t)r * dy_stride + c0) * esz), d);
-    R::unpack(*(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz), f);
-    if (relu) R::unpack(*(const V*)((const char*)y_ + ((size_t)r * y_stride + c0) * esz), o);
+  float mu[R::VEC], is[R::VEC], k0[R::VEC], k1[R::VEC], k2[R::VEC];
 #pragma unroll
-    for (int j = 0; j < R::VEC; ++j) {
-      const float dz = relu && o[j] <= 0.f ? 0.f : d[j];   // torch's threshold_backward: zero where y <= 0
-      d[j] = dz;
-      const float w = weight ? weight[c0 + j] : 1.f;
-      const float xhat = (f[j] - mean[c0 + j]) * invstd[c0 + j];
-      f[j] = w * invstd[c0 + j] * (dz - sum_dz[c0 + j] * inv_n - xhat * (sum_dz_xhat[c0 + j] * inv_n));
+  for (int j = 0; j < R::VEC; ++j) {
+    mu[j] = mean[c0 + j];
+    is[j] = invstd[c0 + j];
+    k0[j] = (weight ? weight[c0 + j] : 1.f) * is[j];     // w * invstd
+    k1[j] = sum_dz[c0 + j] * inv_n;                       // mean of dz
+    k2[j] = sum_dz_xhat[c0 + j] * inv_n;                  // mean of dz * xhat
+  }
+  for (long long r0 = (long long)blockIdx.x * (THREADS / lpr) + (int)threadIdx.x / lpr; r0 < n; r0 += 4 * step) {
+    V vd[4], vx[4], vy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long r = r0 + u * step < n ? r0 + u * step : r0;
+      vd[u] = *(const V*)((const char*)dy_ + ((size_t)r * dy_stride + c0) * esz);
+      vx[u] = *(const V*)((const char*)x_ + ((size_t)r * stride + c0) * esz);
+      if (relu) vy[u] = *(const V*)((const char*)y_ + ((size_t)r * y_stride + c0) * esz);
     }
-    *(V*)((char*)dx_ + ((size_t)r * dx_stride + c0) * esz) = R::pack(f);
-    if (dres_) *(V*)((char*)dres_ + ((size_t)r * dres_stride + c0) * esz) = R::pack(d);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r0 + u * step >= n) break;
+      float d[R::VEC], f[R::VEC], o[R::VEC];
+      R::unpack(vd[u], d);
+      R::unpack(vx[u], f);
+      if (relu) R::unpack(vy[u], o);
+#pragma unroll
+      for (int j = 0; j < R::VEC; ++j) {
+        const float dz = relu && o[j] <= 0.f ? 0.f : d[j];   // torch's threshold_backward: zero where y <= 0
+        d[j] = dz;
+        const float xhat = (f[j] - mu[j]) * is[j];
+        f[j] = k0[j] * (dz - k1[j] - xhat * k2[j]);
+      }
+      const size_t r = (size_t)(r0 + u * step);
+      *(V*)((char*)dx_ + (r * dx_stride + c0) * esz) = R::pack(f);
+      if (dres_) *(V*)((char*)dres_ + (r * dres_stride + c0) * esz) = R::pack(d);
+    }
   }
 }
 
@@ -297,14 +367,15 @@ static int check_shape(const char* who, long long n, int c, int dtype) {
 
 static unsigned reduce_grid(long long n, int c, int dtype) {
   const int vec = dtype == 0 ? 4 : 8, rif = THREADS / (c / vec);
-  long long g = n / ((long long)rif * 16);     // >= 16 trips per workgroup
+  long long g = n / ((long long)rif * 16);     // >= 16 rows per lane (four trips of four)
   return (unsigned)(g < 1 ? 1 : g > 1024 ? 1024 : g);
 }
 
 static unsigned apply_grid(long long n, int c, int dtype) {
   const int vec = dtype == 0 ? 4 : 8;
-  long long g = (n * (c / vec) + THREADS * 4 - 1) / (THREADS * 4);
-  return (unsigned)(g < 1 ? 1 : g > 8192 ? 8192 : g);
+  const int rpw = THREADS / (c / vec);                               // rows per workgroup and trip
+  long long g = (n + (long long)rpw * 4 - 1) / ((long long)rpw * 4);   // one batch of four rows per lane up to 4096 workgroups
+  return (unsigned)(g < 1 ? 1 : g > 4096 ? 4096 : g);
 }
 
 }  // namespace bn

@@ -394,12 +394,20 @@ __global__ __launch_bounds__(256) void vox_survivors_batch_kernel(VoxBatch vb, c
 // the run.  The run length comes from the wave's ballot of run boundaries (no dependent walk over the keys), the point indices
 // of the run and then the points themselves are fetched as batches of independent, PREDICATED loads (a lane only requests the
 // rows it owns) before they are added in input order: two memory round trips per voxel instead of two per point.
+// fp32 -> fp16 (dtype 1) / bf16 (dtype 2) bits, round to nearest even — torch's .half() / .bfloat16()
+__device__ __forceinline__ uint32_t vox_to_16(float x, int dtype) {
+  if (dtype == 1) return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)x);
+  const uint32_t u = __float_as_uint(x);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
 __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
     VoxBatch vb, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ first_scan, const uint32_t* __restrict__ surv_scan /*null: first-appearance rows*/,
     const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
     int max_points, int max_voxels, float* __restrict__ feats, int* __restrict__ coords4,
-    int* __restrict__ num_points_per_voxel) {
+    int* __restrict__ num_points_per_voxel, uint16_t* __restrict__ rows16, int rows16_dtype, int rows16_pitch) {
   const VoxRow vr = vox_locate(vb);
   const int b = vr.b;
   const uint32_t n = vr.n, j = vr.j;
@@ -455,7 +463,18 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
         }
     }
 #pragma unroll
-    for (int f = 0; f < 5; ++f) feats[row * 5 + f] = __fdiv_rn(acc[f], fc);
+    for (int f = 0; f < 5; ++f) acc[f] = __fdiv_rn(acc[f], fc);
+#pragma unroll
+    for (int f = 0; f < 5; ++f) feats[row * 5 + f] = acc[f];
+    if (rows16 && rows16_pitch == 8) {
+      // the encoder's input rows as it stores them (bevamd_spconv_pad_cast_rows: the fp32 mean rounded to 16 bits, zero padding to
+      // 8 channels) written by the launch that has the means in registers: one 16-byte store instead of a pass over the rows
+      uint32_t h[8];
+#pragma unroll
+      for (int f = 0; f < 8; ++f) h[f] = f < 5 ? vox_to_16(acc[f], rows16_dtype) : 0u;
+      struct alignas(16) Q { uint32_t w[4]; } q = {{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)}};
+      *(Q*)(rows16 + row * 8) = q;
+    }
   } else if (nfeat <= 8) {
     float acc[8];
 #pragma unroll
@@ -589,6 +608,11 @@ size_t bevamd_voxelize_mean_batch_workspace_bytes(const int* num_points, int bat
   return voxelize_batch_ws_bytes(sg);
 }
 
+int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num_points, int batch_size, int num_features,
+                                      const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                                      int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
+                                      int* counts_dev, int* total_dev, void* rows16, int rows16_dtype, int rows16_pitch, void* ws,
+                                      size_t ws_bytes, void* stream_);
 int bevamd_voxelize_mean_batch_ex(const float* const* points, const int* num_points, int batch_size, int num_features,
                                   const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
                                   int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
@@ -607,7 +631,20 @@ int bevamd_voxelize_mean_batch_ex(const float* const* points, const int* num_poi
                                   const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
                                   int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
                                   int* counts_dev, int* total_dev, void* ws, size_t ws_bytes, void* stream_) {
+  return bevamd_voxelize_mean_batch_rows16(points, num_points, batch_size, num_features, voxel_size, coors_range, max_points,
+                                           max_voxels, packed, order, feats, coords4, num_points_per_voxel, counts_dev, total_dev,
+                                           nullptr, 0, 0, ws, ws_bytes, stream_);
+}
+
+int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num_points, int batch_size, int num_features,
+                                      const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                                      int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
+                                      int* counts_dev, int* total_dev, void* rows16, int rows16_dtype, int rows16_pitch, void* ws,
+                                      size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(!rows16 || ((rows16_dtype == 1 || rows16_dtype == 2) && rows16_pitch == 8 && num_features == 5 &&
+                             ((uintptr_t)rows16 & 15) == 0),
+                 "voxelize_mean_batch_rows16: 16-bit rows are written for 5 point features into pitch-8 rows (dtype 1 fp16 | 2 bf16)");
   BEVAMD_REQUIRE(order == 0 || order == 1, "voxelize_mean_batch: order %d (0 = first appearance, 1 = linear cell index)", order);
   BEVAMD_REQUIRE(points && num_points, "voxelize_mean_batch: points / num_points are null (host arrays)");
   BEVAMD_REQUIRE(batch_size >= 1 && batch_size <= VOX_MAX_BATCH, "voxelize_mean_batch: batch_size %d (1..%d supported)",
@@ -676,7 +713,8 @@ int bevamd_voxelize_mean_batch_ex(const float* const* points, const int* num_poi
     if (rc) return rc;
   }
   vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, surv, rowbase, num_features, g, ncells,
-                                                    max_points, max_voxels, feats, coords4, num_points_per_voxel);
+                                                    max_points, max_voxels, feats, coords4, num_points_per_voxel,
+                                                    (uint16_t*)rows16, rows16_dtype, rows16_pitch);
   BEVAMD_LAUNCH_CHECK("vox_mean_batch");
   return BEVAMD_OK;
 }

@@ -92,6 +92,8 @@ class SparseEncoder(nn.Module):
         if num_voxels is not None:            # the module path needs exact row counts on the host
             live = int(num_voxels.reshape(-1)[0])
             voxel_features, coors = voxel_features[:live], coors[:live]
+        if voxel_features.shape[1] != self.in_channels and voxel_features.shape[1] == _fused.ops.padded_channels(self.in_channels):
+            voxel_features = voxel_features[:, : self.in_channels]   # the voxelizer's zero-padded encoder rows on the module path
         if self.fp16_enabled and voxel_features.dtype == torch.float32:
             voxel_features = voxel_features.half()
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, int(batch_size))

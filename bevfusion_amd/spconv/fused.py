@@ -704,9 +704,13 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
     n = voxel_features.shape[0]
     if n == 0:
         raise NotThisCall("empty input")
-    cin = voxel_features.shape[1]
+    cin = enc.in_channels if hasattr(enc, "in_channels") else voxel_features.shape[1]
     pitch = ops.padded_channels(cin)
-    if _PAD_CAST and voxel_features.dtype == torch.float32 and voxel_features.is_contiguous():
+    if voxel_features.dtype == dtype and voxel_features.shape[1] == pitch and voxel_features.is_contiguous() and pitch != cin:
+        feats = voxel_features      # the voxelizer already wrote the padded 16-bit rows (voxelize_batch_device(encoder_rows=...))
+    elif voxel_features.shape[1] != cin:
+        raise RuntimeError(f"run_encoder: voxel_features has {voxel_features.shape[1]} columns, the encoder reads {cin}")
+    elif _PAD_CAST and voxel_features.dtype == torch.float32 and voxel_features.is_contiguous():
         feats = torch.empty((n, pitch), dtype=dtype, device=voxel_features.device)
         with torch.cuda.device(voxel_features.device):
             rc = _capi.load().bevamd_spconv_pad_cast_rows(_capi.ptr(voxel_features), n, cin, pitch, ops._dtype_code(feats),

@@ -293,7 +293,8 @@ _VOXEL_MAX_BATCH = 64
 _ORDERS = {"first": 0, "appearance": 0, None: 0, "key": 1, "linear": 1}
 
 
-def _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, packed, order="first"):
+def _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, packed, order="first",
+                         rows16_dtype=None):
     """All samples in the launches of one (`bevamd_voxelize_mean_batch_ex`): returns (feats [B*cap, F], coords [B*cap, 4],
     sizes [B*cap], counts [B], total [1]); rows packed sample after sample when `packed`, else sample b at row b*cap.
     order: "first" = first-appearance rows (the reference's numbering), "key" = the same rows in ascending linear cell index."""
@@ -317,11 +318,20 @@ def _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_poi
     with torch.cuda.device(dev):
         wsb = lib.bevamd_voxelize_mean_batch_workspace_bytes(nums, B)
         ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=dev)
-        rc = lib.bevamd_voxelize_mean_batch_ex(ptrs, nums, B, F, _capi.floats(voxel_size), _capi.floats(point_cloud_range),
-                                               int(max_num_points), int(max_voxels), 1 if packed else 0, _ORDERS[order],
-                                               _capi.ptr(feats), _capi.ptr(coords), _capi.ptr(sizes), _capi.ptr(counts),
-                                               _capi.ptr(total), _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+        rows16 = None
+        if rows16_dtype is not None:
+            if F != 5 or rows16_dtype not in (torch.float16, torch.bfloat16):
+                raise ValueError("voxelize: 16-bit encoder rows are written for 5 point features, fp16 or bf16")
+            rows16 = torch.empty((B * max_voxels, 8), dtype=rows16_dtype, device=dev)
+        rc = lib.bevamd_voxelize_mean_batch_rows16(ptrs, nums, B, F, _capi.floats(voxel_size), _capi.floats(point_cloud_range),
+                                                   int(max_num_points), int(max_voxels), 1 if packed else 0, _ORDERS[order],
+                                                   _capi.ptr(feats), _capi.ptr(coords), _capi.ptr(sizes), _capi.ptr(counts),
+                                                   _capi.ptr(total), _capi.ptr(rows16),
+                                                   0 if rows16 is None else (1 if rows16_dtype == torch.float16 else 2),
+                                                   8 if rows16 is not None else 0, _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
     _capi.check(rc, "voxelize_mean_batch")
+    if rows16 is not None:
+        return feats, coords, sizes, counts, total, rows16
     return feats, coords, sizes, counts, total
 
 
@@ -400,17 +410,26 @@ def _voxelize_mean_lanes(points_list, voxel_size, point_cloud_range, max_num_poi
 
 
 @torch.no_grad()
-def voxelize_batch_device(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, order="first"):
+def voxelize_batch_device(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels, order="first", encoder_rows=None):
     """`voxelize_batch` that never touches the host: returns (feats [B*max_voxels, F], coords [B*max_voxels, 4],
     sizes [B*max_voxels], total [1] int32 on the device) with the batch packed sample after sample in the first `total`
     rows — what `SparseEncoder(..., num_voxels=total)` consumes on its sync-free path.  order="key": rows in ascending
     linear index over the whole packed batch (pass `coors_order="linear"` to the encoder: level 1 then runs on the
-    staged-rows kernels with sorted-key neighbour search)."""
+    staged-rows kernels with sorted-key neighbour search).  encoder_rows=torch.float16 | torch.bfloat16 (5 point features): the first
+    element of the result is instead the [B*max_voxels, 8] 16-bit zero-padded rows the SparseEncoder's first convolution reads —
+    the fp32 means rounded once, exactly what the encoder's own pad-and-cast pass would produce — written by the mean kernel
+    itself; pass it to the encoder as `voxel_features`."""
     lib = _capi.load()
     if _VOXEL_BATCHED and len(points_list) <= _VOXEL_MAX_BATCH:
+        if encoder_rows is not None:
+            _, oc, osz, _, total, rows16 = _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points,
+                                                                max_voxels, packed=True, order=order, rows16_dtype=encoder_rows)
+            return rows16, oc, osz, total
         of, oc, osz, _, total = _voxelize_mean_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,
                                                      packed=True, order=order)
         return of, oc, osz, total
+    if encoder_rows is not None:
+        raise ValueError("voxelize_batch_device: encoder_rows needs the batched entry (<= 64 samples, BEVAMD_VOXEL_BATCHED=1)")
     if _ORDERS.get(order, -1) != 0:
         raise ValueError("voxelize_batch_device: order='key' needs the batched entry (<= 64 samples, BEVAMD_VOXEL_BATCHED=1)")
     feats, coords, sizes, counts = voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, max_voxels,

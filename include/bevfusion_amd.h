@@ -317,6 +317,16 @@ int bevamd_voxelize_mean_batch_ex(const float* const* points, const int* num_poi
                                   int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
                                   int* counts_dev, int* total_dev, void* ws, size_t ws_bytes, void* stream);
 
+/* The same, additionally writing the voxel means as the 16-bit, zero-padded rows the SparseEncoder's first convolution reads
+ * (rows16 [batch_size * max_voxels, 8]; rows16_dtype 1 fp16 | 2 bf16; the fp32 mean rounded once, as the cast of
+ * functional.py:24 custom_fwd(cast_inputs=torch.half) does) from the launch that holds the means in registers — the separate
+ * pad-and-cast pass over the rows (bevamd_spconv_pad_cast_rows) disappears from the LiDAR branch.  5 point features only. */
+int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num_points, int batch_size, int num_features,
+                                      const float* voxel_size, const float* coors_range, int max_points, int max_voxels,
+                                      int packed, int order, float* feats, int* coords4, int* num_points_per_voxel,
+                                      int* counts_dev, int* total_dev, void* rows16, int rows16_dtype, int rows16_pitch, void* ws,
+                                      size_t ws_bytes, void* stream);
+
 /* Dynamic scatter.  Replace voxel_layer.dynamic_point_to_voxel_forward / _backward
  *   (voxel/src/voxelization.cpp:6-11 -> voxelization.h:108-140 -> scatter_points_cuda.cu:197-330).
  * bevamd_dynamic_scatter_index: coors [num_points, ndim] int32 (ndim 1..4); rows with a negative entry are dropped.

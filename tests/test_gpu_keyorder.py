@@ -360,6 +360,34 @@ def test_encoder_key_ordered_path_is_bit_identical_to_first_appearance_path(dev,
     assert fused.geometry_status(lvl_bad) & 2
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_voxelizer_writes_the_encoder_rows_itself(dev, dtype):
+    """`voxelize_batch_device(encoder_rows=dtype)`: the mean kernel also writes the 16-bit, zero-padded rows the first convolution
+    reads — bit for bit what the encoder's own pad-and-cast pass makes of the fp32 means — and the encoder takes them as they are:
+    same dense output, one launch and one pass over the rows less in the LiDAR branch."""
+    B = 3
+    pts = [torch.from_numpy(synth.lidar_points(seed=60 + b, sweeps=2 if b else 1)).to(dev) for b in range(B)]
+    vs, pr, mp, mv = CFG["voxel_size"], CFG["point_cloud_range"], CFG["max_num_points"], CFG["max_voxels"][1]
+    for order in ("key", "first"):
+        f, c, _, t = voxelize_batch_device(pts, vs, pr, mp, mv, order=order)
+        r16, c2, _, t2 = voxelize_batch_device(pts, vs, pr, mp, mv, order=order, encoder_rows=dtype)
+        n = int(t.item())
+        assert n == int(t2.item()) and torch.equal(c[:n], c2[:n])
+        assert r16.dtype == dtype and tuple(r16.shape) == (B * mv, 8)
+        want = torch.zeros((n, 8), dtype=dtype, device=dev)
+        want[:, :5] = f[:n].to(dtype)
+        assert torch.equal(r16[:n].view(torch.int16), want.view(torch.int16))
+        enc = flagship_encoder(dev, dtype)
+        with torch.no_grad():
+            kw = dict(coors_order="linear") if order == "key" else {}
+            ref = enc(f, c, B, num_voxels=t, **kw)
+            got = enc(r16, c2, B, num_voxels=t2, **kw)
+            assert enc.last_path == "fused", enc.last_path_reason
+        assert torch.equal(got, ref)
+    with pytest.raises(ValueError, match="5 point features"):
+        voxelize_batch_device([p[:, :4].contiguous() for p in pts], vs, pr, mp, mv, encoder_rows=dtype)
+
+
 def test_broken_linear_promise_is_memory_safe_and_the_encoder_falls_back(dev):
     """first-appearance rows (and rows whose coordinates leave the grid) passed off as coors_order="linear".  The
     sorted-key SEARCH runs on the broken index (clamped reads: no fault), the status bit is raised, and the encoder's first

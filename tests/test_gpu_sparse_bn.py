@@ -55,6 +55,7 @@ def test_against_torch_modules(dev, dtype, n, c, relu, with_res):
 
     def close(a, b, scale=1.0):
         a, b = a.float(), b.float()
+        a, b = a.detach(), b.detach()
         return float((a - b).abs().max()) <= tol * scale * (1.0 + float(b.abs().max()))
 
     assert close(yo, yr)
@@ -119,7 +120,7 @@ def test_sparse_encoder_training_step_native_vs_torch_batchnorm(dev):
             enc = make()
             with torch.autocast("cuda", dtype=torch.float16):
                 y = enc(vf, vc, 2)
-            y.float().square().mean().backward()
+            (y.float().square().sum() * 1e-3).backward()      # a loss scale that keeps the fp16 gradients out of the subnormals
             results.append((y.detach().float(), {k: p.grad.clone() for k, p in enc.named_parameters()},
                             {k: b.clone() for k, b in enc.named_buffers()}))
         finally:
@@ -132,4 +133,4 @@ def test_sparse_encoder_training_step_native_vs_torch_batchnorm(dev):
         else:
             assert torch.equal(b0[k], b1[k]), k
     worst = max(float((g0[k] - g1[k]).abs().max()) / (1e-6 + float(g1[k].abs().max())) for k in g1)
-    assert worst <= 0.1, worst
+    assert worst <= 0.05, worst
