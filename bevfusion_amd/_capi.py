@@ -39,6 +39,7 @@ _SIGNATURES = {
     "bevamd_bev_pool_fused_columns_count": (I, [P, I, I, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_fused_columns_build": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
     "bevamd_bev_pool_fused_forward_columns": (I, [P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_fused_backward_columns": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_cell_of_point": (I, [P, P, I, P, P]),
     "bevamd_bev_pool_fused_backward": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_backward_rows": (I, [P, P, P, P, I, I, I, I, I, I, P]),

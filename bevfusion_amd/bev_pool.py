@@ -393,9 +393,24 @@ class BevPoolPlan:
         if ctx.dtype != torch.float32:
             raise RuntimeError("bev_pool fused backward: fp32 context only")
         c = ctx.shape[-1]
-        d_depth = torch.empty_like(depth)
         d_ctx = torch.empty_like(ctx)
         cop = self.cell_of_point()
+        cols = None
+        if _FUSED_MODE == "columns" and self.n > 0 and fh * (c // 4) <= 1024 and c % 4 == 0:
+            cols = self.fused_columns(depth_bins, fh, fw, c, build=not torch.cuda.is_current_stream_capturing())
+        if cols is not None:
+            # column formulation (csrc/bev_pool_fused_cols.hip): the depth gradient comes back with an image column's values
+            # contiguous, [cams, fw, depth_bins, fh], and is handed on as a permuted view of that buffer
+            cams = self.n // (int(depth_bins) * int(fh) * int(fw))
+            d_depth_t = torch.empty((cams, int(fw), int(depth_bins), int(fh)), dtype=torch.float32, device=ctx.device)
+            with torch.cuda.device(ctx.device):
+                rc = lib.bevamd_bev_pool_fused_backward_columns(
+                    _capi.ptr(out_grad), _capi.ptr(depth), _capi.ptr(ctx), _capi.ptr(cols.keep), _capi.ptr(cols.end), _capi.ptr(cop),
+                    _capi.ptr(d_depth_t), _capi.ptr(d_ctx), self.n, c, int(depth_bins), int(fh), int(fw), self.B, self.D, self.H,
+                    self.W, _capi.stream_ptr(ctx.device))
+            _capi.check(rc, "bev_pool_fused_backward_columns")
+            return d_depth_t.permute(0, 2, 3, 1).reshape(depth.shape), d_ctx   # a view unless `depth` was flat (then one copy)
+        d_depth = torch.empty_like(depth)
         with torch.cuda.device(ctx.device):
             rc = lib.bevamd_bev_pool_fused_backward(
                 _capi.ptr(out_grad), _capi.ptr(depth), _capi.ptr(ctx), _capi.ptr(cop), _capi.ptr(d_depth), _capi.ptr(d_ctx),

@@ -331,6 +331,151 @@ __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __r
   if (ok1) store(c1, acc1);
 }
 
+// ---- backward by columns ---------------------------------------------------------------------------------------------------
+//   d_depth[p]      = < g[cell(p), :], ctx[pixel(p), :] >            (0 for points the range mask dropped)
+//   d_ctx[pixel, :] = sum over the depth bins d of the pixel of  depth[p] * g[cell(p), :]
+// The point-wise kernels of bev_pool_fused.hip fetch one 4*C-byte gradient row and one context row from L2 per POINT (882 + 357 us
+// per 4 flagship frames).  A workgroup here owns ONE image column (camera, w): the gradient rows of its runs — one row per (depth
+// bin, run), ~D of them — its fH context rows and its masked depth values sit in LDS, both products are formed from there, and
+// every global byte is read or written once: d_depth leaves as [camera][w][d][h] (contiguous per column; the host hands it on as
+// a permuted view), d_ctx as the column's fH rows.
+constexpr int BWD_RCAP = 128;      // gradient rows resident at a time (more runs than this: several passes over the column)
+constexpr int BWD_THREADS = 256;
+
+__global__ __launch_bounds__(BWD_THREADS) void bev_fused_bwd_cols_kernel(
+    const float* __restrict__ out_grad, const float* __restrict__ depth, const float* __restrict__ ctx,
+    const uint32_t* __restrict__ keep, const uint32_t* __restrict__ endm, const uint32_t* __restrict__ cell_of_point,
+    float* __restrict__ d_depth_t /*[BN][fW][D][fH]*/, float* __restrict__ d_ctx, int BN, int D, int fH, int fW, int C, int B, int Dz,
+    int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lpr = C >> 2;
+  float* s_cx = lds;                                   // [fH][C]
+  float* s_g = s_cx + (size_t)fH * C;                  // [BWD_RCAP][C]
+  float* s_dep = s_g + (size_t)BWD_RCAP * C;           // [D][fH] masked depth
+  uint32_t* s_row = (uint32_t*)(s_dep + (size_t)D * fH);   // [D * fH]: gradient row (cell) index of every run, by local run id
+  int* s_pre = (int*)(s_row + (size_t)D * fH);         // [D + 1] runs before depth bin d
+  uint16_t* s_ridx = (uint16_t*)(s_pre + D + 1);       // [D][fH] local run id of the point, 0xFFFF = dropped
+  const int tid = threadIdx.x;
+  // column: XCD x takes a contiguous eighth of the (camera, w) columns — whole cameras, whose cell gradients it then keeps in its L2
+  const int total = BN * fW, per = (total + 7) >> 3;
+  const int t = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (((int)blockIdx.x >> 3) >= per || t >= total) return;
+  const int bn = t / fW, w = t - bn * fW;
+
+  for (int i = tid; i < fH * lpr; i += BWD_THREADS) {
+    const int h = i / lpr, j = i - h * lpr;
+    ((float4*)s_cx)[i] = ((const float4*)ctx)[(((size_t)bn * fH + h) * fW + w) * lpr + j];
+  }
+  for (int d = tid; d < D; d += BWD_THREADS) s_pre[d + 1] = __popc(endm[((size_t)bn * D + d) * fW + w]);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int d = 0; d < D; ++d) { const int c = s_pre[d + 1]; s_pre[d] = run; run += c; }
+    s_pre[D] = run;
+  }
+  __syncthreads();
+  const int nrun = s_pre[D];
+  const uint32_t ncells = (uint32_t)B * Dz * H * W;
+  for (int d = tid; d < D; d += BWD_THREADS) {
+    const size_t col = ((size_t)bn * D + d) * fW + w;
+    const uint32_t k = keep[col], e = endm[col];
+    int run = s_pre[d];
+    for (int h = 0; h < fH; ++h) {
+      s_ridx[d * fH + h] = (k >> h) & 1u ? (uint16_t)run : (uint16_t)0xFFFFu;
+      if ((e >> h) & 1u) {
+        uint32_t r = cell_of_point[(((size_t)bn * D + d) * fH + h) * fW + w];   // rank = ((x * W + y) * Dz + z) * B + b
+        r = r < ncells ? r : 0u;
+        const uint32_t gb = r % (uint32_t)B; r /= (uint32_t)B;
+        const uint32_t gz = r % (uint32_t)Dz; r /= (uint32_t)Dz;
+        const uint32_t gy = r % (uint32_t)W;
+        const uint32_t gx = r / (uint32_t)W;
+        s_row[run] = ((gb * (uint32_t)Dz + gz) * (uint32_t)H + gx) * (uint32_t)W + gy;   // row of out_grad [B, Dz, H, W, C]
+        ++run;
+      }
+    }
+  }
+  for (int i0 = 0; i0 < D * fH; i0 += 4 * BWD_THREADS) {   // masked depth: four strided loads in flight per lane
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + u * BWD_THREADS + tid;
+      i = i < D * fH ? i : D * fH - 1;
+      v[u] = depth[((size_t)bn * D * fH + i) * fW + w];
+    }
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * BWD_THREADS + tid;
+      if (i < D * fH) s_dep[i] = v[u];
+    }
+  }
+  __syncthreads();
+
+  const int n_hc = fH * lpr;                           // (h, channel group) items of d_ctx
+  float4 acc[4];                                       // items tid, tid + 256, ... (<= 4: fH * C / 4 <= 1024)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* dd = d_depth_t + ((size_t)bn * fW + w) * D * fH;
+  for (int c0 = 0; c0 < nrun || c0 == 0; c0 += BWD_RCAP) {
+    const int nr = nrun - c0 < BWD_RCAP ? nrun - c0 : BWD_RCAP;
+    for (int i = tid; i < nr * lpr; i += BWD_THREADS) {
+      const int r = i / lpr, j = i - r * lpr;
+      ((float4*)s_g)[i] = ((const float4*)out_grad)[(size_t)s_row[c0 + r] * lpr + j];
+    }
+    __syncthreads();
+    // d_depth of the points whose run is resident (dropped points: zero, written in the first pass)
+    for (int p = tid; p < D * fH; p += BWD_THREADS) {
+      const int r = (int)s_ridx[p] - c0;
+      if (s_ridx[p] == 0xFFFFu) {
+        if (c0 == 0) dd[p] = 0.f;
+      } else if (r >= 0 && r < nr) {
+        const int h = p % fH;
+        const float4* g = (const float4*)s_g + (size_t)r * lpr;
+        const float4* c = (const float4*)s_cx + (size_t)h * lpr;
+        float a0 = 0.f, a1 = 0.f;
+        for (int j = 0; j < lpr; ++j) {
+          const float4 gv = g[j], cv = c[j];
+          a0 = fmaf(gv.x, cv.x, a0); a1 = fmaf(gv.y, cv.y, a1); a0 = fmaf(gv.z, cv.z, a0); a1 = fmaf(gv.w, cv.w, a1);
+        }
+        dd[p] = a0 + a1;
+      }
+    }
+    // d_ctx: (h, channel group) items, depth bins in order
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = tid + u * BWD_THREADS;
+      if (it < n_hc) {
+        const int h = it / lpr, j = it - h * lpr;
+        for (int d = 0; d < D; ++d) {
+          const int r = (int)s_ridx[d * fH + h] - c0;
+          if (r >= 0 && r < nr) {
+            const float wgt = s_dep[d * fH + h];
+            const float4 gv = ((const float4*)s_g)[(size_t)r * lpr + j];
+            acc[u].x = fmaf(wgt, gv.x, acc[u].x); acc[u].y = fmaf(wgt, gv.y, acc[u].y);
+            acc[u].z = fmaf(wgt, gv.z, acc[u].z); acc[u].w = fmaf(wgt, gv.w, acc[u].w);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int it = tid + u * BWD_THREADS;
+    if (it < n_hc) {
+      const int h = it / lpr, j = it - h * lpr;
+      ((float4*)d_ctx)[(((size_t)bn * fH + h) * fW + w) * lpr + j] = acc[u];
+    }
+  }
+}
+
+static size_t bwd_cols_lds(int c, int depth_bins, int fh) {
+  size_t b = ((size_t)fh * c + (size_t)BWD_RCAP * c + (size_t)depth_bins * fh) * sizeof(float);   // s_cx, s_g, s_dep
+  b += (size_t)depth_bins * fh * sizeof(uint32_t) + (size_t)(depth_bins + 1) * sizeof(int);         // s_row, s_pre
+  b += (size_t)depth_bins * fh * sizeof(uint16_t);                                                 // s_ridx
+  return (b + 15) / 16 * 16;
+}
+
 static int cols_shape(int c, int depth_bins, int fh, int fw, ColDims& s, size_t& lds_bytes) {
   if (c <= 0 || (c & 3) || (c >> 2) > COL_THREADS || fh <= 0 || fh > 32 || fw <= 0 || (fw % COL_WB) || depth_bins <= 0) return 0;
   s.D = depth_bins; s.fH = fh; s.fW = fw; s.C = c;
@@ -489,6 +634,43 @@ int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, i
   bev_fused_reduce_kernel<<<dim3(cdiv(cdiv(ncells, 2 * rpi), 4)), dim3(256), 0, stream>>>((const float4*)partial, prow_start, ncells, out,
                                                                                      lpr, rpi, b, d, h, w, c);
   BEVAMD_LAUNCH_CHECK("bev_fused_reduce");
+  return BEVAMD_OK;
+}
+
+/* Backward of the fused pooling for fp32 context through the column masks (keep / end of bevamd_bev_pool_fused_columns_count):
+ * out_grad [b, d, h, w, c] -> d_ctx [cams*fh*fw, c] and d_depth_t [cams, fw, depth_bins, fh] — the depth gradient TRANSPOSED per
+ * camera (an image column's values contiguous); the caller views it as [cams, depth_bins, fh, fw].  Same values as
+ * bevamd_bev_pool_fused_backward up to fp32 summation order; no atomics, deterministic.  Shapes: c % 4 == 0, fh <= 32,
+ * fh * c / 4 <= 1024, depth_bins * fh < 65535 runs per column. */
+int bevamd_bev_pool_fused_backward_columns(const float* out_grad, const float* depth, const float* ctx, const uint32_t* keep,
+                                           const uint32_t* endm, const uint32_t* cell_of_point, float* d_depth_t, float* d_ctx,
+                                           int n, int c, int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(n > 0 && c > 0 && (c & 3) == 0 && depth_bins > 0 && fh > 0 && fh <= 32 && fw > 0 && b > 0 && d > 0 && h > 0 && w > 0,
+                 "bev_pool_fused_backward_columns: bad sizes (c %% 4 == 0, fh <= 32)");
+  const long long per_cam = (long long)depth_bins * fh * fw;
+  BEVAMD_REQUIRE(n % per_cam == 0, "bev_pool_fused_backward_columns: n=%d is not a multiple of depth_bins*fh*fw=%lld", n, per_cam);
+  BEVAMD_REQUIRE(fh * (c / 4) <= 4 * BWD_THREADS && depth_bins * fh < 65535, "bev_pool_fused_backward_columns: column too large");
+  BEVAMD_REQUIRE((unsigned long long)b * d * h * w < 0xFFFFFFF0ull, "bev_pool_fused_backward_columns: b*d*h*w too large");
+  BEVAMD_REQUIRE(out_grad && depth && ctx && keep && endm && cell_of_point && d_depth_t && d_ctx, "bev_pool_fused_backward_columns: null buffer");
+  BEVAMD_REQUIRE((((uintptr_t)out_grad | (uintptr_t)ctx | (uintptr_t)d_ctx) & 15) == 0, "bev_pool_fused_backward_columns: 16-byte aligned buffers");
+  const size_t lds = bwd_cols_lds(c, depth_bins, fh);
+  BEVAMD_REQUIRE(lds <= 150 * 1024, "bev_pool_fused_backward_columns: column does not fit LDS (%zu bytes)", lds);
+  if (lds > 65536) {
+    static int raised[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (!raised[dev]) {
+      (void)hipFuncSetAttribute((const void*)&bev_fused_bwd_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+      raised[dev] = 1;
+    }
+  }
+  const int bn = (int)(n / per_cam), total = bn * fw;
+  bev_fused_bwd_cols_kernel<<<dim3(((total + 7) / 8) * 8), dim3(BWD_THREADS), lds, stream>>>(
+      out_grad, depth, ctx, keep, endm, cell_of_point, d_depth_t, d_ctx, bn, depth_bins, fh, fw, c, b, d, h, w);
+  BEVAMD_LAUNCH_CHECK("bev_fused_bwd_cols");
   return BEVAMD_OK;
 }
 

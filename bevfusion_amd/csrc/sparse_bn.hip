@@ -111,9 +111,17 @@ __device__ __forceinline__ void finish_totals(const float* sa, const float* sb, 
     const int c = c0 + (int)threadIdx.x % Cp, s = (int)threadIdx.x / Cp;
     double a = 0.0, b = 0.0;
     if (c < C && s < nshare)
-      for (int g = s; g < G; g += nshare) {
-        a += (double)__hip_atomic_load(part + (size_t)g * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b += (double)__hip_atomic_load(part + (size_t)g * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int g = s; g < G; g += 4 * nshare) {   // four slabs' partials requested together, added in slab order
+        float pa[4], pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int gu = g + u * nshare < G ? g + u * nshare : g;
+          pa[u] = __hip_atomic_load(part + (size_t)gu * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pb[u] = __hip_atomic_load(part + (size_t)gu * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (g + u * nshare < G) { a += (double)pa[u]; b += (double)pb[u]; }
       }
     red[0][threadIdx.x] = a;
     red[1][threadIdx.x] = b;
@@ -367,8 +375,8 @@ static int check_shape(const char* who, long long n, int c, int dtype) {
 
 static unsigned reduce_grid(long long n, int c, int dtype) {
   const int vec = dtype == 0 ? 4 : 8, rif = THREADS / (c / vec);
-  long long g = n / ((long long)rif * 16);     // >= 16 rows per lane (four trips of four)
-  return (unsigned)(g < 1 ? 1 : g > 1024 ? 1024 : g);
+  long long g = n / ((long long)rif * 16);     // >= 16 rows per lane (four trips of four); at most 512 slabs: the last workgroup
+  return (unsigned)(g < 1 ? 1 : g > 512 ? 512 : g);   // adds their partials up alone (a serial tail of G / nshare round trips)
 }
 
 static unsigned apply_grid(long long n, int c, int dtype) {

@@ -174,6 +174,14 @@ int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, i
                                           const uint32_t* prow_start, float* partial, float* out, int n, int nruns, int c,
                                           int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream);
 
+/* Backward of the fused pooling through the column masks (fp32 context): one workgroup per image column (camera, w) keeps the
+ * gradient rows of the column's runs, its fh context rows and its masked depth values in LDS — every global byte moves once
+ * (the point-wise kernels below fetch two 4*c-byte rows per POINT).  d_depth_t is [cams, fw, depth_bins, fh]: the depth gradient
+ * with an image column's values contiguous; view it as [cams, depth_bins, fh, fw] by permuting.  d_ctx [cams*fh*fw, c]. */
+int bevamd_bev_pool_fused_backward_columns(const float* out_grad, const float* depth, const float* ctx, const uint32_t* keep,
+                                           const uint32_t* end, const uint32_t* cell_of_point, float* d_depth_t, float* d_ctx,
+                                           int n, int c, int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream);
+
 /* Backward of the fused op (fp32 context): d_depth [n] = sum_c out_grad[cell(p), c] * ctx[pixel(p), c] (0 for dropped
  * points), d_ctx [cams*fh*fw, c] = sum over the depth bins of a pixel of depth[p] * out_grad[cell(p), :]; both fully
  * written, no atomics.  cell_of_point [n] (rank per point in POINT order) comes from bevamd_bev_pool_cell_of_point. */

@@ -239,3 +239,81 @@ def test_column_path_replays_from_a_graph(dev):
     depth.mul_(0.5)
     graph.replay()
     assert float((out - ref * 0.5).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("B,n_cam,D,fh,fw,c,aug", [(1, 3, 118, 32, 88, 80, True), (2, 2, 40, 16, 44, 64, True), (1, 1, 59, 32, 88, 80, False)])
+def test_column_backward_vs_point_kernels_and_float64(dev, B, n_cam, D, fh, fw, c, aug):
+    """d depth / d context through the column masks (bevamd_bev_pool_fused_backward_columns) against the point-wise kernels of the
+    same plan and against float64 formulas; a pitched / rolled rig with rotated augmentation gives several runs per column."""
+    from bevfusion_amd import bev_pool as bp
+
+    cfg = synth.CL_CONFIG
+    geom = rigged_geometry(B, n_cam, D, fh, fw, seed=21 + n_cam, rot_deg=5.4 if aug else 0.0, flip=aug)
+    dx, bx, nx = synth.gen_dx_bx(cfg["xbound"], cfg["ybound"], cfg["zbound"])
+    origin = (bx - dx / np.float32(2.0)).astype(np.float32)
+    H, W, Dz = (int(v) for v in nx)
+    plan = BevPoolPlan.from_geometry(torch.from_numpy(geom.reshape(-1, 3)).to(dev), B, origin, dx, nx)
+    cams = B * n_cam
+    g = torch.Generator(device=dev).manual_seed(5)
+    depth = torch.softmax(torch.randn((cams, D, fh, fw), generator=g, device=dev), 1)
+    ctx = torch.randn((cams * fh * fw, c), generator=g, device=dev) * 0.5
+    gout = torch.randn((B, Dz, H, W, c), generator=g, device=dev)
+    assert plan.fused_columns(D, fh, fw, c) is not None
+    dd_c, dc_c = plan.launch_fused_backward(gout, depth, ctx, D, fh, fw)
+    assert tuple(dd_c.shape) == tuple(depth.shape) and dd_c.stride(-1) != 1      # the transposed buffer, viewed in place
+    old, bp._FUSED_MODE = bp._FUSED_MODE, "cells"
+    try:
+        dd_p, dc_p = plan.launch_fused_backward(gout, depth, ctx, D, fh, fw)
+    finally:
+        bp._FUSED_MODE = old
+    assert float((dd_c - dd_p).abs().max()) <= 1e-4 * (1 + float(dd_p.abs().max()))
+    assert float((dc_c - dc_p).abs().max()) <= 1e-4 * (1 + float(dc_p.abs().max()))
+    # float64: cell of every point by the reference's arithmetic
+    cell = ((geom.reshape(-1, 3) - origin) / dx).astype(np.int64)
+    ok = ((cell >= 0) & (cell < np.array([H, W, Dz]))).all(1)
+    bidx = np.repeat(np.arange(B), cell.shape[0] // B)
+    gn = gout.cpu().numpy().astype(np.float64)
+    grow = np.zeros((cell.shape[0], c))
+    grow[ok] = gn[bidx[ok], cell[ok, 2], cell[ok, 0], cell[ok, 1]]
+    p = np.arange(cell.shape[0])
+    pix = (p // (D * fh * fw)) * fh * fw + (p % (D * fh * fw)) % (fh * fw)
+    cn = ctx.cpu().numpy().astype(np.float64)
+    want_dd = (grow * cn[pix]).sum(1).reshape(cams, D, fh, fw)
+    want_dc = np.zeros_like(cn)
+    np.add.at(want_dc, pix, depth.cpu().numpy().reshape(-1, 1).astype(np.float64) * grow)
+    assert np.max(np.abs(dd_c.cpu().numpy() - want_dd)) <= 1e-4 * (1 + np.abs(want_dd).max())
+    assert np.max(np.abs(dc_c.cpu().numpy() - want_dc)) <= 1e-4 * (1 + np.abs(want_dc).max())
+    # autograd end to end on a [B, N, D, fH, fW] depth tensor (what the view transform passes)
+    d5 = depth.view(B, n_cam, D, fh, fw).clone().requires_grad_(True)
+    c2 = ctx.clone().requires_grad_(True)
+    plan.fused(d5, c2, D, fh, fw).backward(gout)
+    assert torch.equal(d5.grad.view(cams, D, fh, fw), dd_c.contiguous()) and torch.equal(c2.grad, dc_c)
+
+
+def test_column_backward_with_more_runs_than_fit_at_once(dev):
+    """Every row its own run (random cells): 16 x 8 = 128 ... 59 x 16 = 944 runs per column, several resident passes."""
+    rng = np.random.default_rng(2)
+    for cams, D, fh, fw, c in ((2, 16, 8, 4, 16), (1, 59, 16, 8, 80)):
+        B, Dz, H, W = 1, 1, 9, 11
+        n = cams * D * fh * fw
+        coords = np.stack([rng.integers(-1, H + 1, n), rng.integers(-1, W + 1, n), np.zeros(n, np.int64), np.zeros(n, np.int64)], 1)
+        plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)
+        depth = torch.from_numpy(rng.random((cams, D, fh, fw)).astype(np.float32)).to(dev)
+        ctx = torch.from_numpy(rng.standard_normal((cams * fh * fw, c)).astype(np.float32)).to(dev)
+        gout = torch.from_numpy(rng.standard_normal((B, Dz, H, W, c)).astype(np.float32)).to(dev)
+        cols = plan.fused_columns(D, fh, fw, c, force=True)
+        lib = _capi.load()
+        dd_t = torch.empty((cams, fw, D, fh), device=dev)
+        dc = torch.empty_like(ctx)
+        rc = lib.bevamd_bev_pool_fused_backward_columns(_capi.ptr(gout), _capi.ptr(depth), _capi.ptr(ctx), _capi.ptr(cols.keep),
+                                                        _capi.ptr(cols.end), _capi.ptr(plan.cell_of_point()), _capi.ptr(dd_t),
+                                                        _capi.ptr(dc), n, c, D, fh, fw, B, Dz, H, W, _capi.stream_ptr(dev))
+        _capi.check(rc, "bev_pool_fused_backward_columns")
+        from bevfusion_amd import bev_pool as bp
+        old, bp._FUSED_MODE = bp._FUSED_MODE, "cells"
+        try:
+            dd_p, dc_p = plan.launch_fused_backward(gout, depth, ctx, D, fh, fw)
+        finally:
+            bp._FUSED_MODE = old
+        assert float((dd_t.permute(0, 2, 3, 1) - dd_p).abs().max()) <= 1e-4
+        assert float((dc - dc_p).abs().max()) <= 1e-4 * (1 + float(dc_p.abs().max()))
