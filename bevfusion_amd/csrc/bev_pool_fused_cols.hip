@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __r
 // bin, run), ~D of them — its fH context rows and its masked depth values sit in LDS, both products are formed from there, and
 // every global byte is read or written once: d_depth leaves as [camera][w][d][h] (contiguous per column; the host hands it on as
 // a permuted view), d_ctx as the column's fH rows.
-constexpr int BWD_RCAP = 128;      // gradient rows resident at a time (more runs than this: several passes over the column)
+constexpr int BWD_RCAP = 64;       // gradient rows resident at a time (a column with more runs takes several passes; 64 rows keep two workgroups per CU)
 constexpr int BWD_THREADS = 256;
 
 __global__ __launch_bounds__(BWD_THREADS) void bev_fused_bwd_cols_kernel(
@@ -433,7 +433,18 @@ __global__ __launch_bounds__(BWD_THREADS) void bev_fused_bwd_cols_kernel(
         const float4* g = (const float4*)s_g + (size_t)r * lpr;
         const float4* c = (const float4*)s_cx + (size_t)h * lpr;
         float a0 = 0.f, a1 = 0.f;
-        for (int j = 0; j < lpr; ++j) {
+        int j = 0;
+        for (; j + 4 <= lpr; j += 4) {   // eight LDS reads in flight per trip
+          float4 gv[4], cv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { gv[u] = g[j + u]; cv[u] = c[j + u]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            a0 = fmaf(gv[u].x, cv[u].x, a0); a1 = fmaf(gv[u].y, cv[u].y, a1);
+            a0 = fmaf(gv[u].z, cv[u].z, a0); a1 = fmaf(gv[u].w, cv[u].w, a1);
+          }
+        }
+        for (; j < lpr; ++j) {
           const float4 gv = g[j], cv = c[j];
           a0 = fmaf(gv.x, cv.x, a0); a1 = fmaf(gv.y, cv.y, a1); a0 = fmaf(gv.z, cv.z, a0); a1 = fmaf(gv.w, cv.w, a1);
         }
@@ -446,13 +457,28 @@ __global__ __launch_bounds__(BWD_THREADS) void bev_fused_bwd_cols_kernel(
       const int it = tid + u * BWD_THREADS;
       if (it < n_hc) {
         const int h = it / lpr, j = it - h * lpr;
-        for (int d = 0; d < D; ++d) {
-          const int r = (int)s_ridx[d * fH + h] - c0;
-          if (r >= 0 && r < nr) {
-            const float wgt = s_dep[d * fH + h];
-            const float4 gv = ((const float4*)s_g)[(size_t)r * lpr + j];
-            acc[u].x = fmaf(wgt, gv.x, acc[u].x); acc[u].y = fmaf(wgt, gv.y, acc[u].y);
-            acc[u].z = fmaf(wgt, gv.z, acc[u].z); acc[u].w = fmaf(wgt, gv.w, acc[u].w);
+        // four depth bins per trip, branch-free: a bin whose run is not resident (or dropped, or past the end) reads row 0 with
+        // weight 0 — its loads are issued with the others instead of behind a branch
+        for (int d0 = 0; d0 < D; d0 += 4) {
+          int r[4];
+          float wgt[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int d = d0 + q < D ? d0 + q : D - 1;
+            r[q] = (int)s_ridx[d * fH + h] - c0;
+            wgt[q] = s_dep[d * fH + h];
+          }
+          float4 gv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool ok = d0 + q < D && r[q] >= 0 && r[q] < nr;
+            wgt[q] = ok ? wgt[q] : 0.f;
+            gv[q] = ((const float4*)s_g)[(size_t)(ok ? r[q] : 0) * lpr + j];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[u].x = fmaf(wgt[q], gv[q].x, acc[u].x); acc[u].y = fmaf(wgt[q], gv[q].y, acc[u].y);
+            acc[u].z = fmaf(wgt[q], gv[q].z, acc[u].z); acc[u].w = fmaf(wgt[q], gv[q].w, acc[u].w);
           }
         }
       }

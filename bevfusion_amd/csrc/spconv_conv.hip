@@ -443,8 +443,8 @@ __device__ __forceinline__ f32x4 mfma16(const s16x8& a, const s16x8& b, f32x4 ac
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
-template <int DT, int CIT, int COT, int KPW>
-__global__ __launch_bounds__(256, 2) void spconv_wgrad16_kernel(const typename Elem<DT>::T* __restrict__ feat,
+template <int DT, int CIT, int COT, int KPW, int NW = WG2_NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void spconv_wgrad16_kernel(const typename Elem<DT>::T* __restrict__ feat,
                                                                 const typename Elem<DT>::T* __restrict__ gout,
                                                                 const int* __restrict__ nbr, int nbr_stride, int m, int K,
                                                                 int cin, int cout, int cinp_tot, int coutp_tot,
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad16_kernel(const typename E
   constexpr int NLD = (R * A8 + 63) / 64;            // gathered pieces per lane and offset (R * A8 = 64 | 128)
   static_assert(R * A8 % 64 == 0, "whole wave instructions");
   __shared__ __attribute__((aligned(16))) H fb[2][R * COB];
-  __shared__ __attribute__((aligned(16))) H fa[WG2_NW][R * CIB];
+  __shared__ __attribute__((aligned(16))) H fa[NW][R * CIB];
   const H* featb = (const H*)feat;
   const H* goutb = (const H*)gout;
   const int s = blockIdx.x, ci0 = blockIdx.y * CIB, co0 = blockIdx.z * COB;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad16_kernel(const typename E
   auto load_idx = [&](int r0, int (&ix)[KPW]) {
 #pragma unroll
     for (int kk = 0; kk < KPW; ++kk) {
-      const int k = w + kk * WG2_NW, o = r0 + (lane & 31);
+      const int k = w + kk * NW, o = r0 + (lane & 31);
       ix[kk] = (k < K && o < rend) ? nbr[(size_t)k * nbr_stride + o] : -1;
     }
   };
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad16_kernel(const typename E
   }
 #pragma unroll
   for (int kk = 0; kk < KPW; ++kk) {
-    const int k = w + kk * WG2_NW;
+    const int k = w + kk * NW;
     if (k >= K) continue;
     float* dst = part + ((size_t)s * K + k) * cinp_tot * coutp_tot;
 #pragma unroll
@@ -692,27 +692,45 @@ int bevamd_spconv_conv_forward(const void* features, int dtype, const void* prep
  * (sparse_conv_ext.indice_conv_backward_*'s filter half, spconv_ops.h:363-456).  nbr is the FORWARD table (nbr[k][o] = input
  * row).  MFMA (exact fp32), no atomics, bit-reproducible.  ws: WG_MAX_SLABS * K * cin_pad * cout_pad fp32 slab partials. */
 // geometry of the row-tile-stationary filter gradient for (K, cin, cout): channel blocks, padded widths, most slabs it will use
-struct Wgrad2Plan { int cit, cot, nci, nco, cinp, coutp, kpw, max_slabs; };
-static bool wgrad2_plan(int K, int cin, int cout, Wgrad2Plan& p) {
+struct Wgrad2Plan { int cit, cot, nci, nco, cinp, coutp, kpw, max_slabs, nw; };
+// `wide` (16-bit features, cin >= 32, cout >= 64, K > 8): a workgroup of EIGHT waves owns 64 output channels (COT = 4) and each wave
+// four kernel offsets.  Every (input block, output block) workgroup gathers its 32-channel slice of a neighbour row per offset,
+// so the gathered bytes of a layer are rows x offsets x row bytes x (output blocks): what bounds the kernel (64 -> 64 at 4
+// frames: 2.7 GB of 64-byte gathers from L2 in 640 us).  Twice the output channels per workgroup = half the gathers, twice the
+// MFMAs per gathered tile.
+static bool wgrad2_plan(int K, int cin, int cout, Wgrad2Plan& p, bool wide = false) {
   if (K > 7 * WG2_NW || cin > 128 || cout > 128) return false;
+  wide = wide && cin >= 32 && cout >= 64 && K > 8 && K <= 32;
+  p.nw = wide ? 8 : WG2_NW;
   p.cit = cin <= 16 ? 1 : 2;
-  p.cot = cout <= 16 ? 1 : 2;
+  p.cot = wide ? 4 : cout <= 16 ? 1 : 2;
   p.nci = (cin + p.cit * 16 - 1) / (p.cit * 16);
   p.nco = (cout + p.cot * 16 - 1) / (p.cot * 16);
   p.cinp = p.nci * p.cit * 16;
   p.coutp = p.nco * p.cot * 16;
-  const int need = (K + WG2_NW - 1) / WG2_NW;
-  p.kpw = need <= 1 ? 1 : need <= 2 ? 2 : 7;
-  int sl = WG2_TARGET_WGS / (p.nci * p.nco);
+  const int need = (K + p.nw - 1) / p.nw;
+  p.kpw = wide ? 4 : need <= 1 ? 1 : need <= 2 ? 2 : 7;
+  int sl = (wide ? WG2_TARGET_WGS / 2 : WG2_TARGET_WGS) / (p.nci * p.nco);
   p.max_slabs = sl < 1 ? 1 : sl > WG2_MAX_SLABS ? WG2_MAX_SLABS : sl;
   return true;
+}
+static bool wgrad_wide_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("BEVAMD_SPCONV_WGRAD_WIDE"); on = e ? atoi(e) != 0 : 1; }
+  return on != 0;
 }
 
 size_t bevamd_spconv_wgrad_workspace_bytes(int kernel_volume, int cin, int cout) {
   if (kernel_volume <= 0 || cin <= 0 || cout <= 0 || cin > 128 || cout > 128) return 0;
-  Wgrad2Plan p;
-  if (wgrad2_plan(kernel_volume, cin, cout, p))
-    return align_up((size_t)p.max_slabs * kernel_volume * p.cinp * p.coutp * sizeof(float), 256);
+  Wgrad2Plan p, pw;
+  if (wgrad2_plan(kernel_volume, cin, cout, p)) {
+    size_t b = (size_t)p.max_slabs * kernel_volume * p.cinp * p.coutp * sizeof(float);
+    if (wgrad2_plan(kernel_volume, cin, cout, pw, true)) {   // the 16-bit wide plan may use more slabs: size for either
+      const size_t bw = (size_t)pw.max_slabs * kernel_volume * pw.cinp * pw.coutp * sizeof(float);
+      b = bw > b ? bw : b;
+    }
+    return align_up(b, 256);
+  }
   const int cit = (cin + 15) / 16, cinp = (cit <= 1 ? 1 : cit <= 2 ? 2 : cit <= 4 ? 4 : 8) * 16;
   const int coutp = (cout + 15) / 16 * 16;
   return align_up((size_t)WG_MAX_SLABS * kernel_volume * cinp * coutp * sizeof(float), 256);
@@ -737,7 +755,7 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
     return BEVAMD_ERR_WORKSPACE;
   }
   Wgrad2Plan wp;
-  if (wgrad2_plan(kernel_volume, cin, cout, wp)) {
+  if (wgrad2_plan(kernel_volume, cin, cout, wp, dtype != DT_F32 && wgrad_wide_enabled())) {
     // row-tile-stationary kernel: slabs of whole 32-row tiles, ~768 workgroups over (slab, ci block, co block)
     int nslabs = (num_out + 4 * WG2_R - 1) / (4 * WG2_R);   // at least 4 tiles per slab
     if (nslabs > wp.max_slabs) nslabs = wp.max_slabs;
@@ -745,7 +763,7 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
     int rows_per_slab = ((num_out + nslabs - 1) / nslabs + WG2_R - 1) / WG2_R * WG2_R;
     nslabs = (num_out + rows_per_slab - 1) / rows_per_slab;
     float* part = (float*)ws;
-    dim3 grid(nslabs, wp.nci, wp.nco), block(256);
+    dim3 grid(nslabs, wp.nci, wp.nco), block(wp.nw * 64);
 #define BEVAMD_WG2(DT, T, CIT, COT, KPW) \
   spconv_wgrad2_kernel<DT, CIT, COT, KPW><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
                                                                       kernel_volume, cin, cout, wp.cinp, wp.coutp, rows_per_slab, part)
@@ -771,7 +789,10 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
   } while (0)
 #define BEVAMD_WG16_C(DT, T)                                                                   \
   do {                                                                                        \
-    if (wp.cit == 1 && wp.cot == 1) BEVAMD_WG16_K(DT, T, 1, 1);                               \
+    if (wp.nw == 8)                                                                           \
+      spconv_wgrad16_kernel<DT, 2, 4, 4, 8><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
+                                                                        kernel_volume, cin, cout, wp.cinp, wp.coutp, rows_per_slab, part); \
+    else if (wp.cit == 1 && wp.cot == 1) BEVAMD_WG16_K(DT, T, 1, 1);                          \
     else if (wp.cit == 1) BEVAMD_WG16_K(DT, T, 1, 2);                                         \
     else if (wp.cot == 1) BEVAMD_WG16_K(DT, T, 2, 1);                                         \
     else BEVAMD_WG16_K(DT, T, 2, 2);                                                          \
