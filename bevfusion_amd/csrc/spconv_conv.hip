@@ -808,9 +808,9 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
 #undef BEVAMD_WG2
     BEVAMD_LAUNCH_CHECK("spconv_wgrad2");
     dim3 rgrid2((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048));
-    if (dtype == DT_F32) spconv_wgrad_reduce_kernel<DT_F32><<<rgrid2, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (float*)filter_grad);
-    else if (dtype == DT_F16) spconv_wgrad_reduce_kernel<DT_F16><<<rgrid2, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (_Float16*)filter_grad);
-    else spconv_wgrad_reduce_kernel<DT_BF16><<<rgrid2, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (uint16_t*)filter_grad);
+    if (dtype == DT_F32) spconv_wgrad_reduce_kernel<DT_F32><<<rgrid2, dim3(256), 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (float*)filter_grad);
+    else if (dtype == DT_F16) spconv_wgrad_reduce_kernel<DT_F16><<<rgrid2, dim3(256), 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (_Float16*)filter_grad);
+    else spconv_wgrad_reduce_kernel<DT_BF16><<<rgrid2, dim3(256), 0, stream>>>(part, nslabs, kernel_volume, cin, cout, wp.cinp, wp.coutp, (uint16_t*)filter_grad);
     BEVAMD_LAUNCH_CHECK("spconv_wgrad_reduce");
     return BEVAMD_OK;
   }
