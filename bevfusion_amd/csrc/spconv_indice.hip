@@ -200,23 +200,24 @@ __global__ __launch_bounds__(256) void sp_nbr_rows_kernel(const int* __restrict_
   xcd_chunk(m, lo, hi);
   for (int o = lo + threadIdx.x; o < hi; o += 256) {
     const int4 c = ((const int4*)out_indices)[o];
-    int k = 0;
-    for (int kx = 0; kx < g.ksize[0]; ++kx) {
-      int ix_ = 0;
-      const bool okx = axis_out_to_in(g, 0, c.y, kx, ix_);
-      for (int ky = 0; ky < g.ksize[1]; ++ky) {
-        int iy = 0;
-        const bool oky = okx && axis_out_to_in(g, 1, c.z, ky, iy);
-        for (int kz = 0; kz < g.ksize[2]; ++kz, ++k) {
-          int iz = 0, r = -1;
-          if (oky && axis_out_to_in(g, 2, c.w, kz, iz)) {
-            const uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
-            r = index_lookup<KIND>(ix, (uint32_t)c.x, key);
-          }
-          nbr[(size_t)k * nbr_stride + o] = r;
+    // all lookups of the row first, into registers (their loads overlap), then the stores: with a store behind every lookup the
+    // compiler keeps them in order — 27 dependent round trips per row (measured: 116 us for 788 k rows, first cut)
+    int v[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      v[k] = -1;
+      if (k < g.K) {
+        const int kz = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kx = k / (g.ksize[2] * g.ksize[1]);
+        int ix_ = 0, iy = 0, iz = 0;
+        if (axis_out_to_in(g, 0, c.y, kx, ix_) && axis_out_to_in(g, 1, c.z, ky, iy) && axis_out_to_in(g, 2, c.w, kz, iz)) {
+          const uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
+          v[k] = index_lookup<KIND>(ix, (uint32_t)c.x, key);
         }
       }
     }
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+      if (k < g.K) nbr[(size_t)k * nbr_stride + o] = v[k];
   }
 }
 
@@ -728,7 +729,7 @@ static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const 
     BEVAMD_LAUNCH_CHECK("sp_nbr_subm_sym");
     return BEVAMD_OK;
   }
-  if (kind == INDEX_RANK && !g.transpose) {   // neighbouring rows share index words: one thread per row, all offsets
+  if (kind == INDEX_RANK && !g.transpose && g.K <= 27) {   // neighbouring rows share index words: one thread per row, all offsets
     sp_nbr_rows_kernel<INDEX_RANK><<<dim3(stride_grid(m_cap)), dim3(256), 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
     BEVAMD_LAUNCH_CHECK("sp_nbr_rows");
     return BEVAMD_OK;
@@ -842,7 +843,7 @@ __device__ __forceinline__ int sorted_lower_bound(const uint32_t* __restrict__ k
 // x-plane's segment of the directory) and then walks the rows up to the window's last key, four keys per round trip, turning
 // each into its (ky, kz) tap — 3 searches per row instead of one lookup per tap.  Output rows must be in ascending linear
 // index too (what makes a plane's inputs a contiguous range).  SUBM: the centre tap is the row itself.
-template <int BM, bool SUBM>
+template <int BM, bool SUBM, bool COMPACT = false>
 __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __restrict__ out_indices, int m_cap,
                                                                  const int* __restrict__ m_dev, ConvGeom g,
                                                                  const uint32_t* __restrict__ in_keys,
@@ -902,7 +903,8 @@ __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __re
     }
   }
   if (SUBM) v[13] = live ? row : -1;
-  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+  if constexpr (COMPACT) slab::slab_emit_compact<BM>(v, blk, t, hdr, slots, status);
+  else slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
 }
 
 }  // namespace bevamd
@@ -1204,11 +1206,27 @@ int bevamd_spconv_sorted_index_build(const int* indices, int n_cap, const int* n
  * else the strided convolution whose active outputs are out_indices [m_cap, 4] on out_shape (rows in ascending linear index,
  * as bevamd_spconv_downsample emits them).  Replaces the neighbour table (108 B per row written and read back) for layers that
  * run on the slab kernels. */
+int bevamd_spconv_slab_build_from_sorted_ex(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
+                                            const int* in_shape, const int* out_shape, const int* stride, const int* padding,
+                                            int subm, const void* in_index, int in_n_cap, int block_rows, int compact, void* hdr,
+                                            void* slots, int* status, void* stream_);
 int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
                                          const int* in_shape, const int* out_shape, const int* stride, const int* padding,
                                          int subm, const void* in_index, int in_n_cap, int block_rows, void* hdr, void* slots,
                                          int* status, void* stream_) {
+  return bevamd_spconv_slab_build_from_sorted_ex(out_indices, m_cap, m_dev, batch_size, in_shape, out_shape, stride, padding, subm,
+                                                 in_index, in_n_cap, block_rows, 0, hdr, slots, status, stream_);
+}
+
+/* The same with a choice of slot format: compact = 0 the [27][block_rows] 16-bit slot table (54 bytes per row), compact = 1 the
+ * mask + start + list format of the narrow-row kernels (slots sized by bevamd_spconv_slab_slot_bytes_ex(m_cap, block_rows, 1):
+ * 60 bytes per row reserved, 6 + 2 * pairs used; block_rows 128 | 256). */
+int bevamd_spconv_slab_build_from_sorted_ex(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
+                                            const int* in_shape, const int* out_shape, const int* stride, const int* padding,
+                                            int subm, const void* in_index, int in_n_cap, int block_rows, int compact, void* hdr,
+                                            void* slots, int* status, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(!compact || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_sorted: compact slots come in 128- or 256-row blocks");
   ConvGeom g;
   const int k3[3] = {3, 3, 3};
   int rc = make_geom(batch_size, in_shape, subm ? in_shape : out_shape, k3, stride, padding, nullptr, subm, g);
@@ -1220,11 +1238,14 @@ int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, cons
   const uint32_t* keys = (const uint32_t*)in_index;
   const int* xstart = (const int*)((const char*)in_index + align_up((size_t)(in_n_cap > 0 ? in_n_cap : 1) * 4, 256));
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;
-#define BEVAMD_GO(BM, SUBM) \
-  sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, in_n_cap, (int2*)hdr, (uint16_t*)slots, status)
-  if (block_rows == 64) { if (subm) BEVAMD_GO(64, true); else BEVAMD_GO(64, false); }
-  else if (block_rows == 128) { if (subm) BEVAMD_GO(128, true); else BEVAMD_GO(128, false); }
-  else { if (subm) BEVAMD_GO(256, true); else BEVAMD_GO(256, false); }
+#define BEVAMD_GO(BM, SUBM, COMPACT) \
+  sp_slab_from_sorted_kernel<BM, SUBM, COMPACT><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, in_n_cap, (int2*)hdr, (uint16_t*)slots, status)
+  if (compact) {
+    if (block_rows == 128) { if (subm) BEVAMD_GO(128, true, true); else BEVAMD_GO(128, false, true); }
+    else { if (subm) BEVAMD_GO(256, true, true); else BEVAMD_GO(256, false, true); }
+  } else if (block_rows == 64) { if (subm) BEVAMD_GO(64, true, false); else BEVAMD_GO(64, false, false); }
+  else if (block_rows == 128) { if (subm) BEVAMD_GO(128, true, false); else BEVAMD_GO(128, false, false); }
+  else { if (subm) BEVAMD_GO(256, true, false); else BEVAMD_GO(256, false, false); }
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("sp_slab_from_sorted");
   return BEVAMD_OK;
