@@ -10,6 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVAMD_LIB") or os.path.join(_HERE, "lib", "libbevfusion_amd.so")   # BEVAMD_LIB: tools/exp_build.sh A/B builds
+EXT_LIB_PATH = os.path.join(_HERE, "lib", "libbevfusion_amd_ext.so")
 
 _lib = None
 
@@ -76,12 +77,6 @@ _SIGNATURES = {
     "bevamd_spconv_max_outputs": (I, [I, P, P, I]),
     "bevamd_spconv_build_rulebook": (I, [P, I, I, P, P, P, P, P, P, I, I, P, I, P, I, P, P, P, Z, P]),
     "bevamd_spconv_max_outputs_ex": (I, [I, P, P, P, I, I]),
-    "bevamd_dynamic_scatter_workspace_bytes": (Z, [I]),
-    "bevamd_dynamic_scatter_index": (I, [P, I, I, P, P, P, P, P, P, P, P, Z, P]),
-    "bevamd_dynamic_scatter_reduce": (I, [P, I, P, P, I, I, P, P]),
-    "bevamd_dynamic_scatter_backward": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
-    "bevamd_spconv_maxpool_forward": (I, [P, I, I, P, I, I, I, I, P, I, P]),
-    "bevamd_spconv_maxpool_backward": (I, [P, P, P, I, P, I, I, I, I, P, P]),
     "bevamd_spconv_dense_bev": (I, [P, I, I, I, I, P, I, I, P, P, P]),
     "bevamd_spconv_pairs_workspace_bytes": (Z, [I, I]),
     "bevamd_spconv_pairs_from_nbr": (I, [P, I, I, I, P, I, P, P, Z, P]),
@@ -129,6 +124,17 @@ _SIGNATURES = {
 }
 
 
+# libbevfusion_amd_ext.so (include/bevfusion_amd_ext.h): exports of the reference's pybind modules outside the hot path
+_EXT_SIGNATURES = {
+    "bevamd_dynamic_scatter_workspace_bytes": (Z, [I]),
+    "bevamd_dynamic_scatter_index": (I, [P, I, I, P, P, P, P, P, P, P, P, Z, P]),
+    "bevamd_dynamic_scatter_reduce": (I, [P, I, P, P, I, I, P, P]),
+    "bevamd_dynamic_scatter_backward": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
+    "bevamd_spconv_maxpool_forward": (I, [P, I, I, P, I, I, I, I, P, I, P]),
+    "bevamd_spconv_maxpool_backward": (I, [P, P, P, I, P, I, I, I, I, P, P]),
+}
+
+
 class NativeLibraryMissing(RuntimeError):
     pass
 
@@ -148,20 +154,47 @@ def load():
     # loading ours first would put two HIP runtimes in the process ("no ROCm-capable device").
     import torch  # noqa: F401
 
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
+    lib = _bind(LIB_PATH, _SIGNATURES, ctypes.RTLD_GLOBAL)   # global: the optional ext library resolves its shared primitives here
+    _lib = _Library(lib)
+    return _lib
+
+
+def _bind(path, signatures, mode=ctypes.DEFAULT_MODE):
+    lib = ctypes.CDLL(path, mode=mode)
+    for name, (res, args) in signatures.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:  # pragma: no cover
-            raise NativeLibraryMissing(f"symbol {name} missing from {LIB_PATH}: rebuild the library") from e
+            raise NativeLibraryMissing(f"symbol {name} missing from {path}: rebuild the library") from e
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+class _Library:
+    """The hot-path library, plus — on first use of one of its symbols — the optional ext library (sparse max pooling, dynamic
+    scatter: OUT of SURVEY.md §8's path, built into libbevfusion_amd_ext.so).  Callers see one namespace."""
+
+    def __init__(self, main):
+        self._main, self._ext = main, None
+
+    def __getattr__(self, name):
+        if name in _EXT_SIGNATURES:
+            if self._ext is None:
+                if not os.path.exists(EXT_LIB_PATH):
+                    raise NativeLibraryMissing(f"{EXT_LIB_PATH} not found: {name} lives in the optional ext library "
+                                               "(`python -m bevfusion_amd.build` builds both)")
+                self._ext = _bind(EXT_LIB_PATH, _EXT_SIGNATURES)
+            return getattr(self._ext, name)
+        return getattr(self._main, name)
 
 
 def exported_names():
     return list(_SIGNATURES)
+
+
+def ext_exported_names():
+    return list(_EXT_SIGNATURES)
 
 
 def last_error():

@@ -34,8 +34,20 @@ CFLAGS = [
 ]
 
 
+EXT_CSRC = os.path.join(CSRC, "ext")
+EXT_LIB = os.path.join(LIBDIR, "libbevfusion_amd_ext.so")
+
+
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _ext_sources():
+    """csrc/ext/: exports of the reference's pybind modules OUTSIDE the hot path (sparse max pooling, dynamic scatter), built into
+    their own library so that libbevfusion_amd.so carries only what the path runs."""
+    if not os.path.isdir(EXT_CSRC):
+        return []
+    return sorted(os.path.join(EXT_CSRC, f) for f in os.listdir(EXT_CSRC) if f.endswith(".hip"))
 
 
 def _headers():
@@ -94,16 +106,32 @@ def build(force=False, verbose=False, profiling=None):
     srcs = _sources()
     if not srcs:
         raise RuntimeError("no .hip sources found in " + CSRC)
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    ext_srcs = _ext_sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs) + len(ext_srcs))) as ex:
         results = list(ex.map(lambda s: _compile_one(s, force, verbose, extra), srcs))
+        ext_results = list(ex.map(lambda s: _compile_one(s, force, verbose, list(extra) + [f"-I{CSRC}"]), ext_srcs))
     objs = [o for o, _ in results]
-    if any(changed for _, changed in results) or not os.path.exists(LIB) or force:
+    manifest = os.path.join(OBJDIR, ".linked")           # the object list of the last link: a unit that moved or vanished relinks
+    stale = not os.path.exists(manifest) or open(manifest).read().split() != [os.path.basename(o) for o in objs]
+    if any(changed for _, changed in results) or not os.path.exists(LIB) or force or stale:
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(manifest, "w") as fh:
+            fh.write("\n".join(os.path.basename(o) for o in objs))
+    ext_objs = [o for o, _ in ext_results]
+    if ext_objs and (any(changed for _, changed in ext_results) or not os.path.exists(EXT_LIB) or force):
+        # the optional library resolves the shared primitives (scan, sort, error string) from the main one, found next to it
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", EXT_LIB] + ext_objs + [f"-L{LIBDIR}", "-lbevfusion_amd",
+                                                                                            "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link of the ext library failed:\n{r.stdout}\n{r.stderr}")
     return LIB
 
 

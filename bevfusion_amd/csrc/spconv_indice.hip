@@ -187,37 +187,50 @@ __global__ __launch_bounds__(256) void sp_nbr_kernel(const int* __restrict__ out
   }
 }
 
-// The same table with ONE thread per output row walking all K offsets: the row's coordinates are read once (not K times) and the
-// index words its K cells live in are shared with the neighbouring rows of the workgroup (rank index: 8 bytes per 32 cells).  The
-// table column nbr[k][.] is written coalesced across the rows; every entry is written, so nothing has to be cleared first.
-template <int KIND>
+// The same table with ONE thread per output row walking all K offsets of an undilated, untransposed KX x KY x KZ convolution: the
+// row's coordinates are read once (not K times), the index words its K cells live in are shared with the neighbouring rows of
+// the workgroup (rank index: 8 bytes per 32 cells), every lookup is issued unconditionally (an input cell outside the grid looks
+// the row's own first cell up and discards the answer) so that the K loads overlap, and the table column nbr[k][.] is written
+// coalesced across the rows.  Every entry is written: nothing has to be cleared first.
+template <int KX, int KY, int KZ>
 __global__ __launch_bounds__(256) void sp_nbr_rows_kernel(const int* __restrict__ out_indices, int m_cap,
-                                                          const int* __restrict__ m_dev, ConvGeom g, IndexRef ix,
+                                                          const int* __restrict__ m_dev, ConvGeom g, const uint2* __restrict__ words,
                                                           int* __restrict__ nbr, int nbr_stride) {
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   int lo, hi;
   xcd_chunk(m, lo, hi);
+  const int X = g.in_shape[0], Y = g.in_shape[1], Z = g.in_shape[2];
   for (int o = lo + threadIdx.x; o < hi; o += 256) {
     const int4 c = ((const int4*)out_indices)[o];
-    // all lookups of the row first, into registers (their loads overlap), then the stores: with a store behind every lookup the
-    // compiler keeps them in order — 27 dependent round trips per row (measured: 116 us for 788 k rows, first cut)
-    int v[27];
+    const int x0 = c.y * g.stride[0] - g.pad[0], y0 = c.z * g.stride[1] - g.pad[1], z0 = c.w * g.stride[2] - g.pad[2];
+    const uint32_t base = (uint32_t)c.x * (uint32_t)X;
+    constexpr int K = KX * KY * KZ;
+    uint32_t key[K];
+    unsigned okmask = 0;
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      v[k] = -1;
-      if (k < g.K) {
-        const int kz = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kx = k / (g.ksize[2] * g.ksize[1]);
-        int ix_ = 0, iy = 0, iz = 0;
-        if (axis_out_to_in(g, 0, c.y, kx, ix_) && axis_out_to_in(g, 1, c.z, ky, iy) && axis_out_to_in(g, 2, c.w, kz, iz)) {
-          const uint32_t key = (uint32_t)((((long long)c.x * g.in_shape[0] + ix_) * g.in_shape[1] + iy) * g.in_shape[2] + iz);
-          v[k] = index_lookup<KIND>(ix, (uint32_t)c.x, key);
+    for (int kx = 0; kx < KX; ++kx)
+#pragma unroll
+      for (int ky = 0; ky < KY; ++ky)
+#pragma unroll
+        for (int kz = 0; kz < KZ; ++kz) {
+          const int x = x0 + kx, y = y0 + ky, z = z0 + kz, k = (kx * KY + ky) * KZ + kz;
+          const bool ok = x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z;
+          key[k] = ok ? ((base + (uint32_t)x) * (uint32_t)Y + (uint32_t)y) * (uint32_t)Z + (uint32_t)z : base * (uint32_t)Y * (uint32_t)Z;
+          okmask |= ok ? 1u << k : 0u;
         }
-      }
-    }
+    uint2 wd[K];
 #pragma unroll
-    for (int k = 0; k < 27; ++k)
-      if (k < g.K) nbr[(size_t)k * nbr_stride + o] = v[k];
+    for (int k = 0; k < K; ++k) wd[k] = words[key[k] >> 5];
+    // (opaque uses: the K loads are all in flight before the first one is waited for; hipcc otherwise pairs each with its use)
+#pragma unroll
+    for (int k = 0; k < K; ++k) asm volatile("" : "+v"(wd[k].x), "+v"(wd[k].y));
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t b = 1u << (key[k] & 31);
+      const int r = (wd[k].x & b) ? (int)(wd[k].y + __popc(wd[k].x & (b - 1u))) : -1;
+      nbr[(size_t)k * nbr_stride + o] = (okmask >> k) & 1u ? r : -1;
+    }
   }
 }
 
@@ -729,10 +742,16 @@ static int neighbors(const int* out_indices, int m_cap, const int* m_dev, const 
     BEVAMD_LAUNCH_CHECK("sp_nbr_subm_sym");
     return BEVAMD_OK;
   }
-  if (kind == INDEX_RANK && !g.transpose && g.K <= 27) {   // neighbouring rows share index words: one thread per row, all offsets
-    sp_nbr_rows_kernel<INDEX_RANK><<<dim3(stride_grid(m_cap)), dim3(256), 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);
-    BEVAMD_LAUNCH_CHECK("sp_nbr_rows");
-    return BEVAMD_OK;
+  if (kind == INDEX_RANK && !g.transpose && undilated) {   // neighbouring rows share index words: one thread per row, all offsets
+    const bool k333 = g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3;
+    const bool k113 = g.ksize[0] == 1 && g.ksize[1] == 1 && g.ksize[2] == 3;
+    if (k333 || k113) {
+      const dim3 grid(stride_grid(m_cap)), block(256);
+      if (k333) sp_nbr_rows_kernel<3, 3, 3><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix.words, nbr, nbr_stride);
+      else sp_nbr_rows_kernel<1, 1, 3><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix.words, nbr, nbr_stride);
+      BEVAMD_LAUNCH_CHECK("sp_nbr_rows");
+      return BEVAMD_OK;
+    }
   }
   dim3 grid(stride_grid(m_cap), g.K), block(256);
   if (kind == INDEX_HASH) sp_nbr_kernel<INDEX_HASH><<<grid, block, 0, stream>>>(out_indices, m_cap, m_dev, g, ix, nbr, nbr_stride);

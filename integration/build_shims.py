@@ -65,7 +65,7 @@ def build_one(name, force=False, verbose=False):
     for d in inc:
         cmd += ["-I", d]
     cmd += [src, "-o", out, f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ltorch_python",
-            f"-L{os.path.dirname(lib)}", "-lbevfusion_amd",
+            f"-L{os.path.dirname(lib)}", "-lbevfusion_amd", "-lbevfusion_amd_ext",   # ext: sparse max pooling / dynamic scatter exports
             f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN/../../../bevfusion_amd/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)

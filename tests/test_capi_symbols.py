@@ -11,27 +11,39 @@ from bevfusion_amd import _capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    names = set()
-    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
-        txt = open(h).read()
-        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-        names |= set(re.findall(r"\b(bevamd_\w+)\s*\(", txt))
-    return names
+def _declared(header="bevfusion_amd.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(bevamd_\w+)\s*\(", txt))
 
 
 def test_header_declares_something():
     assert len(_declared()) >= 10
+    assert sorted(os.path.basename(h) for h in glob.glob(os.path.join(ROOT, "include", "*.h"))) == ["bevfusion_amd.h", "bevfusion_amd_ext.h"]
 
 
 def test_library_exports_every_declared_symbol():
-    lib = ctypes.CDLL(_capi.LIB_PATH)
+    lib = ctypes.CDLL(_capi.LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     missing = [n for n in sorted(_declared()) if not hasattr(lib, n)]
-    assert not missing, f"declared in include/ but not exported: {missing}"
+    assert not missing, f"declared in include/bevfusion_amd.h but not exported: {missing}"
+    ext = ctypes.CDLL(_capi.EXT_LIB_PATH)
+    missing = [n for n in sorted(_declared("bevfusion_amd_ext.h")) if not hasattr(ext, n)]
+    assert not missing, f"declared in include/bevfusion_amd_ext.h but not exported: {missing}"
+
+
+def test_hot_library_carries_only_the_hot_path():
+    """The exports of the reference's pybind modules OUTSIDE SURVEY.md §8's path (sparse max pooling, dynamic scatter) live in the
+    optional ext library: the hot library does not define them, the one namespace `_capi.load()` hands out still resolves them."""
+    out = os.popen(f"nm -D --defined-only {_capi.LIB_PATH}").read()
+    assert "bevamd_bev_pool_forward_cells" in out
+    assert not [n for n in _declared("bevfusion_amd_ext.h") if f" {n}\n" in out]
+    lib = _capi.load()
+    assert lib.bevamd_dynamic_scatter_workspace_bytes(1000) > 0 and lib.bevamd_scan_workspace_bytes(1000) > 0
 
 
 def test_binding_table_matches_header():
     assert set(_capi.exported_names()) == _declared()
+    assert set(_capi.ext_exported_names()) == _declared("bevfusion_amd_ext.h")
     _capi.load()  # resolves every symbol with its argtypes
 
 
