@@ -103,9 +103,6 @@ _SIGNATURES = {
     "bevamd_spconv_sorted_index_bytes": (Z, [I, I, P]),
     "bevamd_spconv_sorted_index_build": (I, [P, I, P, I, P, P, Z, P, P]),
     "bevamd_spconv_slab_build_from_sorted": (I, [P, I, P, I, P, P, P, P, I, P, I, I, P, P, P, P]),
-    "bevamd_spconv_slab_build_from_sorted_ex": (I, [P, I, P, I, P, P, P, P, I, P, I, I, I, P, P, P, P]),
-    "bevamd_spconv_slab_slot_bytes_ex": (Z, [I, I, I]),
-    "bevamd_spconv_slab_variant_compact": (I, [I, I]),
     "bevamd_spconv_conv_forward_slab": (I, [P, I, I, I, P, P, P, I, I, P, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_wgrad_workspace_bytes": (Z, [I, I, I]),
     "bevamd_spconv_conv_wgrad": (I, [P, P, I, P, I, I, I, I, I, P, P, Z, P]),

@@ -862,7 +862,7 @@ __device__ __forceinline__ int sorted_lower_bound(const uint32_t* __restrict__ k
 // x-plane's segment of the directory) and then walks the rows up to the window's last key, four keys per round trip, turning
 // each into its (ky, kz) tap — 3 searches per row instead of one lookup per tap.  Output rows must be in ascending linear
 // index too (what makes a plane's inputs a contiguous range).  SUBM: the centre tap is the row itself.
-template <int BM, bool SUBM, bool COMPACT = false>
+template <int BM, bool SUBM>
 __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __restrict__ out_indices, int m_cap,
                                                                  const int* __restrict__ m_dev, ConvGeom g,
                                                                  const uint32_t* __restrict__ in_keys,
@@ -922,8 +922,7 @@ __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __re
     }
   }
   if (SUBM) v[13] = live ? row : -1;
-  if constexpr (COMPACT) slab::slab_emit_compact<BM>(v, blk, t, hdr, slots, status);
-  else slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
 }
 
 }  // namespace bevamd
@@ -1225,27 +1224,11 @@ int bevamd_spconv_sorted_index_build(const int* indices, int n_cap, const int* n
  * else the strided convolution whose active outputs are out_indices [m_cap, 4] on out_shape (rows in ascending linear index,
  * as bevamd_spconv_downsample emits them).  Replaces the neighbour table (108 B per row written and read back) for layers that
  * run on the slab kernels. */
-int bevamd_spconv_slab_build_from_sorted_ex(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
-                                            const int* in_shape, const int* out_shape, const int* stride, const int* padding,
-                                            int subm, const void* in_index, int in_n_cap, int block_rows, int compact, void* hdr,
-                                            void* slots, int* status, void* stream_);
 int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
                                          const int* in_shape, const int* out_shape, const int* stride, const int* padding,
                                          int subm, const void* in_index, int in_n_cap, int block_rows, void* hdr, void* slots,
                                          int* status, void* stream_) {
-  return bevamd_spconv_slab_build_from_sorted_ex(out_indices, m_cap, m_dev, batch_size, in_shape, out_shape, stride, padding, subm,
-                                                 in_index, in_n_cap, block_rows, 0, hdr, slots, status, stream_);
-}
-
-/* The same with a choice of slot format: compact = 0 the [27][block_rows] 16-bit slot table (54 bytes per row), compact = 1 the
- * mask + start + list format of the narrow-row kernels (slots sized by bevamd_spconv_slab_slot_bytes_ex(m_cap, block_rows, 1):
- * 60 bytes per row reserved, 6 + 2 * pairs used; block_rows 128 | 256). */
-int bevamd_spconv_slab_build_from_sorted_ex(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
-                                            const int* in_shape, const int* out_shape, const int* stride, const int* padding,
-                                            int subm, const void* in_index, int in_n_cap, int block_rows, int compact, void* hdr,
-                                            void* slots, int* status, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  BEVAMD_REQUIRE(!compact || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_sorted: compact slots come in 128- or 256-row blocks");
   ConvGeom g;
   const int k3[3] = {3, 3, 3};
   int rc = make_geom(batch_size, in_shape, subm ? in_shape : out_shape, k3, stride, padding, nullptr, subm, g);
@@ -1257,14 +1240,11 @@ int bevamd_spconv_slab_build_from_sorted_ex(const int* out_indices, int m_cap, c
   const uint32_t* keys = (const uint32_t*)in_index;
   const int* xstart = (const int*)((const char*)in_index + align_up((size_t)(in_n_cap > 0 ? in_n_cap : 1) * 4, 256));
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;
-#define BEVAMD_GO(BM, SUBM, COMPACT) \
-  sp_slab_from_sorted_kernel<BM, SUBM, COMPACT><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, in_n_cap, (int2*)hdr, (uint16_t*)slots, status)
-  if (compact) {
-    if (block_rows == 128) { if (subm) BEVAMD_GO(128, true, true); else BEVAMD_GO(128, false, true); }
-    else { if (subm) BEVAMD_GO(256, true, true); else BEVAMD_GO(256, false, true); }
-  } else if (block_rows == 64) { if (subm) BEVAMD_GO(64, true, false); else BEVAMD_GO(64, false, false); }
-  else if (block_rows == 128) { if (subm) BEVAMD_GO(128, true, false); else BEVAMD_GO(128, false, false); }
-  else { if (subm) BEVAMD_GO(256, true, false); else BEVAMD_GO(256, false, false); }
+#define BEVAMD_GO(BM, SUBM) \
+  sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, in_n_cap, (int2*)hdr, (uint16_t*)slots, status)
+  if (block_rows == 64) { if (subm) BEVAMD_GO(64, true); else BEVAMD_GO(64, false); }
+  else if (block_rows == 128) { if (subm) BEVAMD_GO(128, true); else BEVAMD_GO(128, false); }
+  else { if (subm) BEVAMD_GO(256, true); else BEVAMD_GO(256, false); }
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("sp_slab_from_sorted");
   return BEVAMD_OK;

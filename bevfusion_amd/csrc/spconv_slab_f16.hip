@@ -33,9 +33,7 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
   if (cin >= 1 && cin <= 16) {
     if (max_n > 0) codes[0] = slab::SMALL_BASE + 256;
     if (max_n > 1) codes[1] = slab::SMALL_BASE + 128;
-    if (max_n > 2) codes[2] = slab::SMALL_BASE + slab::SMALL_COMPACT + 256;
-    if (max_n > 3) codes[3] = slab::SMALL_BASE + slab::SMALL_COMPACT + 128;
-    return 4;
+    return 2;
   }
   int n = 0, nr = 0;
   const slab::Shape* s = slab::shapes_of(cin, &n);
@@ -66,14 +64,6 @@ size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows) {
   if (m_cap <= 0 || block_rows <= 0) return 0;
   return (size_t)((m_cap + block_rows - 1) / block_rows) * 27 * block_rows * sizeof(uint16_t);
 }
-/* ... of the compact format (compact != 0: 60 bytes per row reserved — mask, start, up to 27 slots; the narrow-row kernels) */
-size_t bevamd_spconv_slab_slot_bytes_ex(int m_cap, int block_rows, int compact) {
-  if (!compact) return bevamd_spconv_slab_slot_bytes(m_cap, block_rows);
-  if (m_cap <= 0 || block_rows <= 0) return 0;
-  return (size_t)((m_cap + block_rows - 1) / block_rows) * slab::COMPACT_BYTES_PER_ROW * block_rows;
-}
-/* 1 if `variant` of the narrow-row kernels (cin <= 16) reads the compact slot format */
-int bevamd_spconv_slab_variant_compact(int cin, int variant) { return slab::small_compact(cin, variant) ? 1 : 0; }
 
 /* Block metadata of a 3x3x3 SubM neighbour table nbr [27, nbr_stride] over m rows (m = *m_dev clamped to m_cap, or m_cap):
  * per block of block_rows (128 | 256) rows and kernel plane kx: hdr = (first input row, row count) of the range its nine
@@ -141,7 +131,7 @@ int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_st
   sa.slots = (const uint16_t*)slots;
   sa.wimg_bytes = (unsigned)(tile::image_elems(27, cinp, cout / 16) * 2);
   {
-    const size_t sb = bevamd_spconv_slab_slot_bytes_ex(num_out, block_rows, slab::small_compact(cin, variant) ? 1 : 0);
+    const size_t sb = bevamd_spconv_slab_slot_bytes(num_out, block_rows);
     BEVAMD_REQUIRE(sb < 0x100000000ull, "spconv_conv_forward_slab: slot table of 4 GiB or more");
     sa.slot_bytes = (unsigned)sb;
   }

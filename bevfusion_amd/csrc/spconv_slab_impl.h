@@ -44,15 +44,13 @@ static inline long long persistent_cap(int wg_per_xcd) {
   const long long c = (long long)wg_per_xcd * pct / 100;
   return c < 1 ? 1 : c;
 }
-constexpr int SMALL_BASE = 3000000;   // variant codes of the narrow-row kernels: SMALL_BASE + rows per block,
-constexpr int SMALL_COMPACT = 100000;  // + SMALL_COMPACT: the same kernel reading compact slot metadata (mask + start + list)
+constexpr int SMALL_BASE = 3000000;   // variant codes of the narrow-row kernels: SMALL_BASE + rows per block
 static inline int small_block_rows(int cinp, int variant) {
   if (cinp != 8 && cinp != 16) return 0;
-  if (variant == 0 || variant == SMALL_BASE + 256 || variant == SMALL_BASE + SMALL_COMPACT + 256) return 256;
-  if (variant == SMALL_BASE + 128 || variant == SMALL_BASE + SMALL_COMPACT + 128) return 128;
+  if (variant == 0 || variant == SMALL_BASE + 256) return 256;
+  if (variant == SMALL_BASE + 128) return 128;
   return 0;
 }
-static inline bool small_compact(int cin, int variant) { return cin <= 16 && variant >= SMALL_BASE + SMALL_COMPACT && variant < SMALL_BASE + 2 * SMALL_COMPACT; }
 // resident workgroups per XCD of a persistent kernel on the current device (0 on error)
 template <typename K>
 static inline int resident_per_xcd(PerDevice& pd, K kern, int threads, int bytes) {
@@ -231,11 +229,11 @@ static inline int block_rows_of(int cin, int variant) {
 }
 
 // ---- narrow-row kernels (spconv_slab_small.h): cin padded to 8 | 16, cout 16 | 32; variant = 3000000 + block rows ----------
-template <int DT, int CIN, int NT, int MT, int NW, int CW, int CAP, bool COMPACT = false>
+template <int DT, int CIN, int NT, int MT, int NW, int CW, int CAP>
 static int run_s(const SlabArgs& sa, hipStream_t stream) {
-  typedef PlanS<CIN, NT, MT, NW, CW, CAP, COMPACT> P;
+  typedef PlanS<CIN, NT, MT, NW, CW, CAP> P;
   static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
-  auto kern = &spconv_slabs_kernel<DT, CIN, NT, MT, NW, CW, CAP, COMPACT>;
+  auto kern = &spconv_slabs_kernel<DT, CIN, NT, MT, NW, CW, CAP>;
   static PerDevice pd = {};
   const int wg_per_xcd = resident_per_xcd(pd, kern, NW * 64, P::BYTES);
   if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
@@ -249,17 +247,7 @@ static int run_s(const SlabArgs& sa, hipStream_t stream) {
 template <int DT>
 int launch_s_impl(const SlabArgs& sa, int cinp, int nt, int variant, hipStream_t stream) {
   const int bm = small_block_rows(cinp, variant);
-  if (small_compact(cinp, variant)) {
-    if (bm == 256) {
-      if (cinp == 8 && nt == 1) return run_s<DT, 8, 1, 4, 4, 1, 384, true>(sa, stream);
-      if (cinp == 16 && nt == 1) return run_s<DT, 16, 1, 4, 4, 1, 384, true>(sa, stream);
-      if (cinp == 16 && nt == 2) return run_s<DT, 16, 2, 4, 8, 2, 384, true>(sa, stream);
-    } else if (bm == 128) {
-      if (cinp == 8 && nt == 1) return run_s<DT, 8, 1, 2, 4, 1, 256, true>(sa, stream);
-      if (cinp == 16 && nt == 1) return run_s<DT, 16, 1, 2, 4, 1, 256, true>(sa, stream);
-      if (cinp == 16 && nt == 2) return run_s<DT, 16, 2, 2, 8, 2, 256, true>(sa, stream);
-    }
-  } else if (bm == 256) {
+  if (bm == 256) {
     if (cinp == 8 && nt == 1) return run_s<DT, 8, 1, 4, 4, 1, 384>(sa, stream);
     if (cinp == 16 && nt == 1) return run_s<DT, 16, 1, 4, 4, 1, 384>(sa, stream);
     if (cinp == 16 && nt == 2) return run_s<DT, 16, 2, 4, 8, 2, 384>(sa, stream);

@@ -68,86 +68,6 @@ __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, in
   if (overflow && t == 0 && status) atomicOr(status, 1);
 }
 
-// COMPACT metadata (the narrow-row kernels of spconv_slab_small.h: level 1 of the encoder, where a row has ~5 of its 27 neighbours
-// and a 54-byte slot row is more than the 32-byte feature row it addresses): per block of BM rows, 60 * BM bytes reserved,
-//   mask  [BM] u32   bit k set: tap k has a neighbour (inside the plane's range)
-//   start [BM] u16   entries of the rows before this one in the block's list
-//   list  [<= 27 * BM] u16   the slots of the set taps, row after row, taps ascending
-// and the list length in bits 16..29 of the block's first header count.  Only the used part is written or read: 6 + 2 * pairs
-// bytes per row (level 1: ~16 instead of 54).  Same slot values as slab_emit.
-constexpr int COMPACT_BYTES_PER_ROW = 60;
-template <int BM>
-__device__ __forceinline__ void slab_emit_compact(const int (&v)[27], int blk, int t, int2* __restrict__ hdr,
-                                                  uint16_t* __restrict__ slots, int* __restrict__ status) {
-  __shared__ int s_lo[BM / 64][PLANES], s_hi[BM / 64][PLANES];
-  __shared__ int s_cnt[BM / 64];
-  const int w = t >> 6;
-#pragma unroll
-  for (int j = 0; j < PLANES; ++j) {
-    int lo = 0x7FFFFFFF, hi = -1;
-#pragma unroll
-    for (int d = 0; d < TAPS; ++d) {
-      const int x = v[j * TAPS + d];
-      if (x >= 0) { lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-      lo = l2 < lo ? l2 : lo;
-      hi = h2 > hi ? h2 : hi;
-    }
-    if ((t & 63) == 0) { s_lo[w][j] = lo; s_hi[w][j] = hi; }
-  }
-  __syncthreads();
-  bool overflow = false;
-  int plo[PLANES], pcnt[PLANES];
-#pragma unroll
-  for (int j = 0; j < PLANES; ++j) {
-    int lo = 0x7FFFFFFF, hi = -1;
-#pragma unroll
-    for (int i = 0; i < BM / 64; ++i) { lo = s_lo[i][j] < lo ? s_lo[i][j] : lo; hi = s_hi[i][j] > hi ? s_hi[i][j] : hi; }
-    int cnt = hi >= 0 ? hi - lo + 1 : 0;
-    if (hi < 0) lo = 0;
-    if (cnt > 0xFFFE) { cnt = 0xFFFE; overflow = true; }
-    plo[j] = lo;
-    pcnt[j] = cnt;
-  }
-  uint32_t mask = 0;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int x = v[k], j = k / TAPS;
-    if (x >= 0 && x - plo[j] < pcnt[j]) mask |= 1u << k;
-  }
-  const int n = __popc(mask);
-  // exclusive scan of n over the block (wave scan + wave totals)
-  int inc = n;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(inc, o, 64);
-    if ((t & 63) >= o) inc += u;
-  }
-  if ((t & 63) == 63) s_cnt[w] = inc;
-  __syncthreads();
-  int base = 0, total = 0;
-#pragma unroll
-  for (int i = 0; i < BM / 64; ++i) { base += i < w ? s_cnt[i] : 0; total += s_cnt[i]; }
-  const int start = base + inc - n;
-  char* const blkb = (char*)slots + (size_t)blk * (COMPACT_BYTES_PER_ROW * BM);
-  ((uint32_t*)blkb)[t] = mask;
-  ((uint16_t*)(blkb + 4 * BM))[t] = (uint16_t)start;
-  uint16_t* list = (uint16_t*)(blkb + 6 * BM);
-  int idx = start;
-#pragma unroll
-  for (int k = 0; k < 27; ++k)
-    if ((mask >> k) & 1u) list[idx++] = (uint16_t)(v[k] - plo[k / TAPS]);
-  if (t == 0) {
-#pragma unroll
-    for (int j = 0; j < PLANES; ++j)
-      hdr[(size_t)blk * PLANES + j] = make_int2(plo[j], j == 0 ? (int)((unsigned)pcnt[j] | ((unsigned)total << 16)) : pcnt[j]);
-    if (overflow && status) atomicOr(status, 1);
-  }
-}
-
 // from a neighbour table nbr [27, nbr_stride]
 template <int BM>
 __global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ nbr, int nbr_stride, int m_cap,

@@ -21,11 +21,7 @@ namespace slab {
 
 // NW waves form an (NW / CW) x CW grid: wave (r, c) owns 16*MT rows x (NT / CW) 16-channel output tiles (the 16->32 layer
 // splits its two output tiles over two waves: 56 filter registers per wave instead of 112, 4 waves per SIMD instead of 1).
-// COMPACT: the block's metadata is mask [BM] u32 | start [BM] u16 | list [<= 27 BM] u16 (spconv_slab_meta.h: slab_emit_compact)
-// instead of the [27][BM] slot table: level-1 rows have ~5 of 27 neighbours, and the table (54 B per row) was more than half of
-// what a 16 -> 16 layer reads (profiles/r03_pmc_infer_per_kernel.txt: 69 of 129 MB).  A lane keeps the masks / starts of its MT
-// rows in registers; the slot of tap k is list[start + popcount(mask below bit k)].
-template <int CIN, int NT, int MT, int NW, int CW, int CAP, bool COMPACT = false>
+template <int CIN, int NT, int MT, int NW, int CW, int CAP>
 struct PlanS {
   static_assert(CIN == 8 || CIN == 16, "narrow rows: 8 or 16 channels");
   static_assert(NW % CW == 0 && NT % CW == 0, "bad wave grid");
@@ -42,18 +38,17 @@ struct PlanS {
   static constexpr int OFF_X = 0;
   static constexpr int XBYTES = ((ZROW + 1) * RB + 1023) / 1024 * 1024;
   static constexpr int OFF_SLOT = XBYTES;
-  static constexpr int SLOT_STRIDE = (COMPACT ? COMPACT_BYTES_PER_ROW : 27 * 2) * BM;   // bytes of a block's slot metadata in memory
-  static constexpr int SLOT_KIB = (SLOT_STRIDE + 1023) / 1024;   // DMA pieces of a block's slot metadata (compact: at most)
-  static constexpr int OFF_EPI = OFF_SLOT + SLOT_KIB * 1024;
+  static constexpr int SLOT_KIB = (27 * BM * 2 + 1023) / 1024;   // DMA pieces of a block's slot table
+  static constexpr int OFF_EPI = OFF_SLOT + 27 * BM * 2;
   static constexpr int EPI_BYTES = NW * EpiScratch<NTW>::U4 * 16;
   static constexpr int BYTES = OFF_EPI + (EPI_BYTES > 1024 ? EPI_BYTES : 1024);
   static_assert(CAP % RPI == 0, "CAP must be a whole number of DMA instructions");
   static_assert((ZROW + 1) * RB < (1 << 20), "LDS row offsets");
 };
 
-template <int DT, int CIN, int NT, int MT, int NW, int CW, int CAP, bool COMPACT = false>
+template <int DT, int CIN, int NT, int MT, int NW, int CW, int CAP>
 __global__ __launch_bounds__(NW * 64) void spconv_slabs_kernel(SlabArgs sa) {
-  typedef PlanS<CIN, NT, MT, NW, CW, CAP, COMPACT> P;
+  typedef PlanS<CIN, NT, MT, NW, CW, CAP> P;
   typedef typename Num<DT>::T T;
   constexpr int NTW = P::NTW;
   typedef WaveTile<DT, 32, NTW, MT, 1> WT;   // accumulators + epilogue only
@@ -107,16 +102,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_slabs_kernel(SlabArgs sa) {
       lo[j] = __builtin_amdgcn_readlane(hl.x, j);
       cnt[j] = __builtin_amdgcn_readlane(hl.y, j);
     }
-    int slot_kib = P::SLOT_KIB;
-    if constexpr (COMPACT) {   // the list length travels in the upper half of the first count: only the used pieces are fetched
-      const int len = (cnt[0] >> 16) & 0x3FFF;
-      cnt[0] &= 0xFFFF;
-      slot_kib = (6 * P::BM + 2 * len + 1023) >> 10;
-    }
     const bool big = cnt[0] > CAP || cnt[1] > CAP || cnt[2] > CAP;   // workgroup-uniform
-    // slot metadata of the block -> LDS, by DMA as well (whole KiB pieces; past the end of the buffer the descriptor returns zeros)
-    for (int i = w; i < slot_kib; i += NW)
-      dma16(rs_s, (unsigned)lane * 16u, (unsigned)blk * (unsigned)P::SLOT_STRIDE + (unsigned)i * 1024u, (char*)slot + i * 1024);
+    // slot table of the block -> LDS, by DMA as well (whole KiB pieces: the last one may run into the epilogue scratch, which
+    // nobody uses before the stores at the end of the block; past the end of the buffer the descriptor returns zeros)
+    for (int i = w; i < P::SLOT_KIB; i += NW)
+      dma16(rs_s, (unsigned)lane * 16u, (unsigned)blk * (unsigned)(27 * P::BM * 2) + (unsigned)i * 1024u, (char*)slot + i * 1024);
     if (!big) {
 #pragma unroll
       for (int j = 0; j < PLANES; ++j) {
@@ -135,17 +125,6 @@ __global__ __launch_bounds__(NW * 64) void spconv_slabs_kernel(SlabArgs sa) {
     WT wt;
     wt.init(aw, blk * P::BM + wr * 16 * MT, m, nullptr, (u32x4*)(L + P::OFF_EPI) + w * EpiScratch<NTW>::U4);
     const uint16_t* sl = slot + wr * 16 * MT + c;
-    // compact metadata: masks and list starts of this lane's MT rows (row wr*16*MT + mt*16 + c), the list behind them
-    unsigned mk[MT], st[MT];
-    const uint16_t* const clist = (const uint16_t*)((const char*)slot + 6 * P::BM);
-    if constexpr (COMPACT) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int r = wr * 16 * MT + mt * 16 + c;
-        mk[mt] = ((const unsigned*)slot)[r];
-        st[mt] = (unsigned)((const uint16_t*)((const char*)slot + 4 * P::BM))[r];
-      }
-    }
     // The reduction, once per operand source (compile-time: no branch inside the chunk loop).  BIG = false: rows are resident,
     // an operand is one ds_read_b128 at (plane * CAP + slot) * RB; BIG = true: a buffer load at (lo[plane] + slot) * row_bytes.
     auto reduce = [&](auto big_tag) {
@@ -157,24 +136,11 @@ __global__ __launch_bounds__(NW * 64) void spconv_slabs_kernel(SlabArgs sa) {
         const int j = tp / TAPS;
         const unsigned pbase = BIG ? (unsigned)(j == 0 ? lo[0] : j == 1 ? lo[1] : lo[2]) : (unsigned)(j * CAP);
         unsigned sv[MT];
-        bool present[MT];
-        if constexpr (COMPACT) {
-          const unsigned below = (1u << tp) - 1u;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            present[mt] = (mk[mt] >> tp) & 1u;
-            sv[mt] = (unsigned)clist[st[mt] + (unsigned)__popc(mk[mt] & below)];   // (an absent tap reads a neighbouring entry: unused)
-          }
-        } else {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            sv[mt] = (unsigned)sl[tp * P::BM + mt * 16];
-            present[mt] = sv[mt] != NO_SLOT;
-          }
-        }
+        for (int mt = 0; mt < MT; ++mt) sv[mt] = (unsigned)sl[tp * P::BM + mt * 16];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const bool hit = tap_ok && present[mt];
+          const bool hit = tap_ok && sv[mt] != NO_SLOT;
           if constexpr (BIG) xo[mt] = hit ? (pbase + sv[mt]) * row_bytes + piece : OOB;
           else xo[mt] = (hit ? pbase + sv[mt] : (unsigned)P::ZROW) * P::RB + piece;
         }

@@ -195,19 +195,16 @@ class Level:
             self._await(ev)
         return nbr
 
-    def subm_slab(self, block_rows, wait=True, compact=False):
+    def subm_slab(self, block_rows, wait=True):
         """Slab metadata (ops.SlabMeta) of the 3x3x3 SubM neighbour table, for `block_rows`-row blocks: built once, on the
-        geometry stream, behind the table it rewrites.  compact: the narrow-row kernels' mask + start + list format (sorted-key route)."""
-        key = (block_rows, bool(compact))
-        if compact and not self.use_sorted():
-            raise RuntimeError("compact slab metadata comes from the sorted-key route only")
-        if key not in self._slab:
+        geometry stream, behind the table it rewrites."""
+        if block_rows not in self._slab:
             self._fork()
             if self.use_sorted():
                 self.ensure_sorted(wait=False)
                 meta = ops.slab_build_from_sorted(self.indices, self.n_cap, self.n_dev, self.batch, self.shape, self.shape,
                                                   [1, 1, 1], [1, 1, 1], True, self.sorted_index, self.n_cap, block_rows,
-                                                  stream_ptr=self._stream_ptr(), status=self._status(), compact=compact)
+                                                  stream_ptr=self._stream_ptr(), status=self._status())
             elif (3, 3, 3) in self._subm or not _SLAB_DIRECT:
                 nbr = self.subm_neighbors((3, 3, 3), wait=False)
                 meta = ops.slab_build(nbr, self.n_cap, self.n_dev, block_rows, stream_ptr=self._stream_ptr(), status=self._status())
@@ -216,23 +213,23 @@ class Level:
                 meta = ops.slab_build_from_index(self.indices, self.n_cap, self.n_dev, self.batch, self.shape, self.index_kind,
                                                  self.index, self.index_n_cap, block_rows, stream_ptr=self._stream_ptr(),
                                                  status=self._status())
-            self._slab[key] = (meta, self._mark())
-        meta, ev = self._slab[key]
+            self._slab[block_rows] = (meta, self._mark())
+        meta, ev = self._slab[block_rows]
         if wait:
             self._await(ev)
         return meta
 
-    def down_slab(self, ksize, stride, padding, block_rows, wait=True, compact=False):
+    def down_slab(self, ksize, stride, padding, block_rows, wait=True):
         """Slab metadata of the strided 3x3x3 convolution (ksize, stride, padding) over this set, for `block_rows`-row blocks
         of OUTPUT rows: from the sorted-key index of this (input) set, behind the downsample that numbered the outputs."""
-        key = (tuple(ksize), tuple(stride), tuple(padding), block_rows, bool(compact))
+        key = (tuple(ksize), tuple(stride), tuple(padding), block_rows)
         if key not in self._down_slab:
             out, _ = self.downsample(ksize, stride, padding, wait=False, want_nbr=False)
             self.ensure_sorted(wait=False)
             self._fork()
             meta = ops.slab_build_from_sorted(out.indices, out.n_cap, out.n_dev, self.batch, self.shape, out.shape, list(stride),
                                               list(padding), False, self.sorted_index, self.n_cap, block_rows,
-                                              stream_ptr=self._stream_ptr(), status=self._status(), compact=compact)
+                                              stream_ptr=self._stream_ptr(), status=self._status())
             self._down_slab[key] = (meta, self._mark())
         meta, ev = self._down_slab[key]
         if wait:
@@ -374,9 +371,7 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
         rec["start"].record()
     if slab_variant is not None:
         rows = ops.slab_block_rows(cin, slab_variant)
-        cpt = ops.slab_variant_compact(cin, slab_variant)
-        meta = (lvl.subm_slab(rows, compact=cpt) if conv.subm
-                else lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, rows, compact=cpt))
+        meta = lvl.subm_slab(rows) if conv.subm else lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, rows)
         ops.sparse_conv_slab(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                              residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out, variant=slab_variant)
     elif slots_meta:
@@ -434,11 +429,8 @@ _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 
 # its rows in key order: 3000256 = 256-row blocks (the SubM layers share one metadata set), 3000128 = 128-row blocks (the strided
 # 16 -> 32 convolution: its two output tiles go to two waves, 8-wave workgroups, so smaller blocks keep two of them per CU).
 _CHECK = os.environ.get("BEVAMD_SPCONV_CHECK", "0") == "1"   # read the geometry status words back after every fused forward (one sync)
-# 31xxxxx: the same narrow-row kernels on compact slot metadata (mask + start + list: ~16 instead of 54 bytes per level-1 row);
-# BEVAMD_SPCONV_SLAB_COMPACT=0 keeps the [27][rows] slot tables (30xxxxx)
-_SLAB_COMPACT = os.environ.get("BEVAMD_SPCONV_SLAB_COMPACT", "1") != "0"
-_SLAB_NARROW_SUBM = 3100256 if _SLAB_COMPACT else 3000256
-_SLAB_NARROW_STRIDED = 3100128 if _SLAB_COMPACT else 3000128
+_SLAB_NARROW_SUBM = 3000256
+_SLAB_NARROW_STRIDED = 3000128
 _SORTED = os.environ.get("BEVAMD_SPCONV_SORTED", "1") != "0"          # sorted-key neighbour search on levels without a rank index
 _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and on those that have one (tuning)
 # 32 channels from 4 frames: the filter-stationary kernel (spconv_slab_fstat.h; 64-row blocks, baked slots): 159 us isolated against 190
@@ -797,7 +789,7 @@ def _prefetch_geometry(enc, lvl):
         v = _slab_variant_for(m, cur, m.in_channels, m.out_channels)
         if m.subm:
             if v is not None:
-                cur.subm_slab(ops.slab_block_rows(m.in_channels, v), wait=False, compact=ops.slab_variant_compact(m.in_channels, v))
+                cur.subm_slab(ops.slab_block_rows(m.in_channels, v), wait=False)
             else:
                 cur.subm_neighbors(m.kernel_size, wait=False)
         else:
@@ -805,8 +797,7 @@ def _prefetch_geometry(enc, lvl):
             nxt, _ = cur.downsample(m.kernel_size, m.stride, m.padding, wait=False,
                                     want_nbr=(v is None and not slots_meta) or LAYER_PROFILE is not None)
             if v is not None:
-                cur.down_slab(m.kernel_size, m.stride, m.padding, ops.slab_block_rows(m.in_channels, v), wait=False,
-                              compact=ops.slab_variant_compact(m.in_channels, v))
+                cur.down_slab(m.kernel_size, m.stride, m.padding, ops.slab_block_rows(m.in_channels, v), wait=False)
             elif slots_meta:
                 cur.down_slab(m.kernel_size, m.stride, m.padding, _GATHER_SLOT_ROWS, wait=False)
             cur = nxt

@@ -347,9 +347,8 @@ def slab_grid_ok(shape, block_rows):
 class SlabMeta:
     """Block metadata of a 3x3x3 SubM neighbour table over rows in ascending linear index (bevamd_spconv_slab_build)."""
 
-    def __init__(self, hdr, slots, block_rows, status, compact=False):
+    def __init__(self, hdr, slots, block_rows, status):
         self.hdr, self.slots, self.block_rows, self.status = hdr, slots, block_rows, status
-        self.compact = bool(compact)     # mask + start + list slots (the narrow-row kernels' 31xxxxx variants) instead of the table
 
 
 def slab_build(nbr, m_cap, m_dev, block_rows, stream_ptr=None, status=None):
@@ -403,31 +402,23 @@ def sorted_index_build(indices, n_cap, n_dev, batch, shape, stream_ptr=None, sta
 
 
 def slab_build_from_sorted(out_indices, m_cap, m_dev, batch, in_shape, out_shape, stride, padding, subm, in_index, in_n_cap,
-                           block_rows, stream_ptr=None, status=None, compact=False):
+                           block_rows, stream_ptr=None, status=None):
     """Slab metadata of a 3x3x3 convolution (submanifold, or strided with active outputs `out_indices`) from the sorted-key
-    index of its input set (bevamd_spconv_slab_build_from_sorted_ex): no neighbour table.  compact: mask + start + list slots
-    (6 + 2 * pairs bytes per row instead of 54; what the narrow-row kernels' 31xxxxx variants read)."""
+    index of its input set (bevamd_spconv_slab_build_from_sorted): no neighbour table."""
     lib = _capi.load()
     dev = out_indices.device
     with torch.cuda.device(dev):
         hdr = torch.empty(max(lib.bevamd_spconv_slab_hdr_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
-        slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes_ex(int(m_cap), int(block_rows), int(bool(compact))), 16),
-                            dtype=torch.uint8, device=dev)
+        slots = torch.empty(max(lib.bevamd_spconv_slab_slot_bytes(int(m_cap), int(block_rows)), 16), dtype=torch.uint8, device=dev)
         if status is None:   # callers on a hot path hand in a slice of one pre-zeroed pool (a 5 us fill kernel per product otherwise)
             status = torch.zeros(1, dtype=torch.int32, device=dev)
-        rc = lib.bevamd_spconv_slab_build_from_sorted_ex(_capi.ptr(out_indices), int(m_cap), _capi.ptr(m_dev), int(batch),
-                                                         _capi.ints(in_shape), _capi.ints(out_shape), _capi.ints(stride),
-                                                         _capi.ints(padding), int(bool(subm)), _capi.ptr(in_index), int(in_n_cap),
-                                                         int(block_rows), int(bool(compact)), _capi.ptr(hdr), _capi.ptr(slots),
-                                                         _capi.ptr(status),
-                                                         stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
+        rc = lib.bevamd_spconv_slab_build_from_sorted(_capi.ptr(out_indices), int(m_cap), _capi.ptr(m_dev), int(batch),
+                                                      _capi.ints(in_shape), _capi.ints(out_shape), _capi.ints(stride),
+                                                      _capi.ints(padding), int(bool(subm)), _capi.ptr(in_index), int(in_n_cap),
+                                                      int(block_rows), _capi.ptr(hdr), _capi.ptr(slots), _capi.ptr(status),
+                                                      stream_ptr if stream_ptr is not None else _capi.stream_ptr(dev))
     _capi.check(rc, "spconv_slab_build_from_sorted")
-    return SlabMeta(hdr, slots, int(block_rows), status, compact=compact)
-
-
-def slab_variant_compact(cin, variant):
-    """True when `variant` of the narrow-row kernels reads the compact slot format."""
-    return bool(_capi.load().bevamd_spconv_slab_variant_compact(int(padded_channels(cin)), int(variant)))
+    return SlabMeta(hdr, slots, int(block_rows), status)
 
 
 def sparse_conv_slab(features, image, meta, num_out, cin, cout, bias=None, bn_scale=None, bn_shift=None, residual=None,
@@ -443,9 +434,6 @@ def sparse_conv_slab(features, image, meta, num_out, cin, cout, bias=None, bn_sc
         out = torch.empty((num_out, cout), dtype=features.dtype, device=features.device)
     if num_out == 0:
         return out
-    if meta.compact != slab_variant_compact(cin, variant):
-        raise RuntimeError(f"sparse_conv_slab: variant {variant} reads {'compact' if not meta.compact else 'table'} slots, the metadata "
-                           f"holds the {'compact' if meta.compact else 'table'} format")
     if residual is not None and residual.stride(1) != 1:
         residual = residual.contiguous()
     with torch.cuda.device(features.device):

@@ -508,16 +508,6 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n);
 int bevamd_spconv_slab_grid_ok(const int* shape, int block_rows);
 size_t bevamd_spconv_slab_hdr_bytes(int m_cap, int block_rows);
 size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows);
-/* Compact slot format of the narrow-row kernels (cin <= 16; variant codes 3100256 / 3100128): per block of block_rows rows
- * mask [rows] u32 (bit k: tap k has a neighbour) | start [rows] u16 | list [<= 27 rows] u16 (the slots of the set taps, row after
- * row) and the list length in bits 16..29 of the block's first header count — 6 + 2 * pairs bytes per row are written and read
- * instead of 54 (level 1 of the encoder: ~16).  60 bytes per row are reserved. */
-size_t bevamd_spconv_slab_slot_bytes_ex(int m_cap, int block_rows, int compact);
-int bevamd_spconv_slab_variant_compact(int cin, int variant);
-int bevamd_spconv_slab_build_from_sorted_ex(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
-                                            const int* in_shape, const int* out_shape, const int* stride, const int* padding,
-                                            int subm, const void* in_index, int in_n_cap, int block_rows, int compact, void* hdr,
-                                            void* slots, int* status, void* stream);
 int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const int* m_dev, int block_rows, void* hdr,
                              void* slots, int* status, void* stream);
 

@@ -47,7 +47,7 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
     lvl = fused.Level(c, c.shape[0], tot.reshape(-1)[:1].int().contiguous(), B, list(CFG["sparse_shape"]), linear_order=True)
     ind, shape = c[:n].cpu().numpy(), list(CFG["sparse_shape"])
     widths = [16, 32, 64, 128]
-    expect = {16: fused._SLAB_NARROW_SUBM, 32: 4000112, 64: 1644222, 128: 1644220}
+    expect = {16: 3000256, 32: 4000112, 64: 1644222, 128: 1644220}
     down = [((3, 3, 3), (2, 2, 2), (1, 1, 1), 32), ((3, 3, 3), (2, 2, 2), (1, 1, 1), 64), ((3, 3, 3), (2, 2, 2), (1, 1, 0), 128),
             ((1, 1, 3), (1, 1, 2), (0, 0, 0), 128)]
     x = torch.zeros((lvl.n_cap, 16), dtype=torch.float16, device=dev)
@@ -58,9 +58,8 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
         conv = type("C", (), dict(subm=True, kernel_size=(3, 3, 3)))()
         variant = fused._slab_variant_for(conv, lvl, cw, cw)
         assert variant == expect[cw], (cw, variant)                  # exactly the kernels of an 8-frame bench step
-        got = sops.sparse_conv_slab(x, sops.make_filter_image(w),
-                                    lvl.subm_slab(sops.slab_block_rows(cw, variant), compact=sops.slab_variant_compact(cw, variant)),
-                                    lvl.n_cap, cw, cw, num_out_dev=lvl.n_dev, variant=variant)[:n]
+        got = sops.sparse_conv_slab(x, sops.make_filter_image(w), lvl.subm_slab(sops.slab_block_rows(cw, variant)), lvl.n_cap,
+                                    cw, cw, num_out_dev=lvl.n_dev, variant=variant)[:n]
         _, sp, sn, _ = oracle.get_indice_pairs(ind, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
         ref = oracle.indice_conv(x[:n].float().cpu().numpy(), w.float().cpu().numpy(), sp, sn, n)
         err = float(np.max(np.abs(got.float().cpu().numpy() - ref)))
@@ -71,12 +70,12 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
         ws = torch.from_numpy((rng.standard_normal(tuple(ks) + (cw, cout)) / np.sqrt(cw * K / 4)).astype(np.float32)).to(dev).half()
         sconv = type("C", (), dict(subm=False, kernel_size=ks))()
         svar = fused._slab_variant_for(sconv, lvl, cw, cout)
-        assert (svar is not None) == (stage == 0) and (svar is None or svar == fused._SLAB_NARROW_STRIDED)
+        assert (svar is not None) == (stage == 0) and (svar is None or svar == 3000128)
         nxt, nbr = lvl.downsample(list(ks), list(st), list(pd), want_nbr=svar is None)
         m = int(nxt.n_dev.item())
         assert m == oi.shape[0] and np.array_equal(nxt.indices[:m].cpu().numpy(), oi)
         if svar is not None:
-            meta = lvl.down_slab(list(ks), list(st), list(pd), sops.slab_block_rows(cw, svar), compact=sops.slab_variant_compact(cw, svar))
+            meta = lvl.down_slab(list(ks), list(st), list(pd), sops.slab_block_rows(cw, svar))
             y = sops.sparse_conv_slab(x, sops.make_filter_image(ws), meta, nxt.n_cap, cw, cout, num_out_dev=nxt.n_dev, variant=svar)
         else:
             y = sops.sparse_conv_tiled(x, sops.make_filter_image(ws), nbr, nxt.n_cap, K, cw, cout, num_out_dev=nxt.n_dev,

@@ -194,53 +194,6 @@ def test_strided_metadata_from_sorted_keys_equals_the_table_route(dev, batch, sh
     assert fused.geometry_status(lvl) == 0
 
 
-@pytest.mark.parametrize("rows", [128, 256])
-@pytest.mark.parametrize("subm", [True, False])
-def test_compact_slot_metadata_decodes_to_the_slot_table(dev, rows, subm):
-    """mask + start + list (bevamd_spconv_slab_build_from_sorted_ex, compact = 1) holds exactly the slots of the [27][rows] table
-    built by the same search: same headers (the list length rides in the first count), bit k set <=> table entry != 0xFFFF,
-    list entries = the table's values in (row, tap) order, starts = running entry count inside the block."""
-    rng = np.random.default_rng(rows + subm)
-    batch, shape, n = 2, [24, 20, 9], 2500
-    c4, _, ct = random_sorted_set(rng, batch, shape, n, dev)
-    m = c4.shape[0]
-    n_dev = torch.tensor([m], dtype=torch.int32, device=dev)
-    lvl = fused.Level(ct.contiguous(), m, n_dev, batch, shape, linear_order=True)
-    if subm:
-        table, compact = lvl.subm_slab(rows), lvl.subm_slab(rows, compact=True)
-        mo = m
-    else:
-        out, _ = lvl.downsample([3, 3, 3], [2, 2, 2], [1, 1, 1])
-        table = lvl.down_slab([3, 3, 3], [2, 2, 2], [1, 1, 1], rows)
-        compact = lvl.down_slab([3, 3, 3], [2, 2, 2], [1, 1, 1], rows, compact=True)
-        mo = int(out.n_dev.item())
-    assert compact.compact and not table.compact
-    nblk = (mo + rows - 1) // rows
-    th = table.hdr.cpu().numpy().view(np.int32).reshape(-1, 3, 2)[:nblk]
-    ch = compact.hdr.cpu().numpy().view(np.int32).reshape(-1, 3, 2)[:nblk].copy()
-    lens = (ch[:, 0, 1] >> 16) & 0x3FFF
-    ch[:, 0, 1] &= 0xFFFF
-    assert np.array_equal(th, ch)
-    ts = table.slots.cpu().numpy().view(np.uint16)[: nblk * 27 * rows].reshape(nblk, 27, rows)
-    raw = compact.slots.cpu().numpy()[: nblk * 60 * rows].reshape(nblk, 60 * rows)
-    for b in range(nblk):
-        mask = raw[b, : 4 * rows].view(np.uint32)
-        start = raw[b, 4 * rows: 6 * rows].view(np.uint16)
-        lst = raw[b, 6 * rows:].view(np.uint16)
-        live = min(rows, mo - b * rows)
-        want_mask = np.zeros(rows, np.uint32)
-        entries = []
-        for r in range(live):
-            assert start[r] == len(entries)
-            for k in range(27):
-                if ts[b, k, r] != 0xFFFF:
-                    want_mask[r] |= np.uint32(1 << k)
-                    entries.append(ts[b, k, r])
-        assert np.array_equal(mask[:live], want_mask[:live]) and not mask[live:].any()
-        assert lens[b] == len(entries) and np.array_equal(lst[: len(entries)], np.array(entries, np.uint16))
-    assert fused.geometry_status(lvl) == 0
-
-
 # ---- convolution ------------------------------------------------------------------------------------------------------------
 def _filters(rng, ks, cin, cout, dev, dtype):
     w = rng.standard_normal(tuple(ks) + (cin, cout)) / np.sqrt(cin * 27 / 4)
@@ -249,7 +202,7 @@ def _filters(rng, ks, cin, cout, dev, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16)])
-@pytest.mark.parametrize("variant", [3000256, 3000128, 3100256, 3100128])
+@pytest.mark.parametrize("variant", [3000256, 3000128])
 @pytest.mark.parametrize("batch,shape,n", [(2, [24, 20, 9], 2500), (1, [6, 10, 80], 4800), (1, [40, 40, 21], 9000)])
 def test_narrow_subm_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, cin, cout, variant, batch, shape, n):
     """(1, [6, 10, 80], dense) makes plane ranges of 256 + 2*81 rows: past the 384-row staging buffer -> the global-memory
@@ -269,8 +222,8 @@ def test_narrow_subm_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, cin, cout
     w = _filters(rng, (3, 3, 3), cin, cout, dev, dtype)
     img = sops.make_filter_image(w)
     rows = sops.slab_block_rows(cin, variant)
-    assert rows == variant % 1000                                       # 31xxxxx: the same kernels on compact slot metadata
-    meta = lvl.subm_slab(rows, compact=sops.slab_variant_compact(cin, variant))
+    assert rows == variant - 3000000
+    meta = lvl.subm_slab(rows)
     nbr = lvl.subm_neighbors((3, 3, 3))
     bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1).to(dev).to(dtype)
     scale = torch.from_numpy(rng.uniform(0.7, 1.3, cout).astype(np.float32)).to(dev)
@@ -290,7 +243,7 @@ def test_narrow_subm_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, cin, cout
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("variant", [3000256, 3000128, 3100256, 3100128])
+@pytest.mark.parametrize("variant", [3000256, 3000128])
 @pytest.mark.parametrize("batch,shape,n,pad", [(2, [24, 20, 9], 2500, (1, 1, 1)), (1, [16, 24, 41], 15000, (1, 1, 1)),
                                                 (1, [40, 40, 21], 9000, (1, 1, 0))])
 def test_narrow_strided_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, variant, batch, shape, n, pad):
@@ -309,7 +262,7 @@ def test_narrow_strided_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, varian
     img = sops.make_filter_image(w)
     rows = sops.slab_block_rows(16, variant)
     out, nbr = lvl.downsample([3, 3, 3], [2, 2, 2], list(pad))
-    meta = lvl.down_slab([3, 3, 3], [2, 2, 2], list(pad), rows, compact=sops.slab_variant_compact(16, variant))
+    meta = lvl.down_slab([3, 3, 3], [2, 2, 2], list(pad), rows)
     mo = int(out.n_dev.item())
     scale = torch.from_numpy(rng.uniform(0.7, 1.3, 32).astype(np.float32)).to(dev)
     shift = torch.from_numpy(rng.standard_normal(32).astype(np.float32) * 0.1).to(dev)
@@ -396,7 +349,7 @@ def test_encoder_key_ordered_path_is_bit_identical_to_first_appearance_path(dev,
     assert tuple(got.shape) == (B, 256, 180, 180)
     # level 1 ran on the narrow slab kernels: input layer, four 16 -> 16 layers, the strided 16 -> 32
     assert kinds[0][:4] == (5, 16, True, "slab") and all(k[3] == "slab" for k in kinds[1:5]) and kinds[5][:4] == (16, 32, False, "slab")
-    assert kinds[5][4] == fused._SLAB_NARROW_STRIDED and kinds[1][4] == fused._SLAB_NARROW_SUBM
+    assert kinds[5][4] == 3000128 and kinds[1][4] == 3000256
     assert torch.equal(again, ref), "un-profiled key-order pass"
     assert torch.equal(prepared, ref), "key-order pass over a prepared geometry"
     assert torch.equal(got, ref), "profiled key-order pass"
