@@ -80,15 +80,56 @@ __device__ __forceinline__ void slab_of(long long n, long long& lo, long long& h
   hi = lo + per < n ? lo + per : n;
 }
 
-// Per-channel totals of two quantities over all workgroups: every workgroup leaves its slab's sums in part[g][2][C]; the last one
-// to arrive (ticket counter, reset for the next launch) adds them up in slab order in fp64 and hands (A, B) per channel to `fin`.
+// Per-channel totals of two quantities over all workgroups, in two levels so that no workgroup walks more than GROUP partials
+// alone: every workgroup leaves its slab's sums in part[g][2][C] (fp32); the LAST of each group of GROUP consecutive workgroups to
+// arrive (a ticket per group) adds the group's partials up in slab order in fp64 and leaves them in gpart[group][2][C]; the last
+// GROUP leader to finish (one more ticket) adds the group sums up in group order and hands (A, B) per channel to `fin`.  Fixed
+// orders throughout: bit-reproducible.  Tickets are zero before the launch and zero again after it.
+constexpr int GROUP = 32;
+constexpr int MAX_SLABS = 1024;
+constexpr int MAX_GROUPS = MAX_SLABS / GROUP;
+
+// sum over `n` partial rows (stride floats/doubles apart) per channel, by one workgroup: thread -> (channel, share), four rows in flight
+template <typename T, typename Out>
+__device__ __forceinline__ void block_column_sums(const T* __restrict__ src, int n, size_t stride, int C, double (*red)[THREADS], Out out) {
+  const int Cp = C <= THREADS ? C : THREADS;
+  const int nshare = THREADS / Cp;
+  for (int c0 = 0; c0 < C; c0 += Cp) {
+    const int c = c0 + (int)threadIdx.x % Cp, s = (int)threadIdx.x / Cp;
+    double a = 0.0, b = 0.0;
+    if (c < C && s < nshare)
+      for (int g = s; g < n; g += 4 * nshare) {   // four partials requested together, added in order
+        T pa[4], pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int gu = g + u * nshare < n ? g + u * nshare : g;
+          pa[u] = __hip_atomic_load(src + (size_t)gu * stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pb[u] = __hip_atomic_load(src + (size_t)gu * stride + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (g + u * nshare < n) { a += (double)pa[u]; b += (double)pb[u]; }
+      }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < Cp && c < C) {
+      double ta = 0.0, tb = 0.0;
+      for (int s2 = 0; s2 < nshare; ++s2) { ta += red[0][s2 * Cp + threadIdx.x]; tb += red[1][s2 * Cp + threadIdx.x]; }
+      out(c, ta, tb);
+    }
+    __syncthreads();
+  }
+}
+
 template <typename Fin>
 __device__ __forceinline__ void finish_totals(const float* sa, const float* sb, int C, float* __restrict__ part,
-                                              unsigned* __restrict__ ticket, Fin fin) {
-  // sa / sb: this workgroup's sums in LDS, [C] each
+                                              double* __restrict__ gpart, unsigned* __restrict__ tickets, Fin fin) {
+  // sa / sb: this workgroup's sums in LDS, [C] each;  tickets[0 .. ngroups) per group, tickets[MAX_GROUPS] for the leaders
   __shared__ bool last;
   __shared__ double red[2][THREADS];
-  const int G = (int)gridDim.x;
+  const int G = (int)gridDim.x, grp = (int)blockIdx.x / GROUP, ngroups = (G + GROUP - 1) / GROUP;
+  const int gsize = (grp + 1) * GROUP <= G ? GROUP : G - grp * GROUP;
   float* mine = part + (size_t)blockIdx.x * 2 * C;
   for (int c = threadIdx.x; c < C; c += THREADS) {
     __hip_atomic_store(mine + c, sa[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -97,42 +138,29 @@ __device__ __forceinline__ void finish_totals(const float* sa, const float* sb, 
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last = t == (unsigned)G - 1u;
-    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(tickets + grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == (unsigned)gsize - 1u;
+    if (last) __hip_atomic_store(tickets + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (!last) return;
   __threadfence();
-  // thread -> (channel c, share s of the slabs): nshare = THREADS / C' threads per channel, fixed assignment -> fixed order
-  const int Cp = C <= THREADS ? C : THREADS;
-  const int nshare = THREADS / Cp;
-  for (int c0 = 0; c0 < C; c0 += Cp) {
-    const int c = c0 + (int)threadIdx.x % Cp, s = (int)threadIdx.x / Cp;
-    double a = 0.0, b = 0.0;
-    if (c < C && s < nshare)
-      for (int g = s; g < G; g += 4 * nshare) {   // four slabs' partials requested together, added in slab order
-        float pa[4], pb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int gu = g + u * nshare < G ? g + u * nshare : g;
-          pa[u] = __hip_atomic_load(part + (size_t)gu * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          pb[u] = __hip_atomic_load(part + (size_t)gu * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (g + u * nshare < G) { a += (double)pa[u]; b += (double)pb[u]; }
-      }
-    red[0][threadIdx.x] = a;
-    red[1][threadIdx.x] = b;
-    __syncthreads();
-    if ((int)threadIdx.x < Cp && c < C) {
-      double ta = 0.0, tb = 0.0;
-      for (int s2 = 0; s2 < nshare; ++s2) { ta += red[0][s2 * Cp + threadIdx.x]; tb += red[1][s2 * Cp + threadIdx.x]; }
-      fin(c, ta, tb);
-    }
-    __syncthreads();
+  double* gm = gpart + (size_t)grp * 2 * C;
+  block_column_sums<float>(part + (size_t)grp * GROUP * 2 * C, gsize, (size_t)2 * C, C, red, [&](int c, double a, double b) {
+    __hip_atomic_store(gm + c, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(gm + C + c, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  });
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(tickets + MAX_GROUPS, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = t == (unsigned)ngroups - 1u;
+    if (last) __hip_atomic_store(tickets + MAX_GROUPS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  block_column_sums<double>(gpart, ngroups, (size_t)2 * C, C, red, fin);
 }
 
 // this workgroup's per-channel sums of (p, q) over its rows -> LDS sa / sb [C]; `rowfn(row, cv, p[VEC], q[VEC])` supplies the terms
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restric
                                                            float eps, float momentum, float* __restrict__ mean,
                                                            float* __restrict__ invstd, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ part,
-                                                           unsigned* __restrict__ ticket) {
+                                                           double* __restrict__ gpart, unsigned* __restrict__ ticket) {
   typedef Row<DT> R;
   typedef typename R::V V;
   __shared__ float sa[MAX_C], sb[MAX_C];
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restric
       }
     }
   });
-  finish_totals(sa, sb, C, part, ticket, [&](int c, double s, double ss) {
+  finish_totals(sa, sb, C, part, gpart, ticket, [&](int c, double s, double ss) {
     const double m = s / (double)n;
     double var = ss / (double)n - m * m;
     var = var > 0.0 ? var : 0.0;
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const void* __re
                                                                 int relu, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, float* __restrict__ sum_dz,
                                                                 float* __restrict__ sum_dz_xhat, float* __restrict__ part,
-                                                                unsigned* __restrict__ ticket) {
+                                                                double* __restrict__ gpart, unsigned* __restrict__ ticket) {
   typedef Row<DT> R;
   typedef typename R::V V;
   __shared__ float sa[MAX_C], sb[MAX_C];
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const void* __re
       }
     }
   });
-  finish_totals(sa, sb, C, part, ticket, [&](int c, double a, double b) {
+  finish_totals(sa, sb, C, part, gpart, ticket, [&](int c, double a, double b) {
     sum_dz[c] = (float)a;
     sum_dz_xhat[c] = (float)b;
   });
@@ -375,8 +403,8 @@ static int check_shape(const char* who, long long n, int c, int dtype) {
 
 static unsigned reduce_grid(long long n, int c, int dtype) {
   const int vec = dtype == 0 ? 4 : 8, rif = THREADS / (c / vec);
-  long long g = n / ((long long)rif * 16);     // >= 16 rows per lane (four trips of four); at most 512 slabs: the last workgroup
-  return (unsigned)(g < 1 ? 1 : g > 512 ? 512 : g);   // adds their partials up alone (a serial tail of G / nshare round trips)
+  long long g = n / ((long long)rif * 16);     // >= 16 rows per lane (four trips of four), at most MAX_SLABS slabs
+  return (unsigned)(g < 1 ? 1 : g > MAX_SLABS ? MAX_SLABS : g);
 }
 
 static unsigned apply_grid(long long n, int c, int dtype) {
@@ -396,7 +424,9 @@ extern "C" {
 
 /* Scratch of the two reducing kernels: slab partials (fp32) + one ticket word (must be ZERO before the first launch that uses
  * it; every launch leaves it zero again).  bytes: bevamd_sparse_bn_workspace_bytes(c). */
-size_t bevamd_sparse_bn_workspace_bytes(int c) { return c > 0 ? align_up((size_t)1024 * 2 * c * sizeof(float), 256) + 256 : 0; }
+static size_t ws_part_bytes(int c) { return align_up((size_t)MAX_SLABS * 2 * c * sizeof(float), 256); }
+static size_t ws_gpart_bytes(int c) { return align_up((size_t)MAX_GROUPS * 2 * c * sizeof(double), 256); }
+size_t bevamd_sparse_bn_workspace_bytes(int c) { return c > 0 ? ws_part_bytes(c) + ws_gpart_bytes(c) + 256 : 0; }
 
 /* Training-mode statistics of x [n, c] (row pitch `stride` elements; dtype 0 fp32 | 1 fp16 | 2 bf16): mean [c], invstd [c] =
  * 1 / sqrt(biased var + eps) (fp32), and — when given — running_mean / running_var updated in place with `momentum` (unbiased
@@ -412,11 +442,12 @@ int bevamd_sparse_bn_stats(const void* x, int dtype, long long n, int c, long lo
     return BEVAMD_ERR_WORKSPACE;
   }
   float* part = (float*)ws;
-  unsigned* ticket = (unsigned*)((char*)ws + align_up((size_t)1024 * 2 * c * sizeof(float), 256));
+  double* gpart = (double*)((char*)ws + ws_part_bytes(c));
+  unsigned* ticket = (unsigned*)((char*)ws + ws_part_bytes(c) + ws_gpart_bytes(c));   // MAX_GROUPS + 1 words, zero between launches
   const unsigned g = reduce_grid(n, c, dtype);
   const int vec = dtype == 0 ? 4 : 8;
   const size_t lds = (size_t)(THREADS / (c / vec)) * 2 * c * sizeof(float);
-#define BEVAMD_GO(DT) bn_stats_kernel<DT><<<dim3(g), dim3(THREADS), lds, stream>>>(x, n, c, stride, eps, momentum, mean, invstd, running_mean, running_var, part, ticket)
+#define BEVAMD_GO(DT) bn_stats_kernel<DT><<<dim3(g), dim3(THREADS), lds, stream>>>(x, n, c, stride, eps, momentum, mean, invstd, running_mean, running_var, part, gpart, ticket)
   if (dtype == 0) BEVAMD_GO(0); else if (dtype == 1) BEVAMD_GO(1); else BEVAMD_GO(2);
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("bn_stats");
@@ -459,14 +490,15 @@ int bevamd_sparse_bn_backward(const void* dy, long long dy_stride, const void* y
     return BEVAMD_ERR_WORKSPACE;
   }
   float* part = (float*)ws;
-  unsigned* ticket = (unsigned*)((char*)ws + align_up((size_t)1024 * 2 * c * sizeof(float), 256));
+  double* gpart = (double*)((char*)ws + ws_part_bytes(c));
+  unsigned* ticket = (unsigned*)((char*)ws + ws_part_bytes(c) + ws_gpart_bytes(c));
   const unsigned g = reduce_grid(n, c, dtype), ga = apply_grid(n, c, dtype);
   const int vec = dtype == 0 ? 4 : 8;
   const size_t lds = (size_t)(THREADS / (c / vec)) * 2 * c * sizeof(float);
 #define BEVAMD_GO(DT)                                                                                                              \
   do {                                                                                                                             \
     bn_bwd_reduce_kernel<DT><<<dim3(g), dim3(THREADS), lds, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean,      \
-                                                                      invstd, sum_dz, sum_dz_xhat, part, ticket);                  \
+                                                                      invstd, sum_dz, sum_dz_xhat, part, gpart, ticket);           \
     bn_bwd_apply_kernel<DT><<<dim3(ga), dim3(THREADS), 0, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean, invstd, \
                                                                     weight, sum_dz, sum_dz_xhat, dx, dx_stride, d_residual,        \
                                                                     dres_stride);                                                  \

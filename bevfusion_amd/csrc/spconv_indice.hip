@@ -388,12 +388,14 @@ __global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint8_t* _
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
 }
 
-// exclusive popcount prefix of every bitmap word.  `tile_sums` are the raw per-tile popcounts: each workgroup adds up the
-// tiles before it itself (a few hundred values) — no scan launch in between — and the last one publishes the row count,
+// Exclusive popcount prefix of every bitmap word + the coordinates of every active output in ascending linear index, in ONE
+// launch (rounds 1-3: a prefix kernel and an emit kernel): `tile_sums` are the raw per-tile popcounts, each workgroup adds up the
+// tiles before it itself (a few hundred values: no scan launch in between), completes the prefix of its tile's words and — with
+// the bits and the prefixes still in registers — emits the outputs those words hold; the last one publishes the row count,
 // clamped to the capacity.
-__global__ __launch_bounds__(256) void sp_rank_apply_kernel(uint2* __restrict__ words, size_t nwords,
-                                                            const uint32_t* __restrict__ tile_sums, int* count,
-                                                            int out_cap) {
+__global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restrict__ words, size_t nwords,
+                                                                 const uint32_t* __restrict__ tile_sums, int* count, ConvGeom g,
+                                                                 int* __restrict__ out_indices, int out_cap) {
   __shared__ unsigned lds_wave[4];
   unsigned part = 0;
   for (unsigned t = threadIdx.x; t < blockIdx.x; t += 256) part += tile_sums[t];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void sp_rank_apply_kernel(uint2* __restrict__ 
   __syncthreads();
   const unsigned tile_base = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
   __syncthreads();
-  constexpr int PER = RANK_TILE / 256;  // consecutive words per thread
+  constexpr int PER = RANK_TILE / 256;
   const size_t w0 = (size_t)blockIdx.x * RANK_TILE + (size_t)threadIdx.x * PER;
   uint32_t bits[PER];
   unsigned s = 0;
@@ -416,33 +418,23 @@ __global__ __launch_bounds__(256) void sp_rank_apply_kernel(uint2* __restrict__ 
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     if (w0 + i < nwords) words[w0 + i].y = run;
-    run += __popc(bits[i]);
-  }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    const unsigned total = tile_base + tot;
-    *count = (int)(total < (unsigned)out_cap ? total : (unsigned)out_cap);
-  }
-}
-
-// coordinates of every active output, in ascending linear index: one thread per bitmap word
-__global__ __launch_bounds__(256) void sp_rank_emit_kernel(const uint2* __restrict__ words, size_t nwords, ConvGeom g,
-                                                           int* __restrict__ out_indices, int out_cap) {
-  for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (size_t)gridDim.x * 256) {
-    const uint2 wd = words[w];
-    uint32_t b = wd.x;
-    unsigned run = wd.y;
+    uint32_t b = bits[i];
     while (b) {
       const int t = __ffs(b) - 1;
       b &= b - 1;
       if (run < (unsigned)out_cap) {
-        uint32_t k = (uint32_t)(w * 32 + t);
-        int oz = (int)(k % (uint32_t)g.out_shape[2]); k /= (uint32_t)g.out_shape[2];
-        int oy = (int)(k % (uint32_t)g.out_shape[1]); k /= (uint32_t)g.out_shape[1];
-        int ox = (int)(k % (uint32_t)g.out_shape[0]); k /= (uint32_t)g.out_shape[0];
+        uint32_t k = (uint32_t)((w0 + i) * 32 + t);
+        const int oz = (int)(k % (uint32_t)g.out_shape[2]); k /= (uint32_t)g.out_shape[2];
+        const int oy = (int)(k % (uint32_t)g.out_shape[1]); k /= (uint32_t)g.out_shape[1];
+        const int ox = (int)(k % (uint32_t)g.out_shape[0]); k /= (uint32_t)g.out_shape[0];
         ((int4*)out_indices)[run] = make_int4((int)k, ox, oy, oz);
       }
       ++run;
     }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const unsigned total = tile_base + tot;
+    *count = (int)(total < (unsigned)out_cap ? total : (unsigned)out_cap);
   }
 }
 
@@ -706,10 +698,8 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
   BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
   (void)sws;
   (void)sws_bytes;
-  sp_rank_apply_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, out_cap);
-  BEVAMD_LAUNCH_CHECK("sp_rank_apply");
-  sp_rank_emit_kernel<<<dim3(stride_grid((long long)nw)), dim3(256), 0, stream>>>(words, nw, g, out_indices, out_cap);
-  BEVAMD_LAUNCH_CHECK("sp_rank_emit");
+  sp_rank_apply_emit_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, g, out_indices, out_cap);
+  BEVAMD_LAUNCH_CHECK("sp_rank_apply_emit");
   if (nbr) {
     sp_nbr_clear_kernel<<<dim3(stride_grid(((long long)out_cap + 3) / 4), g.K), dim3(256), 0, stream>>>(nbr, nbr_stride, out_cap, num_out_dev, 0);
     BEVAMD_LAUNCH_CHECK("sp_nbr_clear");

@@ -69,6 +69,7 @@ class Level:
     def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False, status_pool=None, allow_slab=True):
         self.indices = indices
         self.allow_slab = bool(allow_slab)   # False: every layer of this chain of levels stays on the gather kernels
+        self.frames_hint = None     # frames per step as the tilings count them, from the live row count of level 1 (see _frames_hint)
         # device status words of the products built for this chain of levels: slices of ONE zeroed tensor (a separate
         # torch.zeros(1) per product put ten 5-us fill kernels in front of the first convolution); [pool, next free]
         self._status_pool = status_pool
@@ -283,6 +284,7 @@ class Level:
         _capi.check(rc, "spconv_downsample")
         out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream, status_pool=self._status_pool,
                     allow_slab=self.allow_slab)
+        out.frames_hint = self.frames_hint
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
         out.linear_order = True
         if from_outputs:
@@ -365,7 +367,7 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
         torch.cuda.synchronize()          # the rulebook chain (geometry stream) is out of the way: the events bracket the kernel
         rec = dict(cin=cin, cout=cout, K=K, subm=bool(conv.subm),
                    kernel="slab" if slab_variant is not None else "gather+slots" if slots_meta else "gather",
-                   variant=slab_variant if slab_variant is not None else _variant_for(lvl.batch, K, cin, cout),
+                   variant=slab_variant if slab_variant is not None else _variant_for(_frames_equivalent(lvl), K, cin, cout),
                    start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True),
                    n_in=lvl.n_dev, n_out=out_lvl.n_dev, n_in_cap=lvl.n_cap, n_out_cap=out_lvl.n_cap, nbr=nbr)
         rec["start"].record()
@@ -378,11 +380,11 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
         meta = lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, _GATHER_SLOT_ROWS)
         ops.sparse_conv_tiled_slots(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                                     residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
-                                    variant=_variant_for(lvl.batch, K, cin, cout))
+                                    variant=_variant_for(_frames_equivalent(lvl), K, cin, cout))
     else:
         ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
                               residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
-                              variant=_variant_for(lvl.batch, K, cin, cout))
+                              variant=_variant_for(_frames_equivalent(lvl), K, cin, cout))
     if rec is not None:
         rec["end"].record()
         LAYER_PROFILE.append(rec)
@@ -439,6 +441,29 @@ _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and 
 _SLAB_DEFAULT = {32: 4000112, 64: 1644222, 128: 1644220}
 _SLAB_DEFAULT_SMALL_BATCH = {32: 1322410}   # below 4 frames per step
 _SLAB_MIN_BATCH = {128: 4}
+# The same decisions in LIVE ROWS (8 sparse frames are not 8 capped ones).  The tilings were measured on
+# capped flagship frames (160 k voxels each), so "frames" = live level-1 rows / 160 k.  The host does not know the row count on the
+# sync-free path: the encoder's FIRST eager call at a batch size reads it back once (_frames_hint), every later call at that batch
+# size — graph captures included — uses the same figure, so that a replayed graph and its eager warm-up run the same kernels.
+_ROWS_PER_FLAGSHIP_FRAME = 160000
+
+
+def _frames_hint(enc, batch_size, n_rows, num_voxels):
+    """Frames-equivalent of this encoder's inputs at `batch_size`, measured once (one 4-byte read-back outside graph capture)."""
+    hints = enc.__dict__.setdefault("_bevamd_frames_hint", {})
+    if batch_size not in hints:
+        if num_voxels is None:
+            hints[batch_size] = n_rows / float(_ROWS_PER_FLAGSHIP_FRAME)
+        elif torch.cuda.is_current_stream_capturing():
+            return None
+        else:
+            hints[batch_size] = min(int(num_voxels.reshape(-1)[0]), n_rows) / float(_ROWS_PER_FLAGSHIP_FRAME)
+    return hints[batch_size]
+
+
+def _frames_equivalent(lvl):
+    """Frames per step as the tilings understand them: from the live row count when it is known, else the batch size."""
+    return float(lvl.batch) if lvl.frames_hint is None else lvl.frames_hint
 # BEVAMD_SPCONV_SLAB_DIRECT=0: build the slab metadata from the int32 neighbour table instead of straight from the rank index
 _SLAB_DIRECT = os.environ.get("BEVAMD_SPCONV_SLAB_DIRECT", "1") != "0"
 
@@ -496,9 +521,10 @@ def _slab_variant_for(conv, lvl, cin, cout):
         return _narrow_variant_for(conv, lvl, cin, cout)
     if not (conv.subm and cin == cout):
         return None
-    if cin not in _SLAB_DEFAULT or lvl.batch < _SLAB_MIN_BATCH.get(cin, 1):
+    frames = _frames_equivalent(lvl)
+    if cin not in _SLAB_DEFAULT or frames < _SLAB_MIN_BATCH.get(cin, 1) - 0.5:
         return None
-    default = _SLAB_DEFAULT_SMALL_BATCH.get(cin, _SLAB_DEFAULT[cin]) if lvl.batch < 4 else _SLAB_DEFAULT[cin]
+    default = _SLAB_DEFAULT_SMALL_BATCH.get(cin, _SLAB_DEFAULT[cin]) if frames < 3.5 else _SLAB_DEFAULT[cin]
     variant = _slab_overrides().get(cin, default)
     rows = ops.slab_block_rows(cin, variant)
     if rows == 0 or not ops.slab_grid_ok(lvl.shape, rows):
@@ -507,7 +533,8 @@ def _slab_variant_for(conv, lvl, cin, cout):
 
 
 def _variant_for(batch, K, cin, cout):
-    if batch >= 6 and K == 27:   # measured neutral at 4 frames (3.15 vs 3.17 ms per step), +4 % at 8
+    """`batch`: frames per step, or the frames-equivalent of the level's live rows (_frames_equivalent)."""
+    if batch >= 5.5 and K == 27:   # measured neutral at 4 frames (3.15 vs 3.17 ms per step), +4 % at 8
         return _BATCHED_VARIANTS.get((ops.padded_channels(cin), cout), 0)
     return 0
 
@@ -609,6 +636,7 @@ def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None, 
         g.wait_stream(main)
     lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool,
                 allow_slab=allow_slab)
+    lvl.frames_hint = _frames_hint(enc, int(batch_size), n, num_voxels)
     try:
         prefetch_geometry(enc, lvl)
     finally:
@@ -738,6 +766,7 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
         g.wait_stream(main)       # fork: coordinates / count are final, recycled buffers are quiescent
     lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool,
                 allow_slab=allow_slab)
+    lvl.frames_hint = _frames_hint(enc, int(batch_size), n, num_voxels)
     redo = None
     try:
         if g is not None:

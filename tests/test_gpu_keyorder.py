@@ -423,6 +423,38 @@ def test_broken_linear_promise_is_memory_safe_and_the_encoder_falls_back(dev):
     assert torch.equal(got, ref) and torch.equal(prepared, ref)
 
 
+def test_tilings_follow_the_live_row_count_not_the_frame_count(dev):
+    """Eight SPARSE frames (one sweep each: ~1/3 of the capped flagship frame) are tiled like the ~2.5 capped frames they amount to,
+    not like 8: the 32-channel layers take the small-batch kernel, the 128-channel layers stay on the gather
+    kernels; eight capped frames keep the 8-frame kernels.  The first eager call measures the figure once per batch size."""
+    B = 8
+    vs, pr, mp, mv = CFG["voxel_size"], CFG["point_cloud_range"], CFG["max_num_points"], CFG["max_voxels"][1]
+
+    def kinds_of(sweeps):
+        pts = [torch.from_numpy(synth.lidar_points(seed=40 + b, sweeps=sweeps)).to(dev) for b in range(B)]
+        f, c, _, t = voxelize_batch_device(pts, vs, pr, mp, mv, order="key")
+        enc = flagship_encoder(dev)
+        with torch.no_grad():
+            enc(f, c, B, num_voxels=t, coors_order="linear")          # measures the frames-equivalent of this input
+            fused.LAYER_PROFILE = []
+            try:
+                out = enc(f, c, B, num_voxels=t, coors_order="linear")
+                kinds = {(r["cin"], r["cout"], r["subm"]): (r["kernel"], r["variant"]) for r in fused.LAYER_PROFILE}
+            finally:
+                fused.LAYER_PROFILE = None
+            enc.fused_inference = False
+            ref = enc(f[: int(t.item())], c[: int(t.item())], B)
+        assert float((out.float() - ref.float()).abs().max()) <= 2e-2 * (1 + float(ref.abs().max()))
+        return kinds, enc.__dict__["_bevamd_frames_hint"][B]
+
+    sparse, fs = kinds_of(1)
+    dense, fd = kinds_of(10)
+    assert 1.5 < fs < 3.5 and fd == 8.0
+    assert sparse[(32, 32, True)] == ("slab", 1322410) and dense[(32, 32, True)] == ("slab", 4000112)
+    assert sparse[(128, 128, True)][0] == "gather" and dense[(128, 128, True)] == ("slab", 1644220)
+    assert sparse[(64, 64, True)] == dense[(64, 64, True)] == ("slab", 1644222)
+
+
 def test_encoder_key_ordered_path_replays_from_a_graph(dev):
     B = 2
     pts = [torch.from_numpy(synth.lidar_points(seed=90 + b, sweeps=2)).to(dev) for b in range(B)]

@@ -143,7 +143,13 @@ def test_sparse_conv_ext_on_the_reference_cpu_functor_goldens(dev, shims, case):
     bias = torch.linspace(-0.5, 0.5, filt.shape[-1], device=dev)
     outb = ext.fused_indice_conv_fp32(feats, filt, bias, pairs, num, m, 0, subm)
     assert np.max(np.abs(outb.cpu().numpy() - (ref + bias.cpu().numpy()))) <= 2e-5 * (1 + np.abs(ref).max())
-    # backward against the float64 restatement of indiceConvBackward (spconv_ops.h:363-456)
+    # backward against the goldens' OWN in_grad / filter_grad: the reference's indice_conv_backward_fp32 on the fixture's out_grad
+    # (spconv_ops.h:363-456; the golden's output rows permuted into the drop-in's row order — input rows and filter are order-free)
+    go = z["out_grad"][gold_sorted]
+    gi, gw = ext.indice_conv_backward_fp32(feats, filt, T(go, dev), pairs, num, 0, subm)
+    assert np.max(np.abs(gi.cpu().numpy() - z["in_grad"])) <= 2e-5 * (1 + np.abs(z["in_grad"]).max())
+    assert np.max(np.abs(gw.cpu().numpy() - z["filter_grad"])) <= 1e-4 * (1 + np.abs(z["filter_grad"]).max())
+    # ... and on a second, random gradient against the float64 restatement
     rng = np.random.default_rng(3)
     go = rng.standard_normal(ref.shape).astype(np.float32)
     gi, gw = ext.indice_conv_backward_fp32(feats, filt, T(go, dev), pairs, num, 0, subm)
