@@ -406,7 +406,9 @@ def summarize_layer_profile(records, elem_bytes=2):
         ideal = n_in * r["cin"] * elem_bytes + pairs * 8 + r["K"] * r["cin"] * r["cout"] * elem_bytes + n_out * r["cout"] * elem_bytes
         out.append(dict(layer=f"{'subm' if r['subm'] else 'conv'} {r['cin']}->{r['cout']} K={r['K']}", kernel=r["kernel"],
                         variant=r["variant"], rows_in=n_in, rows_out=n_out, pairs=pairs, us=us, gflop=flop / 1e9,
-                        tflops=flop / (us * 1e-6) / 1e12, frac_mfma_peak=flop / (us * 1e-6) / 2.5e15, ideal_mb=ideal / 1e6,
+                        tflops=flop / (us * 1e-6) / 1e12, frac_mfma_peak=flop / (us * 1e-6) / 2.5e15,
+                        # real pairs / issued taps of the dense-tap output-stationary kernels (every row x every kernel offset)
+                        useful_mfma_fraction=pairs / float(max(r["K"] * n_out, 1)), ideal_mb=ideal / 1e6,
                         frac_hbm_peak_on_ideal_bytes=ideal / (us * 1e-6) / 8e12))
     return out
 

@@ -443,7 +443,7 @@ def test_tilings_follow_the_live_row_count_not_the_frame_count(dev):
             finally:
                 fused.LAYER_PROFILE = None
             enc.fused_inference = False
-            ref = enc(f[: int(t.item())], c[: int(t.item())], B)
+            ref = enc(f[: int(t.item())].half(), c[: int(t.item())], B)
         assert float((out.float() - ref.float()).abs().max()) <= 2e-2 * (1 + float(ref.abs().max()))
         return kinds, enc.__dict__["_bevamd_frames_hint"][B]
 
