@@ -341,7 +341,13 @@ __global__ __launch_bounds__(256) void sp_mark_outputs_kernel(const int* __restr
   }
 }
 
-constexpr int RANK_TILE = 2048;  // bitmap words per workgroup in the popcount scan
+constexpr int RANK_TILE = 2048;  // bitmap words per workgroup in the popcount scan (large grids; index buffers are sized for it)
+// Small grids take 256-word tiles: the coarse levels are DENSE (a thread of a 2048-word tile emits up to 256 rows one after the
+// other) and few (20 tiles at level 4 of 8 frames, 22 at level 3 of one frame: 37-55 us on a handful of CUs).
+constexpr int RANK_TILE_SMALL = 256;
+constexpr size_t RANK_SMALL_WORDS = (size_t)1 << 19;   // grids up to this many words (16 M cells) use the small tile
+static int rank_tile_for(size_t nwords) { return nwords <= RANK_SMALL_WORDS ? RANK_TILE_SMALL : RANK_TILE; }
+static size_t rank_tiles(size_t nwords) { const size_t t = (size_t)rank_tile_for(nwords); return (nwords + t - 1) / t; }
 
 __device__ __forceinline__ unsigned block_exclusive_scan_256u(unsigned v, unsigned* lds_wave /*[4]*/, unsigned* total) {
   const unsigned inc = wave_inclusive_scan(v);
@@ -362,13 +368,14 @@ __device__ __forceinline__ unsigned block_exclusive_scan_256u(unsigned v, unsign
 
 // byte map -> bitmap words (+ per-tile popcount sums).  Thread t of a tile folds 32 consecutive cells (two 16-byte
 // loads) into one word; `cellmap` is allocated in whole 32-byte groups (zero filled), so no tail handling.
+template <int TILE>
 __global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint8_t* __restrict__ cellmap, uint2* __restrict__ words,
                                                                 size_t nwords, uint32_t* __restrict__ tile_sums) {
   __shared__ unsigned lds_wave[4];
-  const size_t base = (size_t)blockIdx.x * RANK_TILE;
+  const size_t base = (size_t)blockIdx.x * TILE;
   unsigned s = 0;
 #pragma unroll
-  for (int i = 0; i < RANK_TILE / 256; ++i) {
+  for (int i = 0; i < TILE / 256; ++i) {
     const size_t w = base + (size_t)i * 256 + threadIdx.x;
     if (w < nwords) {
       const uint4 lo = ((const uint4*)cellmap)[2 * w], hi = ((const uint4*)cellmap)[2 * w + 1];
@@ -393,6 +400,7 @@ __global__ __launch_bounds__(256) void sp_rank_tile_sums_kernel(const uint8_t* _
 // tiles before it itself (a few hundred values: no scan launch in between), completes the prefix of its tile's words and — with
 // the bits and the prefixes still in registers — emits the outputs those words hold; the last one publishes the row count,
 // clamped to the capacity.
+template <int TILE>
 __global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restrict__ words, size_t nwords,
                                                                  const uint32_t* __restrict__ tile_sums, int* count, ConvGeom g,
                                                                  int* __restrict__ out_indices, int out_cap) {
@@ -404,8 +412,8 @@ __global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restri
   __syncthreads();
   const unsigned tile_base = lds_wave[0] + lds_wave[1] + lds_wave[2] + lds_wave[3];
   __syncthreads();
-  constexpr int PER = RANK_TILE / 256;
-  const size_t w0 = (size_t)blockIdx.x * RANK_TILE + (size_t)threadIdx.x * PER;
+  constexpr int PER = TILE / 256;
+  const size_t w0 = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * PER;
   uint32_t bits[PER];
   unsigned s = 0;
 #pragma unroll
@@ -415,19 +423,36 @@ __global__ __launch_bounds__(256) void sp_rank_apply_emit_kernel(uint2* __restri
   }
   unsigned tot;
   unsigned run = tile_base + block_exclusive_scan_256u(s, lds_wave, &tot);
+  // Cell -> (b, x, y, z): three exact divisions per non-empty WORD (cell 32 w), then per set bit the carry chain z -> y -> x -> b with
+  // multiply-high by floor(2^32 / d) + 1, exact while numerator * d < 2^32 (numerators stay below d + 32).  The coarse levels are
+  // dense — a thread emits up to 256 rows — and three 32-bit divisions per row (~100 instructions) were 37-55 us of this kernel
+  // on ONE frame.
+  const uint32_t Z = (uint32_t)g.out_shape[2], Y = (uint32_t)g.out_shape[1], X = (uint32_t)g.out_shape[0];
+  const uint32_t mz = 0xFFFFFFFFu / Z + 1u, my = 0xFFFFFFFFu / Y + 1u, mx = 0xFFFFFFFFu / X + 1u;
+  const bool small = Z - 2u < 32766u && Y - 2u < 32766u && X - 2u < 32766u;   // d = 1 has no 32-bit magic
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     if (w0 + i < nwords) words[w0 + i].y = run;
     uint32_t b = bits[i];
+    if (!b) continue;
+    uint32_t k = (uint32_t)((w0 + i) * 32);
+    const uint32_t z0 = k % Z; k /= Z;
+    const uint32_t y0 = k % Y; k /= Y;
+    const uint32_t x0 = k % X; k /= X;
     while (b) {
       const int t = __ffs(b) - 1;
       b &= b - 1;
       if (run < (unsigned)out_cap) {
-        uint32_t k = (uint32_t)((w0 + i) * 32 + t);
-        const int oz = (int)(k % (uint32_t)g.out_shape[2]); k /= (uint32_t)g.out_shape[2];
-        const int oy = (int)(k % (uint32_t)g.out_shape[1]); k /= (uint32_t)g.out_shape[1];
-        const int ox = (int)(k % (uint32_t)g.out_shape[0]); k /= (uint32_t)g.out_shape[0];
-        ((int4*)out_indices)[run] = make_int4((int)k, ox, oy, oz);
+        uint32_t n = z0 + (uint32_t)t;
+        uint32_t q = small ? __umulhi(n, mz) : n / Z;
+        const int oz = (int)(n - q * Z);
+        n = y0 + q;
+        q = small ? __umulhi(n, my) : n / Y;
+        const int oy = (int)(n - q * Y);
+        n = x0 + q;
+        q = small ? __umulhi(n, mx) : n / X;
+        const int ox = (int)(n - q * X);
+        ((int4*)out_indices)[run] = make_int4((int)(k + q), ox, oy, oz);
       }
       ++run;
     }
@@ -624,7 +649,7 @@ static size_t grid_words(int batch, const int* shape) {
 }
 
 static size_t rank_index_bytes(int batch, const int* shape) {
-  const size_t nw = grid_words(batch, shape), nt = (nw + RANK_TILE - 1) / RANK_TILE;
+  const size_t nw = grid_words(batch, shape), nt = rank_tiles(nw);
   return align_up(nw * 8, 256) + align_up((nt + 1) * 4, 256) + align_up(scan_workspace_bytes(nt + 1), 256) +
          align_up(nw * 32, 256) /* byte map */ + 256;
 }
@@ -665,6 +690,9 @@ static IndexRef rank_ref(const void* index) {
   return r;
 }
 
+// (Round 4: capping the rulebook kernels' grids so that they leave wave slots to the convolutions they run beside made the LiDAR
+// branch SLOWER — 2048 workgroups 3.75 ms, 1024: 3.81, 512: 3.89, 256: 4.18 on one box: the convolutions do not wait for slots,
+// and a slower chain lands on the critical path.)
 static unsigned stride_grid(long long n) {  // fixed-size grid for grid-stride kernels
   long long b = (n + 255) / 256;
   return (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);
@@ -679,7 +707,7 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
     set_error("spconv rank index: buffer too small (%zu < %zu)", bytes, need);
     return BEVAMD_ERR_WORKSPACE;
   }
-  const size_t nw = grid_words(g.batch, g.out_shape), nt = (nw + RANK_TILE - 1) / RANK_TILE;
+  const size_t nw = grid_words(g.batch, g.out_shape), nt = rank_tiles(nw);
   const bool general = g.transpose || g.dil[0] != 1 || g.dil[1] != 1 || g.dil[2] != 1;
   Carver cv(out_index, bytes);
   uint2* words = cv.take<uint2>(nw);   // must stay first: the rank index IS this array
@@ -694,11 +722,17 @@ static int downsample(const int* indices, int n_cap, const int* n_dev, const Con
     else sp_mark_outputs_kernel<false><<<dim3(stride_grid(n_cap)), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, cellmap);
     BEVAMD_LAUNCH_CHECK("sp_mark_outputs");
   }
-  sp_rank_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(cellmap, words, nw, tile_sums);
-  BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
   (void)sws;
   (void)sws_bytes;
-  sp_rank_apply_emit_kernel<<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, g, out_indices, out_cap);
+  if (rank_tile_for(nw) == RANK_TILE_SMALL) {
+    sp_rank_tile_sums_kernel<RANK_TILE_SMALL><<<dim3((unsigned)nt), dim3(256), 0, stream>>>(cellmap, words, nw, tile_sums);
+    BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
+    sp_rank_apply_emit_kernel<RANK_TILE_SMALL><<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, g, out_indices, out_cap);
+  } else {
+    sp_rank_tile_sums_kernel<RANK_TILE><<<dim3((unsigned)nt), dim3(256), 0, stream>>>(cellmap, words, nw, tile_sums);
+    BEVAMD_LAUNCH_CHECK("sp_rank_tile_sums");
+    sp_rank_apply_emit_kernel<RANK_TILE><<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, g, out_indices, out_cap);
+  }
   BEVAMD_LAUNCH_CHECK("sp_rank_apply_emit");
   if (nbr) {
     sp_nbr_clear_kernel<<<dim3(stride_grid(((long long)out_cap + 3) / 4), g.K), dim3(256), 0, stream>>>(nbr, nbr_stride, out_cap, num_out_dev, 0);
@@ -792,6 +826,60 @@ __global__ __launch_bounds__(BM) void sp_slab_from_index_kernel(const int* __res
   slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
 }
 
+// The same from a RANK index with all 26 lookups of a row in flight together.  The generic kernel above compiles to one load, one
+// wait and one branch per lookup — bits, then the prefix word behind a second branch: 52 dependent round trips per row, 126 us for
+// the 2 M rows of level 2 at 8 frames.  Here every tap has a valid (clamped) key, the 8-byte words are fetched unconditionally
+// and used behind opaque barriers (hipcc otherwise sinks each load to its use), the range checks only select the result.
+template <int BM>
+__global__ __launch_bounds__(BM) void sp_slab_from_rank_kernel(const int* __restrict__ indices, int m_cap,
+                                                               const int* __restrict__ m_dev, ConvGeom g,
+                                                               const uint2* __restrict__ words, int2* __restrict__ hdr,
+                                                               uint16_t* __restrict__ slots, int* __restrict__ status) {
+  int m = m_dev ? *m_dev : m_cap;
+  if (m > m_cap) m = m_cap;
+  const int nblk = (m + BM - 1) / BM, per = (nblk + 7) >> 3;
+  const int xcd = (int)blockIdx.x & 7, bix = (int)blockIdx.x >> 3;
+  const int blk = (gridDim.x & 7u) == 0 ? xcd * per + bix : (int)blockIdx.x;
+  if (((gridDim.x & 7u) == 0 && bix >= per) || blk >= nblk) return;
+  const int t = threadIdx.x, row = blk * BM + t;
+  const bool live = row < m;
+  int4 c = live ? ((const int4*)indices)[row] : make_int4(0, 0, 0, 0);
+  const int X = g.in_shape[0], Y = g.in_shape[1], Z = g.in_shape[2];
+  // coordinates outside the grid (a caller's broken promise) must not turn into addresses outside the index
+  const bool inside = c.x >= 0 && c.x < g.batch && c.y >= 0 && c.y < X && c.z >= 0 && c.z < Y && c.w >= 0 && c.w < Z;
+  if (!inside) c = make_int4(0, 0, 0, 0);
+  const uint32_t base = (uint32_t)c.x * (uint32_t)X;
+  const uint32_t safe = ((base + (uint32_t)c.y) * (uint32_t)Y + (uint32_t)c.z) * (uint32_t)Z + (uint32_t)c.w;   // the row's own cell
+  uint32_t key[27];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        const int x = c.y - 1 + kx, y = c.z - 1 + ky, z = c.w - 1 + kz, k = (kx * 3 + ky) * 3 + kz;
+        const bool ok = live && inside && x >= 0 && x < X && y >= 0 && y < Y && z >= 0 && z < Z;
+        key[k] = ok ? ((base + (uint32_t)x) * (uint32_t)Y + (uint32_t)y) * (uint32_t)Z + (uint32_t)z : safe;
+        okmask |= ok ? 1u << k : 0u;
+      }
+  uint2 wd[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wd[k] = k == 13 ? make_uint2(0u, 0u) : words[key[k] >> 5];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) asm volatile("" : "+v"(wd[k].x), "+v"(wd[k].y));
+  int v[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const uint32_t b = 1u << (key[k] & 31);
+    int r = (wd[k].x & b) ? (int)(wd[k].y + __popc(wd[k].x & (b - 1u))) : -1;
+    if (r >= m || !((okmask >> k) & 1u)) r = -1;
+    v[k] = r;
+  }
+  v[13] = live ? row : -1;
+  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+}
+
 
 // ---- sorted-key lookups: a voxel set whose rows are in ascending linear index is its own index -----------------------------
 // (the voxelizer's key-order output, every level a strided convolution produced).  keys[i] = linear index of row i;
@@ -852,6 +940,8 @@ __device__ __forceinline__ int sorted_lower_bound(const uint32_t* __restrict__ k
 // x-plane's segment of the directory) and then walks the rows up to the window's last key, four keys per round trip, turning
 // each into its (ky, kz) tap — 3 searches per row instead of one lookup per tap.  Output rows must be in ascending linear
 // index too (what makes a plane's inputs a contiguous range).  SUBM: the centre tap is the row itself.
+// (Round 4: searching the three planes TOGETHER — one lower_bound step of each per round trip, twelve window keys in flight — was
+// slower, 85 / 147 us against 64 / 114: the kernel is bound by instruction issue, not by the latency of its dependent loads.)
 template <int BM, bool SUBM>
 __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __restrict__ out_indices, int m_cap,
                                                                  const int* __restrict__ m_dev, ConvGeom g,
@@ -1173,9 +1263,12 @@ int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;   // a multiple of 8: XCD-contiguous block map
 #define BEVAMD_GO(BM, KIND) \
   sp_slab_from_index_kernel<BM, KIND><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix, (int2*)hdr, (uint16_t*)slots, status)
-  if (block_rows == 64) { if (index_kind == INDEX_HASH) BEVAMD_GO(64, INDEX_HASH); else BEVAMD_GO(64, INDEX_RANK); }
-  else if (block_rows == 128) { if (index_kind == INDEX_HASH) BEVAMD_GO(128, INDEX_HASH); else BEVAMD_GO(128, INDEX_RANK); }
-  else { if (index_kind == INDEX_HASH) BEVAMD_GO(256, INDEX_HASH); else BEVAMD_GO(256, INDEX_RANK); }
+#define BEVAMD_GO_RANK(BM) \
+  sp_slab_from_rank_kernel<BM><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix.words, (int2*)hdr, (uint16_t*)slots, status)
+  if (block_rows == 64) { if (index_kind == INDEX_HASH) BEVAMD_GO(64, INDEX_HASH); else BEVAMD_GO_RANK(64); }
+  else if (block_rows == 128) { if (index_kind == INDEX_HASH) BEVAMD_GO(128, INDEX_HASH); else BEVAMD_GO_RANK(128); }
+  else { if (index_kind == INDEX_HASH) BEVAMD_GO(256, INDEX_HASH); else BEVAMD_GO_RANK(256); }
+#undef BEVAMD_GO_RANK
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("sp_slab_from_index");
   return BEVAMD_OK;

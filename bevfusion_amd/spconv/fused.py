@@ -39,6 +39,8 @@ class NotThisCall(Exception):
     """This particular input is left to the module path (e.g. no voxels at all); the fused path stays enabled."""
 
 
+# How many convolutions ahead of the feature pass the rulebook chain is issued (see _Chain); -1: the whole chain up front.
+_CHAIN_LOOKAHEAD = int(os.environ.get("BEVAMD_SPCONV_CHAIN_LOOKAHEAD", "4"))
 _GEOM_STREAMS = {}
 _PREFETCHING = [False]   # inside prefetch_geometry: products are built behind the fork point, nothing of this pass runs on the main stream yet
 
@@ -70,6 +72,7 @@ class Level:
         self.indices = indices
         self.allow_slab = bool(allow_slab)   # False: every layer of this chain of levels stays on the gather kernels
         self.frames_hint = None     # frames per step as the tilings count them, from the live row count of level 1 (see _frames_hint)
+        self.chain = None           # _Chain issuing the rulebook products a few convolutions ahead of the feature pass
         # device status words of the products built for this chain of levels: slices of ONE zeroed tensor (a separate
         # torch.zeros(1) per product put ten 5-us fill kernels in front of the first convolution); [pool, next free]
         self._status_pool = status_pool
@@ -285,6 +288,7 @@ class Level:
         out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream, status_pool=self._status_pool,
                     allow_slab=self.allow_slab)
         out.frames_hint = self.frames_hint
+        out.chain = self.chain
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
         out.linear_order = True
         if from_outputs:
@@ -350,6 +354,8 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
         raise Unfusable("feature pitch smaller than the padded channel count")
     image, bias, scale, shift = folded(conv, bn, dtype)
     lvl = x.level
+    if lvl.chain is not None:
+        lvl.chain.before(conv)
     slab_variant = _slab_variant_for(conv, lvl, cin, cout)
     # a strided 3x3x3 layer that stays on the gather kernels can still read slot metadata (sorted-key search) instead of a table
     slots_meta = slab_variant is None and _gather_reads_slots(conv, lvl)
@@ -772,7 +778,10 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
     redo = None
     try:
         if g is not None:
-            prefetch_geometry(enc, lvl)
+            if _CHAIN_LOOKAHEAD < 0:
+                prefetch_geometry(enc, lvl)
+            else:
+                lvl.chain = _Chain(enc, lvl, _CHAIN_LOOKAHEAD)
         x = FusedTensor(feats, lvl)
         x = _sequential(enc.conv_input, x)
         x = _sequential(enc.encoder_layers, x)
@@ -799,24 +808,27 @@ def prefetch_geometry(enc, lvl):
     it: hash index, SubM neighbour tables and downsamples of every level.  The feature pass then finds each product in
     its Level's cache and waits on its event only.  A tree whose module order differs from its execution order merely
     builds some tables later, on demand."""
-    from .conv import SparseConvolution
-
     _PREFETCHING[0] = True
     try:
-        _prefetch_geometry(enc, lvl)
+        for _ in _geometry_steps(enc, lvl):
+            pass
     finally:
         _PREFETCHING[0] = False
 
 
-def _prefetch_geometry(enc, lvl):
+def _chain_modules(enc):
+    """The convolutions whose rulebook products the chain builds, in module order."""
     from .conv import SparseConvolution
 
+    return [m for m in enc.modules()
+            if isinstance(m, SparseConvolution) and not (m.conv1x1 or m.transposed or m.inverse or m.ndim != 3)
+            and not any(d != 1 for d in m.dilation)]
+
+
+def _geometry_steps(enc, lvl):
+    """Generator: one step per convolution of `_chain_modules`, issuing (wait=False) whatever that layer reads."""
     cur = lvl
-    for m in enc.modules():
-        if not isinstance(m, SparseConvolution) or m.conv1x1 or m.transposed or m.inverse or m.ndim != 3:
-            continue
-        if any(d != 1 for d in m.dilation):
-            continue
+    for m in _chain_modules(enc):
         v = _slab_variant_for(m, cur, m.in_channels, m.out_channels)
         if m.subm:
             if v is not None:
@@ -832,3 +844,45 @@ def _prefetch_geometry(enc, lvl):
             elif slots_meta:
                 cur.down_slab(m.kernel_size, m.stride, m.padding, _GATHER_SLOT_ROWS, wait=False)
             cur = nxt
+        yield m
+
+
+class _Chain:
+    """The rulebook chain of one encoder pass, issued on the geometry stream `lookahead` convolutions ahead of the feature pass
+    instead of all at once in front of it.  On the GPU nothing changes at 8 frames (the host is far ahead either way); what
+    changes is the order the nodes of a captured graph are CREATED in, and a replayed HIP graph enqueues its nodes in that
+    order: with the whole chain issued first the first convolution of a single-frame step was enqueued behind ~45 rulebook
+    nodes and started 190 us after its inputs were ready (tools/ubench/graph_order.py: a branch created after a 50-node chain
+    starts 380 us late, created right after its fork node 5 us late).
+
+    Products are allocated under the geometry stream (its pool): a buffer of the main stream's pool may be a block a
+    still-running convolution reads (see Level._fork), and once convolutions have been issued the chain can no longer rely on
+    the fork at the top of run_encoder for that.  They stay alive in their Level's caches until the join at the end of the pass."""
+
+    def __init__(self, enc, lvl, lookahead):
+        mods = _chain_modules(enc)
+        self.pos = {id(m): i for i, m in enumerate(mods)}
+        self.steps = _geometry_steps(enc, lvl)
+        self.issued = 0
+        self.total = len(mods)
+        self.lookahead = int(lookahead)
+        self.gstream = lvl.gstream
+        self.advance(self.lookahead)
+
+    def advance(self, upto):
+        """Issue the products of modules [issued, upto]."""
+        if self.issued > upto or self.issued >= self.total:
+            return
+        _PREFETCHING[0] = True
+        try:
+            with torch.cuda.stream(self.gstream):
+                while self.issued <= upto and self.issued < self.total:
+                    next(self.steps)
+                    self.issued += 1
+        finally:
+            _PREFETCHING[0] = False
+
+    def before(self, conv):
+        i = self.pos.get(id(conv))
+        if i is not None:
+            self.advance(i + self.lookahead)
