@@ -114,6 +114,8 @@ _SIGNATURES = {
     # primitives
     "bevamd_scan_workspace_bytes": (Z, [Z]),
     "bevamd_exclusive_scan_u32": (I, [P, P, Z, P, P, Z, P]),
+    "bevamd_scan_single_pass_state_bytes": (Z, [Z]),
+    "bevamd_exclusive_scan_u32_single_pass": (I, [P, P, Z, P, P, Z, P]),
     "bevamd_radix_sort_workspace_bytes": (Z, [Z]),
     "bevamd_radix_sort_pairs_u32": (I, [P, P, P, P, Z, I, P, Z, P]),
     "bevamd_radix_sort_segmented_workspace_bytes": (Z, [P, I]),

@@ -124,12 +124,31 @@ struct SortSegs {
   int nseg;
   uint32_t off[SORT_MAX_SEGS + 1];  // element range of segment s: [off[s], off[s+1])
   uint32_t blk[SORT_MAX_SEGS + 1];  // workgroup range of segment s
+  // one-sweep passes: lane x (= blockIdx.x % lanes) owns the tiles [lane_blk[x], lane_blk[x+1]) — whole segments — and hands
+  // them out in ticket order (see radix_onesweep_seg_kernel); lanes = 8 when there are at least 8 segments, else 1
+  int lanes;
+  uint32_t lane_blk[9];
 };
 int sort_segs_init(SortSegs& sg, const int* counts, int nseg);
 size_t radix_sort_segmented_workspace_bytes(const SortSegs& sg);
+// state_zeroed: the caller's own first kernel has zeroed the words radix_sort_segmented_state() names (the one-sweep passes'
+// digit totals, look-back words and tickets); otherwise the sort zeroes them with a launch of its own.
 int radix_sort_pairs_u32_segmented(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
                                    const SortSegs& sg, int nbits, void* ws, size_t ws_bytes, hipStream_t stream,
-                                   uint32_t** result_keys, uint32_t** result_vals);
+                                   uint32_t** result_keys, uint32_t** result_vals, bool state_zeroed = false);
+// the part of a segmented sort's workspace that must be zero when the sort starts (8-byte words); *words = 0: none (the
+// three-launch passes are in use: BEVAMD_SORT_ONESWEEP=0)
+void radix_sort_segmented_state(const SortSegs& sg, int nbits, void* ws, unsigned long long** state, size_t* words);
+
+// Single-pass exclusive scan (chained tiles with decoupled look-back): ONE launch.  `state` — scan_lookback_state_bytes(n)
+// bytes, 8-byte aligned — must be ZERO when the kernel starts (zeroed by an earlier kernel of the same stream: no launch for it)
+// and is left dirty.  in == out allowed.
+size_t scan_lookback_state_bytes(size_t n);
+int exclusive_scan_u32_lookback(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* state, int* err,
+                                hipStream_t stream);
+bool single_pass_enabled();   // BEVAMD_SINGLE_PASS != "0"
+constexpr size_t SINGLE_PASS_AUTO_MAX = 1000000;   // elements up to which the single-pass kernels are the default
+bool single_pass_for(size_t n);
 // fill / copy of 32-bit words as ordinary kernels (captured as kernel nodes in HIP graphs)
 int device_fill_u32(uint32_t* p, size_t n, uint32_t v, hipStream_t stream);
 int device_copy_u32(uint32_t* d, const uint32_t* s, size_t n, hipStream_t stream);

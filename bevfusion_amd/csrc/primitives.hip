@@ -3,6 +3,7 @@
 // for wave64 (ballot-based match inside a wave, LDS counters across the 4 waves
 // of a 256-thread workgroup).  Integer-only, HBM/L2-bound; no MFMA here.
 #include "common.h"
+#include "single_pass.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -176,6 +177,45 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* to
     scan_tile_apply_kernel<false><<<(unsigned)ntiles, SCAN_THREADS, 0, stream>>>(in, out, tile_sums, n, nullptr);
   }
   BEVAMD_LAUNCH_CHECK("scan_tile_apply");
+  return BEVAMD_OK;
+}
+
+bool single_pass_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("BEVAMD_SINGLE_PASS");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
+// BEVAMD_SINGLE_PASS: "1" always, "0" never, unset / "auto": by size.  With every tile of a launch resident at once a tile
+// walks back over all its predecessors, so the single-pass kernels lose against the multi-launch ones once there are many tiles:
+// 8 sweeps (2.5 M points) 375 us against 320 us for the whole voxelizer; one sweep: 124 against 145 us and 9 launches
+// instead of 22.
+bool single_pass_for(size_t n) {
+  static int mode = -1;   // 0 never, 1 always, 2 auto
+  if (mode < 0) {
+    const char* e = getenv("BEVAMD_SINGLE_PASS");
+    mode = !e || e[0] == 'a' ? 2 : e[0] == '0' ? 0 : 1;
+  }
+  return mode == 1 || (mode == 2 && n <= SINGLE_PASS_AUTO_MAX);
+}
+
+size_t scan_lookback_state_bytes(size_t n) { return align_up(sp::scan_state_words(n) * 8, 256); }
+
+int exclusive_scan_u32_lookback(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* state, int* err,
+                                hipStream_t stream) {
+  if (n == 0) {
+    if (total) return device_fill_u32(total, 1, 0u, stream);
+    return BEVAMD_OK;
+  }
+  if (!state || ((uintptr_t)state & 7u)) {
+    set_error("exclusive_scan_u32_lookback: state is null or not 8-byte aligned");
+    return BEVAMD_ERR_INVALID_ARG;
+  }
+  sp::scan_lookback_launch(sp::LoadU32{in}, out, n, total, (unsigned long long*)state, err, stream);
+  BEVAMD_LAUNCH_CHECK("scan_lookback");
   return BEVAMD_OK;
 }
 
@@ -446,6 +486,168 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_seg_kernel(
   radix_scatter_tile(keys_in, vals_in, keys_out, vals_out, t.base, t.end, shift, bits, t.sd, hist_scanned + t.hcol);
 }
 
+// ---- one-sweep passes of the segmented sort ------------------------------------------------------------------------------
+// Three launches per pass (tile histograms, their scan in two launches... four with it, a scatter that ranks the tile AGAIN) become
+// one: the scatter kernel has its tile's digit counts the moment it has ranked the tile; what it lacks is the sum of the
+// counts of the tiles BEFORE it in its segment — obtained by look-back over the words those tiles publish (single_pass.h) — and
+// the digit totals of the whole segment, which depend only on the keys, not on their order, and are therefore counted for ALL
+// passes in one read of the unsorted keys (radix_digit_totals_seg_kernel).  A 3-pass sort: 12 launches -> 4.
+//
+// Tile order: tiles are handed out by ticket.  With >= 8 segments the tiles are split into 8 LANES of whole segments
+// (SortSegs::lane_blk), lane x = blockIdx.x % 8 = the XCD the workgroup runs on, each with its own ticket counter: a
+// segment's keys, values and buckets stay in one L2 like with the three-launch passes, chains never cross a lane (a chain
+// ends at its segment's first tile), and inside a lane ticket order = tile order.  Fewer segments: one lane, tile = ticket.
+constexpr int OS_MAX_PASSES = 4;
+constexpr int OS_TOTALS_TILES = 8;   // tiles per workgroup of the digit-totals kernel
+constexpr unsigned OS_M31 = 0x7FFFFFFFu;
+struct OneSweepPlan { int npass; int shift[OS_MAX_PASSES]; int bits[OS_MAX_PASSES]; };
+
+__global__ __launch_bounds__(RS_THREADS) void radix_digit_totals_seg_kernel(const uint32_t* __restrict__ keys, SortSegs sg,
+                                                                            OneSweepPlan pl, uint32_t* __restrict__ ghist) {
+  __shared__ unsigned lh[OS_MAX_PASSES][RS_MAX_BINS];
+  // workgroup -> (segment, group of OS_TOTALS_TILES tiles), XCD-contiguous like seg_tile
+  const unsigned grp = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  int s = 0;
+  unsigned first = 0;   // first group of segment s
+  bool live = false;
+  for (int q = 0; q < sg.nseg; ++q) {
+    const unsigned ng = (sg.blk[q + 1] - sg.blk[q] + OS_TOTALS_TILES - 1) / OS_TOTALS_TILES;
+    if (grp >= first && grp < first + ng) { s = q; live = true; break; }
+    first += ng;
+  }
+  if (!live) return;
+  for (unsigned i = threadIdx.x; i < (unsigned)pl.npass * RS_MAX_BINS; i += RS_THREADS) (&lh[0][0])[i] = 0;
+  __syncthreads();
+  const size_t base = (size_t)sg.off[s] + (size_t)(grp - first) * (OS_TOTALS_TILES * RS_TILE);
+  const size_t end = sg.off[s + 1];
+#pragma unroll 4
+  for (int i = 0; i < OS_TOTALS_TILES * RS_TILE / RS_THREADS; ++i) {
+    const size_t idx = base + (size_t)i * RS_THREADS + threadIdx.x;
+    if (idx < end) {
+      const uint32_t k = keys[idx];
+      for (int p = 0; p < pl.npass; ++p) atomicAdd(&lh[p][(k >> pl.shift[p]) & ((1u << pl.bits[p]) - 1u)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < pl.npass; ++p)
+    for (unsigned d = threadIdx.x; d < (1u << pl.bits[p]); d += RS_THREADS) {
+      const unsigned c = lh[p][d];
+      if (c) atomicAdd(&ghist[((size_t)p * sg.nseg + s) * RS_MAX_BINS + d], c);
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_onesweep_seg_kernel(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    uint32_t* __restrict__ vals_out, SortSegs sg, int shift, int bits, const uint32_t* __restrict__ totals /*[nseg][512]*/,
+    unsigned long long* __restrict__ status /*[tiles][256]*/, unsigned* __restrict__ tickets /*[8]*/, int* err) {
+  __shared__ unsigned cnt[4][RS_MAX_BINS];
+  __shared__ unsigned lds_wave[4];
+  __shared__ unsigned s_ticket;
+  const unsigned lx = sg.lanes == 8 ? (blockIdx.x & 7u) : 0u;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&tickets[lx], 1u);
+  for (unsigned i = threadIdx.x; i < 4 * RS_MAX_BINS; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const unsigned tile = sg.lane_blk[lx] + s_ticket;
+  if (tile >= sg.lane_blk[lx + 1]) return;
+  int s = 0;
+  while (s + 1 < sg.nseg && tile >= sg.blk[s + 1]) ++s;
+  const unsigned lb = tile - sg.blk[s];
+  const size_t tile_base = (size_t)sg.off[s] + (size_t)lb * RS_TILE, n = sg.off[s + 1];
+
+  const unsigned nbins = 1u << bits, mask = nbins - 1u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t wbase = tile_base + (size_t)wave * RS_WAVE_CHUNK;
+  uint32_t k[RS_ROUNDS], v[RS_ROUNDS];
+  unsigned short rnk[RS_ROUNDS];
+  const unsigned long long lt = lanemask_lt();
+  volatile unsigned* wc = cnt[wave];
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const size_t idx = wbase + (size_t)r * 64 + lane;
+    const bool valid = idx < n;
+    k[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+    v[r] = valid ? vals_in[idx] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {   // rank inside the wave's chunk (see radix_scatter_tile)
+    const size_t idx = wbase + (size_t)r * 64 + lane;
+    const bool valid = idx < n;
+    const unsigned d = (k[r] >> shift) & mask;
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const unsigned before = __popcll(peers & lt);
+    const unsigned old = valid ? wc[d] : 0u;
+    if (valid && before == 0) wc[d] = old + (unsigned)__popcll(peers);
+    rnk[r] = (unsigned short)(old + before);
+  }
+  __syncthreads();
+  // thread t owns digits 2t and 2t + 1: their counts in this tile, the digit totals of the segment (-> first bucket position
+  // of each digit by a scan across the workgroup) and the counts of the tiles before this one (look-back)
+  const unsigned d0 = 2u * threadIdx.x, d1 = d0 + 1u;
+  const bool mine = d0 < nbins;
+  unsigned c0 = 0, c1 = 0, w0c = 0, w1c = 0, w2c = 0, x0c = 0, x1c = 0, x2c = 0, g0 = 0, g1 = 0;
+  if (mine) {
+    w0c = cnt[0][d0]; w1c = cnt[1][d0]; w2c = cnt[2][d0];
+    c0 = w0c + w1c + w2c + cnt[3][d0];
+    x0c = cnt[0][d1]; x1c = cnt[1][d1]; x2c = cnt[2][d1];
+    c1 = x0c + x1c + x2c + cnt[3][d1];
+    g0 = totals[(size_t)s * RS_MAX_BINS + d0];
+    g1 = totals[(size_t)s * RS_MAX_BINS + d1];
+  }
+  unsigned e0 = 0, e1 = 0;
+  if (mine) {
+    unsigned long long* my = status + (size_t)tile * (RS_MAX_BINS / 2) + threadIdx.x;
+    if (lb == 0) {
+      sp::store_word(my, sp::INC | ((unsigned long long)c1 << 31) | c0);
+    } else {
+      sp::store_word(my, sp::AGG | ((unsigned long long)c1 << 31) | c0);
+      // walk back over the words of this digit pair, one tile per round trip (eight per round trip — the loads do not depend
+      // on each other, only where the walk stops does — was slower: 64 / 71 / 58 us per pass against 59 / 61 / 52)
+      const unsigned long long* q = my - (RS_MAX_BINS / 2);
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned long long w = sp::load_word(q);
+        const unsigned flag = (unsigned)(w >> 62);
+        if (flag == 0u) {
+          if (++spins > sp::SPIN_LIMIT) {
+            if (err) atomicOr(err, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        e0 += (unsigned)w & OS_M31;
+        e1 += (unsigned)(w >> 31) & OS_M31;
+        if (flag == 2u) break;
+        q -= RS_MAX_BINS / 2;      // an aggregate: the chain continues (it ends at the segment's first tile, which is inclusive)
+        spins = 0;
+      }
+      sp::store_word(my, sp::INC | ((unsigned long long)(e1 + c1) << 31) | (unsigned long long)(e0 + c0));
+    }
+  }
+  unsigned tot;
+  const unsigned dbase = block_exclusive_scan_256(g0 + g1, lds_wave, &tot);   // (has the barriers the cnt rewrite needs)
+  if (mine) {
+    const unsigned b0 = sg.off[s] + dbase + e0, b1 = sg.off[s] + dbase + g0 + e1;
+    cnt[0][d0] = b0; cnt[1][d0] = b0 + w0c; cnt[2][d0] = b0 + w0c + w1c; cnt[3][d0] = b0 + w0c + w1c + w2c;
+    cnt[0][d1] = b1; cnt[1][d1] = b1 + x0c; cnt[2][d1] = b1 + x0c + x1c; cnt[3][d1] = b1 + x0c + x1c + x2c;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const size_t idx = wbase + (size_t)r * 64 + lane;
+    if (idx < n) {
+      const unsigned d = (k[r] >> shift) & mask;
+      const unsigned dst = cnt[wave][d] + rnk[r];
+      keys_out[dst] = k[r];
+      vals_out[dst] = v[r];
+    }
+  }
+}
+
 size_t radix_sort_workspace_bytes(size_t n) {
   size_t nblocks = (n + RS_TILE - 1) / RS_TILE;
   if (nblocks == 0) nblocks = 1;
@@ -567,28 +769,137 @@ int sort_segs_init(SortSegs& sg, const int* counts, int nseg) {
     sg.off[s + 1] = (uint32_t)tot;
     sg.blk[s + 1] = sg.blk[s] + (uint32_t)(((size_t)counts[s] + RS_TILE - 1) / RS_TILE);
   }
+  // lanes of the one-sweep passes: 8 contiguous groups of whole segments, balanced by tiles (each boundary at the segment end
+  // nearest to its share); fewer than 8 segments: one lane
+  const uint32_t nt = sg.blk[nseg];
+  sg.lanes = nseg >= 8 ? 8 : 1;
+  for (int x = 0; x <= 8; ++x) sg.lane_blk[x] = nt;
+  sg.lane_blk[0] = 0;
+  if (sg.lanes == 8) {
+    int q = 0;
+    for (int x = 1; x < 8; ++x) {
+      const uint32_t want = (uint32_t)(((unsigned long long)nt * x) / 8);
+      while (q < nseg && sg.blk[q + 1] <= want) ++q;
+      // boundary at blk[q] or blk[q + 1], whichever is nearer to `want`
+      uint32_t cut = sg.blk[q];
+      if (q < nseg && sg.blk[q + 1] - want < want - sg.blk[q]) cut = sg.blk[q + 1];
+      if (cut < sg.lane_blk[x - 1]) cut = sg.lane_blk[x - 1];
+      sg.lane_blk[x] = cut;
+    }
+  }
   return BEVAMD_OK;
 }
 
-size_t radix_sort_segmented_workspace_bytes(const SortSegs& sg) {
+static bool onesweep_fits(const SortSegs& sg) {   // 31-bit counts in the look-back words; BEVAMD_SORT_ONESWEEP=0 / the size rule
+  static int env = -1;
+  if (env < 0) {
+    const char* e = getenv("BEVAMD_SORT_ONESWEEP");
+    env = (e && e[0] == '0') ? 0 : 1;
+  }
+  for (int s = 0; s < sg.nseg; ++s)
+    if (sg.off[s + 1] - sg.off[s] >= (1u << 31)) return false;
+  return env == 1 && single_pass_for(sg.off[sg.nseg]);
+}
+static size_t legacy_sort_bytes(const SortSegs& sg) {
   size_t nblocks = sg.blk[sg.nseg] ? sg.blk[sg.nseg] : 1;
   size_t hist = align_up(nblocks * RS_MAX_BINS * sizeof(uint32_t), 256);
   return hist + scan_workspace_bytes(nblocks * RS_MAX_BINS);
 }
+// one-sweep state behind the three-launch workspace: [tickets u32[OS_MAX_PASSES][8], err at u32[32]: 256 B]
+// [digit totals u32[OS_MAX_PASSES][nseg][512]] [look-back words u64[passes][tiles][256]]
+static size_t onesweep_totals_bytes(const SortSegs& sg) { return align_up((size_t)OS_MAX_PASSES * sg.nseg * RS_MAX_BINS * 4, 256); }
+static size_t onesweep_status_bytes(const SortSegs& sg) { return (size_t)(sg.blk[sg.nseg] ? sg.blk[sg.nseg] : 1) * (RS_MAX_BINS / 2) * 8; }
+static int sort_passes(int nbits, int* bits_per_pass) {
+  if (nbits < 1) nbits = 1;
+  if (nbits > 32) nbits = 32;
+  const int npass = (nbits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  *bits_per_pass = (nbits + npass - 1) / npass;
+  return npass;
+}
+
+void radix_sort_segmented_state(const SortSegs& sg, int nbits, void* ws, unsigned long long** state, size_t* words) {
+  *state = nullptr;
+  *words = 0;
+  if (!ws || !onesweep_fits(sg) || sg.blk[sg.nseg] == 0) return;
+  int bpp;
+  const int npass = sort_passes(nbits, &bpp);
+  *state = (unsigned long long*)((char*)ws + legacy_sort_bytes(sg));
+  *words = (256 + onesweep_totals_bytes(sg) + (size_t)npass * onesweep_status_bytes(sg)) / 8;
+}
+
+size_t radix_sort_segmented_workspace_bytes(const SortSegs& sg) {
+  return legacy_sort_bytes(sg) + 256 + onesweep_totals_bytes(sg) + (size_t)OS_MAX_PASSES * onesweep_status_bytes(sg);
+}
+
+static int radix_sort_segmented_onesweep(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
+                                         const SortSegs& sg, int nbits, void* ws, hipStream_t stream,
+                                         uint32_t** result_keys, uint32_t** result_vals, bool state_zeroed) {
+  unsigned long long* state;
+  size_t words;
+  radix_sort_segmented_state(sg, nbits, ws, &state, &words);
+  if (!state_zeroed) {
+    int rc = device_fill_u32((uint32_t*)state, words * 2, 0u, stream);
+    if (rc) return rc;
+  }
+  unsigned* tickets = (unsigned*)state;
+  int* err = (int*)state + 32;
+  uint32_t* totals = (uint32_t*)((char*)state + 256);
+  unsigned long long* status = (unsigned long long*)((char*)totals + onesweep_totals_bytes(sg));
+  OneSweepPlan pl;
+  int bpp;
+  pl.npass = sort_passes(nbits, &bpp);
+  if (nbits < 1) nbits = 1;
+  if (nbits > 32) nbits = 32;
+  int shift = 0;
+  for (int p = 0; p < pl.npass; ++p) {
+    int bits = bpp;
+    if (shift + bits > nbits) bits = nbits - shift;
+    if (bits <= 0) bits = 1;
+    pl.shift[p] = shift;
+    pl.bits[p] = bits;
+    shift += bits;
+  }
+  unsigned groups = 0;
+  for (int s = 0; s < sg.nseg; ++s) groups += (sg.blk[s + 1] - sg.blk[s] + OS_TOTALS_TILES - 1) / OS_TOTALS_TILES;
+  radix_digit_totals_seg_kernel<<<(groups + 7) / 8 * 8, RS_THREADS, 0, stream>>>(keys_a, sg, pl, totals);
+  BEVAMD_LAUNCH_CHECK("radix_digit_totals_seg");
+  unsigned grid = sg.blk[sg.nseg];
+  if (sg.lanes == 8) {
+    unsigned most = 0;
+    for (int x = 0; x < 8; ++x) most = sg.lane_blk[x + 1] - sg.lane_blk[x] > most ? sg.lane_blk[x + 1] - sg.lane_blk[x] : most;
+    grid = most * 8;
+  }
+  uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
+  for (int p = 0; p < pl.npass; ++p) {
+    radix_onesweep_seg_kernel<<<grid, RS_THREADS, 0, stream>>>(
+        ki, vi, ko, vo, sg, pl.shift[p], pl.bits[p], totals + (size_t)p * sg.nseg * RS_MAX_BINS,
+        (unsigned long long*)((char*)status + (size_t)p * onesweep_status_bytes(sg)), tickets + 8 * p, err);
+    BEVAMD_LAUNCH_CHECK("radix_onesweep_seg");
+    uint32_t* t;
+    t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+  }
+  *result_keys = ki;
+  *result_vals = vi;
+  return BEVAMD_OK;
+}
 
 int radix_sort_pairs_u32_segmented(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
                                    const SortSegs& sg, int nbits, void* ws, size_t ws_bytes, hipStream_t stream,
-                                   uint32_t** result_keys, uint32_t** result_vals) {
+                                   uint32_t** result_keys, uint32_t** result_vals, bool state_zeroed) {
   *result_keys = keys_a;
   *result_vals = vals_a;
   const unsigned nblocks = sg.blk[sg.nseg];
   if (nblocks == 0) return BEVAMD_OK;
-  if (nbits < 1) nbits = 1;
-  if (nbits > 32) nbits = 32;
   if (ws == nullptr || ws_bytes < radix_sort_segmented_workspace_bytes(sg)) {
     set_error("radix_sort_pairs_u32_segmented: workspace too small");
     return BEVAMD_ERR_WORKSPACE;
   }
+  if (onesweep_fits(sg))
+    return radix_sort_segmented_onesweep(keys_a, vals_a, keys_b, vals_b, sg, nbits, ws, stream, result_keys, result_vals,
+                                         state_zeroed);
+  if (nbits < 1) nbits = 1;
+  if (nbits > 32) nbits = 32;
   uint32_t* hist = (uint32_t*)ws;
   size_t hist_bytes = align_up((size_t)nblocks * RS_MAX_BINS * sizeof(uint32_t), 256);
   void* scan_ws = (char*)ws + hist_bytes;
@@ -627,6 +938,20 @@ size_t bevamd_scan_workspace_bytes(size_t n) { return bevamd::scan_workspace_byt
 int bevamd_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* ws,
                               size_t ws_bytes, void* stream) {
   return bevamd::exclusive_scan_u32(in, out, n, total, ws, ws_bytes, (hipStream_t)stream);
+}
+size_t bevamd_scan_single_pass_state_bytes(size_t n) { return bevamd::scan_lookback_state_bytes(n); }
+int bevamd_exclusive_scan_u32_single_pass(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* state,
+                                          size_t state_bytes, void* stream) {
+  if (n && (!state || state_bytes < bevamd::scan_lookback_state_bytes(n))) {
+    bevamd::set_error("exclusive_scan_u32_single_pass: state too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  // (a caller inside the library has its previous kernel zero the state; this entry spends a launch on it)
+  if (n) {
+    int rc = bevamd::device_fill_u32((uint32_t*)state, bevamd::scan_lookback_state_bytes(n) / 4, 0u, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return bevamd::exclusive_scan_u32_lookback(in, out, n, total, state, nullptr, (hipStream_t)stream);
 }
 size_t bevamd_radix_sort_workspace_bytes(size_t n) { return bevamd::radix_sort_workspace_bytes(n); }
 int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,

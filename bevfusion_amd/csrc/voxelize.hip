@@ -22,6 +22,7 @@
 //   one pass writes voxels / coors / num_points (unused slots written as zeros, so the output
 //   buffers need no pre-zeroing; the reference's Python side zero-fills 32 MB per call).
 #include "common.h"
+#include "single_pass.h"
 
 namespace bevamd {
 
@@ -329,9 +330,18 @@ __device__ __forceinline__ VoxRow vox_locate(const VoxBatch& vb) {
 }
 static unsigned vox_rows_grid(size_t total) { return (unsigned)(((total + 255) / 256 + 7) / 8 * 8); }
 
+// zero_a / zero_b: the state words of the single-pass kernels that follow (sort passes, scans) — they must be zero when those
+// kernels start, and this launch has threads to spare
 __global__ __launch_bounds__(256) void vox_key_batch_kernel(VoxBatch vb, int nfeat, VoxGrid g, uint32_t ncells,
                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                            uint32_t* __restrict__ first) {
+                                                            uint32_t* __restrict__ first, unsigned long long* __restrict__ zero_a,
+                                                            size_t words_a, unsigned long long* __restrict__ zero_b,
+                                                            size_t words_b) {
+  {
+    const size_t nthreads = (size_t)gridDim.x * 256, me = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = me; i < words_a; i += nthreads) zero_a[i] = 0ull;
+    for (size_t i = me; i < words_b; i += nthreads) zero_b[i] = 0ull;
+  }
   const VoxRow r = vox_locate(vb);
   if (!r.in) return;
   int cx, cy, cz;
@@ -390,6 +400,27 @@ __global__ __launch_bounds__(256) void vox_survivors_batch_kernel(VoxBatch vb, c
   surv[r.J] = s;
 }
 
+// The same flags computed inside the single-pass scan that consumes them (sp::scan_lookback_kernel<SurvLoad>): element J of the
+// concatenated sorted arrays.
+struct SurvLoad {
+  VoxBatch vb;
+  const uint32_t* keys;
+  const uint32_t* idx;
+  const uint32_t* first_scan;
+  uint32_t ncells;
+  int max_voxels;
+  __device__ __forceinline__ uint32_t operator()(size_t J) const {   // branch-free: the scan keeps 32 of these in flight per thread
+    uint32_t lo = 0;
+    for (int q = 1; q < vb.batch; ++q)
+      if (J >= vb.off[q]) lo = vb.off[q];
+    const uint32_t k = keys[J];
+    const uint32_t kp = keys[J > lo ? J - 1 : J];
+    const uint32_t fs = first_scan[lo + idx[J]], f0 = first_scan[lo];
+    const bool head = k < ncells && (J == lo || kp != k);
+    return head && fs - f0 < (uint32_t)max_voxels ? 1u : 0u;
+  }
+};
+
 // One thread per sorted row; the first row of every run of equal keys (the voxel's earliest point: the sort is stable) sums
 // the run.  The run length comes from the wave's ballot of run boundaries (no dependent walk over the keys), the point indices
 // of the run and then the points themselves are fetched as batches of independent, PREDICATED loads (a lane only requests the
@@ -407,9 +438,28 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
     const uint32_t* __restrict__ first_scan, const uint32_t* __restrict__ surv_scan /*null: first-appearance rows*/,
     const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
     int max_points, int max_voxels, float* __restrict__ feats, int* __restrict__ coords4,
-    int* __restrict__ num_points_per_voxel, uint16_t* __restrict__ rows16, int rows16_dtype, int rows16_pitch) {
+    int* __restrict__ num_points_per_voxel, uint16_t* __restrict__ rows16, int rows16_dtype, int rows16_pitch,
+    const uint32_t* __restrict__ first_total, int packed, int* __restrict__ counts, int* __restrict__ total) {
   const VoxRow vr = vox_locate(vb);
   const int b = vr.b;
+  // rowbase == null: what vox_counts_batch_kernel computes, here — every thread the first output row of ITS sweep (uniform
+  // loads), the first thread of the grid the counts and the total (one launch less in front of this kernel)
+  uint32_t my_rowbase = 0;
+  if (rowbase) {
+    my_rowbase = rowbase[b];
+  } else {
+    const uint32_t ntot = vb.off[vb.batch];
+    uint32_t run = 0;
+    for (int q = 0; q < vb.batch; ++q) {
+      const uint32_t lo = vb.off[q] < ntot ? first_scan[vb.off[q]] : *first_total;
+      const uint32_t hi = vb.off[q + 1] < ntot ? first_scan[vb.off[q + 1]] : *first_total;
+      const uint32_t c = hi - lo < (uint32_t)max_voxels ? hi - lo : (uint32_t)max_voxels;
+      if (q == b) my_rowbase = packed ? run : (uint32_t)q * (uint32_t)max_voxels;
+      if (blockIdx.x == 0 && threadIdx.x == 0) counts[q] = (int)c;
+      run += c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && total) *total = (int)run;
+  }
   const uint32_t n = vr.n, j = vr.j;
   const bool in = vr.in;
   const uint32_t J = in ? vr.J : 0u;
@@ -433,7 +483,7 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
   const uint32_t i0 = idx[J];
   const uint32_t vid = first_scan[vr.lo + i0] - first_scan[vr.lo];
   if (vid >= (uint32_t)max_voxels) return;
-  const size_t row = (size_t)rowbase[b] + (surv_scan ? surv_scan[J] - surv_scan[vr.lo] : vid);
+  const size_t row = (size_t)my_rowbase + (surv_scan ? surv_scan[J] - surv_scan[vr.lo] : vid);
   const float* __restrict__ points = vr.pts;
   const int cnt = (int)(len < (uint32_t)max_points ? len : (uint32_t)max_points);
   const float fc = (float)cnt;
@@ -507,8 +557,8 @@ static size_t voxelize_batch_ws_bytes(const SortSegs& sg) {
   const size_t n = sg.off[sg.nseg] ? sg.off[sg.nseg] : 1;
   size_t a = align_up(n * sizeof(uint32_t), 256);
   size_t s1 = radix_sort_segmented_workspace_bytes(sg), s2 = scan_workspace_bytes(n);
-  // keys_a, vals_a, keys_b, vals_b, first (scanned in place), rowbase + total
-  return 5 * a + 2 * 256 + align_up(s1 > s2 ? s1 : s2, 256);
+  // keys_a, vals_a, keys_b, vals_b, first (scanned in place), rowbase + total, the states of the two single-pass scans
+  return 5 * a + 2 * 256 + 2 * scan_lookback_state_bytes(n) + align_up(s1 > s2 ? s1 : s2, 256);
 }
 
 }  // namespace bevamd
@@ -688,25 +738,49 @@ int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num
   uint32_t* first = cv.take<uint32_t>(n);
   uint32_t* rowbase = cv.take<uint32_t>(VOX_MAX_BATCH);
   uint32_t* first_total = cv.take<uint32_t>(1);
+  unsigned long long* scan_state = (unsigned long long*)cv.take<char>(2 * scan_lookback_state_bytes(n));
+  const size_t scan_state_words = 2 * scan_lookback_state_bytes(n) / 8;
   void* sws = cv.base + cv.off;
   const size_t sws_bytes = ws_bytes - cv.off;
+  const int nbits = bits_for((uint64_t)ncells + 1);
+  const bool single = single_pass_for(n);
+  // single-pass kernels (one-sweep sort passes, look-back scans; BEVAMD_SINGLE_PASS=0: the multi-launch ones): 22 -> 9 launches.
+  // Their state words are zeroed by the key kernel.
+  unsigned long long* sort_state = nullptr;
+  size_t sort_words = 0;
+  if (single) radix_sort_segmented_state(sg, nbits, sws, &sort_state, &sort_words);
 
   const dim3 grid(vox_rows_grid(n)), block(256);
-  vox_key_batch_kernel<<<grid, block, 0, stream>>>(vbt, num_features, g, ncells, keys_a, vals_a, first);
+  vox_key_batch_kernel<<<grid, block, 0, stream>>>(vbt, num_features, g, ncells, keys_a, vals_a, first, sort_state, sort_words,
+                                                   scan_state, single ? scan_state_words : 0);
   BEVAMD_LAUNCH_CHECK("vox_key_batch");
   uint32_t *keys_s, *idx_s;
-  rc = radix_sort_pairs_u32_segmented(keys_a, vals_a, keys_b, vals_b, sg, bits_for((uint64_t)ncells + 1), sws, sws_bytes,
-                                      stream, &keys_s, &idx_s);
+  rc = radix_sort_pairs_u32_segmented(keys_a, vals_a, keys_b, vals_b, sg, nbits, sws, sws_bytes, stream, &keys_s, &idx_s,
+                                      /*state_zeroed=*/sort_words != 0);
   if (rc) return rc;
   vox_heads_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, ncells, first);
   BEVAMD_LAUNCH_CHECK("vox_heads_batch");
+  uint32_t* surv = order == 1 ? (keys_s == keys_a ? keys_b : keys_a) : nullptr;   // the sort's other key buffer is free from here on
+  if (single) {
+    unsigned long long* state_b = scan_state + scan_state_words / 2;
+    rc = exclusive_scan_u32_lookback(first, first, n, first_total, scan_state, nullptr, stream);
+    if (rc) return rc;
+    if (order == 1) {
+      sp::scan_lookback_launch(SurvLoad{vbt, keys_s, idx_s, first, ncells, max_voxels}, surv, n, nullptr, state_b, nullptr, stream);
+      BEVAMD_LAUNCH_CHECK("vox_survivors_scan");
+    }
+    vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, surv, nullptr, num_features, g, ncells,
+                                                      max_points, max_voxels, feats, coords4, num_points_per_voxel,
+                                                      (uint16_t*)rows16, rows16_dtype, rows16_pitch, first_total, packed,
+                                                      counts_dev, total_dev);
+    BEVAMD_LAUNCH_CHECK("vox_mean_batch");
+    return BEVAMD_OK;
+  }
   rc = exclusive_scan_u32(first, first, n, first_total, sws, sws_bytes, stream);
   if (rc) return rc;
   vox_counts_batch_kernel<<<1, 64, 0, stream>>>(vbt, first, first_total, max_voxels, packed, counts_dev, rowbase, total_dev);
   BEVAMD_LAUNCH_CHECK("vox_counts_batch");
-  uint32_t* surv = nullptr;
   if (order == 1) {
-    surv = keys_s == keys_a ? keys_b : keys_a;   // the sort's other key buffer is free from here on
     vox_survivors_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, ncells, max_voxels, surv);
     BEVAMD_LAUNCH_CHECK("vox_survivors_batch");
     rc = exclusive_scan_u32(surv, surv, n, nullptr, sws, sws_bytes, stream);
@@ -714,7 +788,8 @@ int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num
   }
   vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, surv, rowbase, num_features, g, ncells,
                                                     max_points, max_voxels, feats, coords4, num_points_per_voxel,
-                                                    (uint16_t*)rows16, rows16_dtype, rows16_pitch);
+                                                    (uint16_t*)rows16, rows16_dtype, rows16_pitch, first_total, packed,
+                                                    counts_dev, total_dev);
   BEVAMD_LAUNCH_CHECK("vox_mean_batch");
   return BEVAMD_OK;
 }

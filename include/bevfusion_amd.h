@@ -554,6 +554,10 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
 size_t bevamd_scan_workspace_bytes(size_t n);
 int bevamd_exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* ws,
                               size_t ws_bytes, void* stream);
+/* the same scan in ONE launch (tiles chained by decoupled look-back, csrc/single_pass.h); `state` is scratch */
+size_t bevamd_scan_single_pass_state_bytes(size_t n);
+int bevamd_exclusive_scan_u32_single_pass(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total, void* state,
+                                          size_t state_bytes, void* stream);
 size_t bevamd_radix_sort_workspace_bytes(size_t n);
 /* stable; sorts on the low nbits of the key; keys_in/vals_in are clobbered */
 int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out,
@@ -561,7 +565,8 @@ int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* 
                                 void* stream);
 
 /* nseg (<= 64) independent arrays laid end to end — counts is a HOST array of their lengths — each stably sorted on its
- * own by the launches of one sort */
+ * own by the launches of one sort: one digit-count pass over the keys + ONE launch per radix pass (one-sweep: tile offsets by
+ * look-back; BEVAMD_SORT_ONESWEEP=0 / BEVAMD_SINGLE_PASS=0: histogram + scan + scatter launches per pass) */
 size_t bevamd_radix_sort_segmented_workspace_bytes(const int* counts, int nseg);
 int bevamd_radix_sort_pairs_u32_segmented(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                                           const int* counts, int nseg, int nbits, void* ws, size_t ws_bytes, void* stream);

@@ -32,6 +32,27 @@ def test_exclusive_scan(dev, n):
     assert total == int(x.sum())
 
 
+@pytest.mark.parametrize("n", [0, 1, 63, 2047, 2048, 2049, 5000, 131072, 131073, 1 << 20, 3000001, 40000003])
+def test_single_pass_scan(dev, n):
+    """One launch: tiles chained by decoupled look-back (csrc/single_pass.h); in place, repeated on the same state buffer."""
+    lib = _capi.load()
+    rng = np.random.default_rng(n + 7)
+    x = rng.integers(0, 5, n).astype(np.int64)
+    if n > 100000:
+        x[rng.integers(0, n, 100)] = 1 << 20      # sums beyond 16 bits inside single tiles
+    sb = lib.bevamd_scan_single_pass_state_bytes(n)
+    state = torch.full((max(sb, 8),), 0xAB, dtype=torch.uint8, device=dev)   # dirty: the entry zeroes it
+    exp = np.cumsum(x) - x
+    for rep in range(3):
+        t = torch.from_numpy(x.astype(np.int32)).to(dev)
+        total = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        rc = lib.bevamd_exclusive_scan_u32_single_pass(_capi.ptr(t), _capi.ptr(t), n, _capi.ptr(total), _capi.ptr(state), sb,
+                                                       _capi.stream_ptr(dev))
+        _capi.check(rc, "single-pass scan")
+        assert np.array_equal(t.cpu().numpy().astype(np.int64), exp)
+        assert int(total.item()) == int(x.sum())
+
+
 def _sort(keys, vals, nbits, dev):
     lib = _capi.load()
     n = keys.shape[0]
@@ -73,7 +94,14 @@ def test_radix_sort_all_equal_and_already_sorted(dev):
 
 
 @pytest.mark.parametrize("counts,nbits", [([5000, 0, 1, 1024, 3000], 13), ([1], 8), ([0, 0, 70000], 27),
-                                          ([2048] * 64, 9), ([310000] * 8, 27), ([1023, 1025], 32)])
+                                          ([2048] * 64, 9), ([310000] * 8, 27), ([1023, 1025], 32),
+                                          # the one-sweep passes' lanes: 8 uneven segments, 9 with empties, 64 ragged ones, one
+                                          # segment far larger than the rest, a single large one (one lane, > 2048 tiles)
+                                          ([300000, 12, 250000, 0, 310000, 99999, 1025, 400000], 27),
+                                          ([90000, 12, 70000, 0, 110000, 9999, 1025, 100000], 27),
+                                          ([0, 70000, 0, 0, 1, 2, 3, 1024, 500000], 20),
+                                          ([(37 * i * i) % 9000 for i in range(64)], 18),
+                                          ([10] * 7 + [2000000] + [10] * 8, 27), ([3000000], 27)])
 def test_segmented_radix_sort_sorts_every_segment_on_its_own(dev, counts, nbits):
     import ctypes
 
