@@ -54,8 +54,10 @@ _SIGNATURES = {
     "bevamd_depth_raster_workspace_bytes": (Z, [I, I, I]),
     "bevamd_depth_raster": (I, [P, I, I, P, P, P, P, I, I, I, P, P, Z, P]),
     "bevamd_depth_raster_batch": (I, [P, P, I, I, P, P, I, P, P, I, I, I, P, P, Z, P]),
+    "bevamd_depth_raster_batch_zero_ws": (I, [P, P, I, I, P, P, I, P, P, I, I, I, P, P, Z, P]),
     "bevamd_lss_geometry": (I, [P, I, P, P, P, P, P, P, I, I, P, P]),
     "bevamd_mat3_inverse": (I, [P, LL, LL, I, P, P]),
+    "bevamd_mat3_inverse_with_column": (I, [P, LL, LL, I, P, P, P]),
     "bevamd_lss_camera_matrices": (I, [P, P, P, LL, LL, I, P, P, P]),
     # voxelization
     "bevamd_hard_voxelize_workspace_bytes": (Z, [I]),
@@ -73,6 +75,7 @@ _SIGNATURES = {
     "bevamd_spconv_rank_index_bytes": (Z, [I, P]),
     "bevamd_spconv_hash_index_build": (I, [P, I, P, I, P, P, Z, P]),
     "bevamd_spconv_downsample": (I, [P, I, P, I, P, P, P, P, P, P, I, P, P, Z, P, I, P]),
+    "bevamd_spconv_downsample_sorted": (I, [P, I, P, I, P, P, P, P, P, I, P, P, I, P, P, Z, P]),
     "bevamd_spconv_neighbors": (I, [P, I, P, I, P, P, P, P, P, I, I, P, I, P, I, P]),
     "bevamd_spconv_max_outputs": (I, [I, P, P, I]),
     "bevamd_spconv_build_rulebook": (I, [P, I, I, P, P, P, P, P, P, I, I, P, I, P, I, P, P, P, Z, P]),

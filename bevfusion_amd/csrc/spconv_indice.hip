@@ -598,6 +598,126 @@ __global__ __launch_bounds__(256) void sp_dense_bev_staged_kernel(const T* __res
   }
 }
 
+// Bitmap words + tile popcounts of a strided convolution's output set WITHOUT the byte map, for an input set in ascending linear
+// index: a workgroup owns one tile of output words, finds the input rows that can reach it — the x-planes (ox*s - p .. ox*s - p +
+// k - 1) of its output planes are ONE contiguous row range, read off the input level's sorted-key directory (SRC 0) or its rank
+// index (SRC 1: rows before a cell = prefix + popcount) — and sets their output cells in an LDS bitmap.  One launch instead of
+// fill + sp_mark_outputs + sp_rank_tile_sums, and no 32-bytes-per-word map (87 MB at level 2 of 8 frames: written by the fill,
+// read-modify-written by the marks, read back by the fold); inputs are read ~2.5 times (tiles share boundary planes).
+// Undilated, untransposed convolutions only.
+template <int TILE, int SRC>
+__global__ __launch_bounds__(256) void sp_rank_tiles_from_rows_kernel(const int* __restrict__ indices, int n_cap,
+                                                                      const int* __restrict__ n_dev, ConvGeom g,
+                                                                      const int* __restrict__ in_xstart,
+                                                                      const uint2* __restrict__ in_words,
+                                                                      uint2* __restrict__ words, size_t nwords,
+                                                                      uint32_t* __restrict__ tile_sums) {
+  __shared__ unsigned bm[TILE];
+  __shared__ unsigned lds_wave[4];
+  int n = n_dev ? *n_dev : n_cap;
+  if (n > n_cap) n = n_cap;
+  for (int i = threadIdx.x; i < TILE; i += 256) bm[i] = 0u;
+  __syncthreads();
+  const int X = g.in_shape[0], Y = g.in_shape[1], Z = g.in_shape[2];
+  const int OX = g.out_shape[0], OY = g.out_shape[1], OZ = g.out_shape[2];
+  const unsigned long long volume = (unsigned long long)g.batch * OX * OY * OZ;
+  const unsigned long long c0 = (unsigned long long)blockIdx.x * TILE * 32;
+  const unsigned long long c1 = c0 + (unsigned long long)TILE * 32 < volume ? c0 + (unsigned long long)TILE * 32 : volume;
+  if (c0 < c1 && n > 0) {
+    const unsigned long long plane = (unsigned long long)OY * OZ;
+    const unsigned long long p0 = c0 / plane, p1 = (c1 - 1) / plane;   // (b * OX + ox) of the first / last cell
+    const int b_lo = (int)(p0 / OX), b_hi = (int)(p1 / OX);
+    for (int b = b_lo; b <= b_hi; ++b) {
+      const int ox_lo = b == b_lo ? (int)(p0 % OX) : 0, ox_hi = b == b_hi ? (int)(p1 % OX) : OX - 1;
+      int ix_lo = ox_lo * g.stride[0] - g.pad[0], ix_hi = ox_hi * g.stride[0] - g.pad[0] + g.ksize[0] - 1;
+      ix_lo = ix_lo < 0 ? 0 : ix_lo;
+      ix_hi = ix_hi > X - 1 ? X - 1 : ix_hi;
+      if (ix_lo > ix_hi) continue;
+      int r0, r1;
+      if constexpr (SRC == 0) {
+        r0 = in_xstart[b * X + ix_lo];
+        r1 = in_xstart[b * X + ix_hi + 1];
+      } else {
+        const uint32_t k0 = (uint32_t)(b * X + ix_lo) * (uint32_t)Y * (uint32_t)Z;
+        const uint2 w0 = in_words[k0 >> 5];
+        r0 = (int)(w0.y + __popc(w0.x & ((1u << (k0 & 31)) - 1u)));
+        if (b * X + ix_hi + 1 >= g.batch * X) {
+          r1 = n;
+        } else {
+          const uint32_t k1 = (uint32_t)(b * X + ix_hi + 1) * (uint32_t)Y * (uint32_t)Z;
+          const uint2 w1 = in_words[k1 >> 5];
+          r1 = (int)(w1.y + __popc(w1.x & ((1u << (k1 & 31)) - 1u)));
+        }
+      }
+      r0 = r0 < 0 ? 0 : r0;            // (a directory built from rows that were not in linear order may hold anything)
+      r1 = r1 > n ? n : r1;
+      // four rows per thread in flight (a coarse level has a few hundred tiles and ~25 rows per thread: one dependent 16-byte
+      // load per iteration left the kernel waiting on memory latency)
+      for (int j0 = r0 + (int)threadIdx.x; j0 < r1; j0 += 4 * 256) {
+        int4 cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cc[u] = ((const int4*)indices)[j0 + u * 256 < r1 ? j0 + u * 256 : r1 - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(cc[u].x), "+v"(cc[u].y), "+v"(cc[u].z), "+v"(cc[u].w));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+        const int4 c = cc[u];
+        if (j0 + u * 256 >= r1 || c.x != b) continue;
+        // the outputs an input feeds, axis by axis: o = (i + pad - k) / stride for the taps k where that division is exact
+        // (at most 3 per axis for k <= 3; powers of two by shift — three runtime divisions per tap made this kernel 2-5 x slower
+        // than the byte-map kernels it replaces)
+        int lo[3][3], ln[3];
+        const int ci[3] = {c.y, c.z, c.w};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const int st = g.stride[a], sm = st - 1;
+          const bool p2 = (st & sm) == 0;
+          const int sh = __ffs(st) - 1;
+          int cnt = 0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int t = ci[a] + g.pad[a] - k;
+            const bool ok = k < g.ksize[a] && t >= 0 && (p2 ? (t & sm) == 0 : t % st == 0);
+            const int o = p2 ? t >> sh : t / st;
+            if (ok && o < g.out_shape[a]) {
+#pragma unroll
+              for (int q = 0; q < 3; ++q) lo[a][q] = q == cnt ? o : lo[a][q];
+              ++cnt;
+            }
+          }
+          ln[a] = cnt;
+        }
+        const uint32_t t0 = (uint32_t)c0, t1 = (uint32_t)c1;   // (batch * volume < 2^32 - 16: make_geom)
+        for (int ix = 0; ix < ln[0]; ++ix) {
+          const uint32_t bx = ((uint32_t)c.x * (uint32_t)OX + (uint32_t)(ix == 0 ? lo[0][0] : ix == 1 ? lo[0][1] : lo[0][2])) * (uint32_t)OY;
+          for (int iy = 0; iy < ln[1]; ++iy) {
+            const uint32_t by = (bx + (uint32_t)(iy == 0 ? lo[1][0] : iy == 1 ? lo[1][1] : lo[1][2])) * (uint32_t)OZ;
+            for (int iz = 0; iz < ln[2]; ++iz) {
+              const uint32_t cell = by + (uint32_t)(iz == 0 ? lo[2][0] : iz == 1 ? lo[2][1] : lo[2][2]);
+              if (cell >= t0 && cell < t1) atomicOr(&bm[(cell - t0) >> 5], 1u << (cell & 31u));
+            }
+          }
+        }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int PER = TILE / 256;
+  const size_t w0i = (size_t)blockIdx.x * TILE + (size_t)threadIdx.x * PER;
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i)
+    if (w0i + i < nwords) {
+      const unsigned bits = bm[threadIdx.x * PER + i];
+      words[w0i + i].x = bits;
+      s += __popc(bits);
+    }
+  unsigned tot;
+  block_exclusive_scan_256u(s, lds_wave, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
 static int make_geom(int batch, const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
                      const int* pad, const int* dil, int subm, ConvGeom& g, int transpose = 0) {
   BEVAMD_REQUIRE(in_shape && out_shape && ksize && stride && pad, "spconv: null geometry (host pointers)");
@@ -1042,6 +1162,49 @@ int bevamd_spconv_downsample(const int* indices, int n_cap, const int* n_dev, in
   BEVAMD_REQUIRE(!nbr || nbr_stride >= out_cap, "spconv_downsample: nbr_stride %d < out_cap %d", nbr_stride, out_cap);
   return downsample(indices, n_cap, n_dev, g, out_indices, out_cap, num_out_dev, out_index, out_index_bytes, nbr,
                     nbr_stride, (hipStream_t)stream_);
+}
+
+/* bevamd_spconv_downsample for an input set whose rows are in ASCENDING LINEAR INDEX and that owns a lookup structure:
+ * src_kind 0 = the x-plane directory of its sorted-key index (bevamd_spconv_sorted_index_build: int32 [batch * in_shape[0] + 1]),
+ * src_kind 1 = its rank index words.  Same outputs (out_indices, num_out_dev, the outputs' rank index in out_index) from two
+ * launches instead of four and without the 32-byte-per-word byte map: see sp_rank_tiles_from_rows_kernel.  Rows that are not
+ * in linear order give a wrong (never out-of-bounds) result; the sorted-key index flags that case. */
+int bevamd_spconv_downsample_sorted(const int* indices, int n_cap, const int* n_dev, int batch_size, const int* in_shape,
+                                    const int* out_shape, const int* ksize, const int* stride, const int* padding, int src_kind,
+                                    const void* src, int* out_indices, int out_cap, int* num_out_dev, void* out_index,
+                                    size_t out_index_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvGeom g;
+  int rc = make_geom(batch_size, in_shape, out_shape, ksize, stride, padding, nullptr, 0, g);
+  if (rc) return rc;
+  BEVAMD_REQUIRE(n_cap >= 0 && (indices || n_cap == 0), "spconv_downsample_sorted: bad input");
+  BEVAMD_REQUIRE(num_out_dev && out_indices && out_cap >= 1, "spconv_downsample_sorted: null output / out_cap < 1");
+  BEVAMD_REQUIRE((src_kind == 0 || src_kind == 1) && src, "spconv_downsample_sorted: src_kind %d (0 | 1) / null src", src_kind);
+  BEVAMD_REQUIRE(ksize[0] <= 3 && ksize[1] <= 3 && ksize[2] <= 3, "spconv_downsample_sorted: kernel sizes up to 3 (got %d %d %d)",
+                 ksize[0], ksize[1], ksize[2]);
+  const size_t need = rank_index_bytes(g.batch, g.out_shape);
+  if (!out_index || out_index_bytes < need) {
+    set_error("spconv rank index: buffer too small (%zu < %zu)", out_index_bytes, need);
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  const size_t nw = grid_words(g.batch, g.out_shape), nt = rank_tiles(nw);
+  Carver cv(out_index, out_index_bytes);
+  uint2* words = cv.take<uint2>(nw);   // must stay first: the rank index IS this array
+  uint32_t* tile_sums = cv.take<uint32_t>(nt + 1);
+  const int* xs = src_kind == 0 ? (const int*)src : nullptr;
+  const uint2* iw = src_kind == 1 ? (const uint2*)src : nullptr;
+#define BEVAMD_GO(TILE)                                                                                                       \
+  do {                                                                                                                        \
+    if (src_kind == 0) sp_rank_tiles_from_rows_kernel<TILE, 0><<<dim3((unsigned)nt), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, xs, iw, words, nw, tile_sums); \
+    else sp_rank_tiles_from_rows_kernel<TILE, 1><<<dim3((unsigned)nt), dim3(256), 0, stream>>>(indices, n_cap, n_dev, g, xs, iw, words, nw, tile_sums); \
+    BEVAMD_LAUNCH_CHECK("sp_rank_tiles_from_rows");                                                                           \
+    sp_rank_apply_emit_kernel<TILE><<<dim3((unsigned)nt), dim3(256), 0, stream>>>(words, nw, tile_sums, num_out_dev, g, out_indices, out_cap); \
+    BEVAMD_LAUNCH_CHECK("sp_rank_apply_emit");                                                                                \
+  } while (0)
+  if (rank_tile_for(nw) == RANK_TILE_SMALL) BEVAMD_GO(RANK_TILE_SMALL);
+  else BEVAMD_GO(RANK_TILE);
+#undef BEVAMD_GO
+  return BEVAMD_OK;
 }
 
 int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev, int batch_size, const int* in_shape,

@@ -121,6 +121,15 @@ __global__ __launch_bounds__(256) void depth_raster_unpack_kernel(const unsigned
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256)
     depth[p] = __uint_as_float((unsigned)(packed[p] & 0xFFFFFFFFull));   // empty pixel: 0 | 0 -> 0.0f
 }
+// the same, leaving the map zero behind it: the next raster over the same (persistent) map needs no fill launch
+__global__ __launch_bounds__(256) void depth_raster_unpack_clear_kernel(unsigned long long* __restrict__ packed, size_t npix,
+                                                                        float* __restrict__ depth) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const unsigned long long w = packed[p];
+    depth[p] = __uint_as_float((unsigned)(w & 0xFFFFFFFFull));
+    if (w) packed[p] = 0ull;
+  }
+}
 
 // ---- batched raster: up to RASTER_MAX_BATCH samples per launch pair (pointers by value in the kernel argument) ---------------
 constexpr int RASTER_MAX_BATCH = 16;
@@ -224,6 +233,16 @@ __device__ __forceinline__ void mat3_inverse_f64(const float* __restrict__ m, lo
   o[8] = (float)((a[0] * a[4] - a[1] * a[3]) * r);
 }
 
+// + the fourth column of the same rows packed as [count, 3] (rotation inverse and translation of a [B, 4, 4] augmentation matrix
+// in one launch: a strided-copy kernel of the framework otherwise)
+__global__ void mat3_inverse_col_kernel(const float* __restrict__ m, long long mat_stride, long long row_stride, int count,
+                                        float* __restrict__ out, float* __restrict__ col) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  mat3_inverse_f64(m + (size_t)i * mat_stride, row_stride, out + (size_t)i * 9);
+  for (int r = 0; r < 3; ++r) col[(size_t)i * 3 + r] = m[(size_t)i * mat_stride + r * row_stride + 3];
+}
+
 __global__ void mat3_inverse_kernel(const float* __restrict__ m, long long mat_stride, long long row_stride, int count,
                                     float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,10 +313,34 @@ int bevamd_depth_raster(const float* points, int num_points, int num_features, c
  * lidar_aug_trans + b * trans_stride floats (trans_stride 3 for a packed [B,3], 16 for column 3 of a [B,4,4] starting at
  * element 3 with row stride 4 is NOT contiguous -> pass a packed copy), lidar2image / img_aug [B,ncam,4,4]; depth [B,ncam,1,ih,iw];
  * ws: batch * bevamd_depth_raster_workspace_bytes(ncam, ih, iw).  Same arithmetic and collision rule per sample. */
+static int depth_raster_batch(const float* const* points, const int* num_points, int batch, int num_features,
+                              const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
+                              const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth, void* ws,
+                              size_t ws_bytes, void* stream_, bool ws_is_zero);
+
 int bevamd_depth_raster_batch(const float* const* points, const int* num_points, int batch, int num_features,
                               const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
                               const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth, void* ws,
                               size_t ws_bytes, void* stream_) {
+  return depth_raster_batch(points, num_points, batch, num_features, lidar_aug_inv_rot, lidar_aug_trans, trans_stride, lidar2image,
+                            img_aug, ncam, ih, iw, depth, ws, ws_bytes, stream_, false);
+}
+
+/* bevamd_depth_raster_batch over a PERSISTENT map: ws must be all zero when the call starts and is all zero again when its kernels
+ * have run (the unpack pass clears what it reads) — two launches instead of three, for a caller that keeps one zero-initialised
+ * workspace per (device, size) and serialises its rasters on one stream. */
+int bevamd_depth_raster_batch_zero_ws(const float* const* points, const int* num_points, int batch, int num_features,
+                                      const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
+                                      const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth,
+                                      void* ws, size_t ws_bytes, void* stream_) {
+  return depth_raster_batch(points, num_points, batch, num_features, lidar_aug_inv_rot, lidar_aug_trans, trans_stride, lidar2image,
+                            img_aug, ncam, ih, iw, depth, ws, ws_bytes, stream_, true);
+}
+
+static int depth_raster_batch(const float* const* points, const int* num_points, int batch, int num_features,
+                              const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
+                              const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth, void* ws,
+                              size_t ws_bytes, void* stream_, bool ws_is_zero) {
   hipStream_t stream = (hipStream_t)stream_;
   BEVAMD_REQUIRE(batch > 0 && num_features >= 3 && ncam > 0 && ih > 0 && iw > 0 && trans_stride >= 3, "depth_raster_batch: bad sizes");
   BEVAMD_REQUIRE(points && num_points && depth && lidar_aug_inv_rot && lidar_aug_trans && lidar2image && img_aug,
@@ -308,8 +351,10 @@ int bevamd_depth_raster_batch(const float* const* points, const int* num_points,
     return BEVAMD_ERR_WORKSPACE;
   }
   unsigned long long* packed = (unsigned long long*)ws;
-  int rc = device_fill_u32((uint32_t*)packed, per * batch * 2, 0u, stream);
-  if (rc) return rc;
+  if (!ws_is_zero) {
+    int rc = device_fill_u32((uint32_t*)packed, per * batch * 2, 0u, stream);
+    if (rc) return rc;
+  }
   for (int b0 = 0; b0 < batch; b0 += RASTER_MAX_BATCH) {
     RasterBatch rb;
     rb.batch = batch - b0 < RASTER_MAX_BATCH ? batch - b0 : RASTER_MAX_BATCH;
@@ -333,7 +378,9 @@ int bevamd_depth_raster_batch(const float* const* points, const int* num_points,
     BEVAMD_LAUNCH_CHECK("depth_raster_batch_packed");
   }
   const size_t npix = per * batch, ub = (npix + 255) / 256;
-  depth_raster_unpack_kernel<<<dim3((unsigned)(ub < 8192 ? ub : 8192)), dim3(256), 0, stream>>>(packed, npix, depth);   // every pixel written: no zero fill
+  // every pixel written: no zero fill of `depth`
+  if (ws_is_zero) depth_raster_unpack_clear_kernel<<<dim3((unsigned)(ub < 8192 ? ub : 8192)), dim3(256), 0, stream>>>(packed, npix, depth);
+  else depth_raster_unpack_kernel<<<dim3((unsigned)(ub < 8192 ? ub : 8192)), dim3(256), 0, stream>>>(packed, npix, depth);
   BEVAMD_LAUNCH_CHECK("depth_raster_unpack");
   return BEVAMD_OK;
 }
@@ -361,6 +408,19 @@ int bevamd_mat3_inverse(const float* m, long long mat_stride, long long row_stri
   BEVAMD_REQUIRE(m && out, "mat3_inverse: null buffer");
   mat3_inverse_kernel<<<dim3(cdiv(count, 64)), dim3(64), 0, stream>>>(m, mat_stride, row_stride, count, out);
   BEVAMD_LAUNCH_CHECK("mat3_inverse");
+  return BEVAMD_OK;
+}
+
+/* bevamd_mat3_inverse + col[i][r] = m[i*mat_stride + r*row_stride + 3] (row_stride >= 4): the inverse rotation and the translation
+ * column of [count, 4, 4] matrices (base.py:289-292) from one launch. */
+int bevamd_mat3_inverse_with_column(const float* m, long long mat_stride, long long row_stride, int count, float* out, float* col,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(count >= 0 && row_stride >= 4 && mat_stride >= 0, "mat3_inverse_with_column: bad sizes");
+  if (count == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(m && out && col, "mat3_inverse_with_column: null buffer");
+  mat3_inverse_col_kernel<<<dim3(cdiv(count, 64)), dim3(64), 0, stream>>>(m, mat_stride, row_stride, count, out, col);
+  BEVAMD_LAUNCH_CHECK("mat3_inverse_col");
   return BEVAMD_OK;
 }
 

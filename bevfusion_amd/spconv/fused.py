@@ -276,14 +276,32 @@ class Level:
         # neighbouring rows share) and writes its column of the table once, coalesced, no fill (_DOWN_NBR_FROM_OUTPUTS)
         from_outputs = want_nbr and _DOWN_NBR_FROM_OUTPUTS and self.index_kind == INDEX_RANK
         nbr = torch.empty((K, cap), dtype=torch.int32, device=dev) if want_nbr and not from_outputs else None
+        # A level in linear order that owns a lookup structure (rank index; level 1 in key order: the directory of its sorted-key
+        # index) finds the inputs of a tile of output cells as ONE row range: the output bitmap is built in LDS, tile by tile — two
+        # launches instead of four, no 32-byte-per-word byte map (bevamd_spconv_downsample_sorted)
+        src_kind = src = None
+        if _DOWN_SORTED and self.linear_order and nbr is None and max(ksize) <= 3:
+            if self.index_kind == INDEX_RANK:
+                src_kind, src = 1, self.index
+            elif self.use_sorted():
+                self.ensure_sorted(wait=False)
+                off = (max(self.n_cap, 1) * 4 + 255) // 256 * 256
+                src_kind, src = 0, self.sorted_index[off:]
         with torch.cuda.device(dev):
             nbytes = lib.bevamd_spconv_rank_index_bytes(self.batch, _capi.ints(out_shape))
             index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            rc = lib.bevamd_spconv_downsample(_capi.ptr(self.indices), self.n_cap, _capi.ptr(self.n_dev), self.batch,
-                                              _capi.ints(self.shape), _capi.ints(out_shape), _capi.ints(ksize),
-                                              _capi.ints(stride), _capi.ints(padding), _capi.ptr(out_indices), cap,
-                                              _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.ptr(nbr), cap,
-                                              self._stream_ptr())
+            if src is not None:
+                rc = lib.bevamd_spconv_downsample_sorted(_capi.ptr(self.indices), self.n_cap, _capi.ptr(self.n_dev), self.batch,
+                                                         _capi.ints(self.shape), _capi.ints(out_shape), _capi.ints(ksize),
+                                                         _capi.ints(stride), _capi.ints(padding), src_kind, _capi.ptr(src),
+                                                         _capi.ptr(out_indices), cap, _capi.ptr(num_out), _capi.ptr(index), nbytes,
+                                                         self._stream_ptr())
+            else:
+                rc = lib.bevamd_spconv_downsample(_capi.ptr(self.indices), self.n_cap, _capi.ptr(self.n_dev), self.batch,
+                                                  _capi.ints(self.shape), _capi.ints(out_shape), _capi.ints(ksize),
+                                                  _capi.ints(stride), _capi.ints(padding), _capi.ptr(out_indices), cap,
+                                                  _capi.ptr(num_out), _capi.ptr(index), nbytes, _capi.ptr(nbr), cap,
+                                                  self._stream_ptr())
         _capi.check(rc, "spconv_downsample")
         out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream, status_pool=self._status_pool,
                     allow_slab=self.allow_slab)
@@ -503,8 +521,28 @@ def _narrow_variant_for(conv, lvl, cin, cout):
 
 # neighbour table of the strided gather layers from the output side (rank-index lookups, no fill); 0 = from the input side
 _DOWN_NBR_FROM_OUTPUTS = os.environ.get("BEVAMD_SPCONV_DOWN_NBR", "outputs") != "inputs"
+# output set of a strided layer over a level in linear order: bitmap tiles in LDS from contiguous input row ranges (0: byte map)
+_DOWN_SORTED = os.environ.get("BEVAMD_SPCONV_DOWN_SORTED", "1") != "0"
 _STATUS_WORDS = 64
 _STATUS_POOL = os.environ.get("BEVAMD_SPCONV_STATUS_POOL", "1") != "0"
+_STATUS_POOLS = {}
+
+
+def _status_pool(dev):
+    """[zeroed int32 words, next free]: the status words of one pass's products.  ONE tensor per device, zeroed when it is created
+    and whenever a reader finds a bit set (geometry_status) — not per pass (that was a fill kernel in front of every encoder
+    pass): the kernels only ever OR bits into a word on an error, nobody looks at the words of a pass that is not checked, and a
+    checked pass clears what it reads.  The first pass on a device that happens to be a graph capture gets a tensor of its own
+    (allocated and zeroed inside the capture, not kept)."""
+    if not _STATUS_POOL:
+        return None
+    key = torch.device(dev).index
+    if key not in _STATUS_POOLS:
+        words = torch.zeros(_STATUS_WORDS, dtype=torch.int32, device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            return [words, 0]
+        _STATUS_POOLS[key] = words
+    return [_STATUS_POOLS[key], 0]
 _PAD_CAST = os.environ.get("BEVAMD_SPCONV_PAD_CAST", "1") != "0"
 _GATHER_SLOT_ROWS = 128
 # measured at 8 frames and NOT the default: LiDAR branch 3.94 ms with it against 3.83 ms with the int32 tables — the 2-byte slot
@@ -639,7 +677,7 @@ def prepare_geometry(enc, coors, batch_size, num_voxels=None, coors_order=None, 
     dev = coors.device
     g = geometry_stream(dev)
     main = torch.cuda.current_stream(dev)
-    pool = [torch.zeros(_STATUS_WORDS, dtype=torch.int32, device=dev), 0] if _STATUS_POOL else None   # zeroed BEFORE the fork: ordered ahead of both streams
+    pool = _status_pool(dev)
     if g is not None:
         g.wait_stream(main)
     lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool,
@@ -723,7 +761,10 @@ def geometry_status(lvl):
             words.append(lvl.sorted_status)
         for wd in words:
             if wd is not None:
-                bits |= int(wd.item())
+                v = int(wd.item())
+                if v:
+                    bits |= v
+                    wd.zero_()      # the words live in a per-device pool that is not re-zeroed per pass (_status_pool)
         nxt = None
         for out, _ in lvl._down.values():
             nxt = out
@@ -769,7 +810,7 @@ def run_encoder(enc, voxel_features, coors, batch_size, num_voxels=None, geometr
     dev = voxel_features.device
     g = geometry_stream(dev)
     main = torch.cuda.current_stream(dev)
-    pool = [torch.zeros(_STATUS_WORDS, dtype=torch.int32, device=dev), 0] if _STATUS_POOL else None   # zeroed BEFORE the fork: ordered ahead of both streams
+    pool = _status_pool(dev)
     if g is not None:
         g.wait_stream(main)       # fork: coordinates / count are final, recycled buffers are quiescent
     lvl = Level(coors, n, num_voxels, batch_size, enc.sparse_shape, gstream=g, linear_order=_is_linear(coors_order), status_pool=pool,

@@ -37,6 +37,8 @@ def gen_dx_bx(xbound, ybound, zbound):
     return dx, bx, nx
 
 
+_RASTER_MAPS = {}   # (device, bytes) -> the persistent zeroed map of _depth_raster_native
+
 class FactoredCamFeats:
     """`get_cam_feats` result kept factored: depth [B, N, D, fH, fW] (softmax) and context [B, N, C, fH, fW].  Equivalent
     to the reference's [B, N, D, fH, fW, C] outer product (depth_lss.py:92-97), which `bev_pool` then never builds."""
@@ -361,15 +363,16 @@ class BaseDepthTransform(BaseTransform):
         dev = points[0].device
         B = len(points)
         depth = torch.empty((B, n_cam, 1, iH, iW), dtype=torch.float32, device=dev)
-        trans = lidar_aug_matrix[:, :3, 3].float().contiguous()
         if self.lapack_inverse:
+            trans = lidar_aug_matrix[:, :3, 3].float().contiguous()
             inv_rot = torch.inverse(lidar_aug_matrix[:, :3, :3].float()).contiguous()
-        else:
+        else:   # inverse rotation and packed translation column from one launch
             la = lidar_aug_matrix.float().contiguous()                     # [B, 4, 4]
             inv_rot = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+            trans = torch.empty((B, 3), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
-                _capi.check(lib.bevamd_mat3_inverse(_capi.ptr(la), 16, 4, B, _capi.ptr(inv_rot), _capi.stream_ptr(dev)),
-                            "mat3_inverse")
+                _capi.check(lib.bevamd_mat3_inverse_with_column(_capi.ptr(la), 16, 4, B, _capi.ptr(inv_rot), _capi.ptr(trans),
+                                                                _capi.stream_ptr(dev)), "mat3_inverse_with_column")
         l2i = lidar2image.float().contiguous()
         ia = img_aug_matrix.float().contiguous()
         pts = [p if (p.dtype == torch.float32 and p.is_contiguous()) else p.float().contiguous() for p in points]
@@ -380,10 +383,22 @@ class BaseDepthTransform(BaseTransform):
         counts = (ctypes.c_int * B)(*[int(p.shape[0]) for p in pts])
         with torch.cuda.device(dev):
             wsb = lib.bevamd_depth_raster_workspace_bytes(n_cam, iH, iW) * B
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            rc = lib.bevamd_depth_raster_batch(ptrs, counts, B, nfeat, _capi.ptr(inv_rot), _capi.ptr(trans), 3, _capi.ptr(l2i),
-                                               _capi.ptr(ia), n_cam, iH, iW, _capi.ptr(depth), _capi.ptr(ws), wsb,
-                                               _capi.stream_ptr(dev))
+            # one zero-initialised (winner, depth) map per device and size, left zero by every raster (the unpack pass clears what
+            # it reads): no fill launch per call — the rasters of a device are issued on one stream at a time (eager calls and
+            # the replays of a captured graph included).  A first use under graph capture takes a fresh map and the fill.
+            key = (dev.index, int(wsb))
+            ws = _RASTER_MAPS.get(key)
+            if ws is None and not torch.cuda.is_current_stream_capturing():
+                ws = _RASTER_MAPS[key] = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+            if ws is not None:
+                rc = lib.bevamd_depth_raster_batch_zero_ws(ptrs, counts, B, nfeat, _capi.ptr(inv_rot), _capi.ptr(trans), 3,
+                                                           _capi.ptr(l2i), _capi.ptr(ia), n_cam, iH, iW, _capi.ptr(depth),
+                                                           _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+            else:
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                rc = lib.bevamd_depth_raster_batch(ptrs, counts, B, nfeat, _capi.ptr(inv_rot), _capi.ptr(trans), 3, _capi.ptr(l2i),
+                                                   _capi.ptr(ia), n_cam, iH, iW, _capi.ptr(depth), _capi.ptr(ws), wsb,
+                                                   _capi.stream_ptr(dev))
         _capi.check(rc, "depth_raster_batch")
         return depth
 

@@ -236,6 +236,13 @@ int bevamd_depth_raster_batch(const float* const* points, const int* num_points,
                               const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
                               const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth,
                               void* ws, size_t ws_bytes, void* stream);
+/* The same over a PERSISTENT map: ws must be all zero when the call starts and is all zero again once its kernels have run (the
+ * unpack pass clears what it reads): two launches instead of three.  For a caller that keeps one zero-initialised workspace per
+ * (device, size) and issues its rasters on one stream. */
+int bevamd_depth_raster_batch_zero_ws(const float* const* points, const int* num_points, int batch, int num_features,
+                                      const float* lidar_aug_inv_rot, const float* lidar_aug_trans, int trans_stride,
+                                      const float* lidar2image, const float* img_aug, int ncam, int ih, int iw, float* depth,
+                                      void* ws, size_t ws_bytes, void* stream);
 
 /* Replaces BaseTransform.get_geometry (base.py:92-135): frustum [frustum_points, 3] (u, v, d) -> geom
  * [batch*cams, frustum_points, 3] in the lidar frame.  post_rot_inv [batch*cams,3,3] = inverse(img_aug[:3,:3]),
@@ -253,6 +260,10 @@ int bevamd_lss_geometry(const float* frustum, int frustum_points, const float* p
  * fp64, one rounding to fp32; no workspace, no host sync (LAPACK's getrf/getrs result may differ in the last 1-2 ulp). */
 int bevamd_mat3_inverse(const float* m, long long mat_stride, long long row_stride, int count, float* out,
                         void* stream);
+/* ... and col[i][r] = m[i*mat_stride + r*row_stride + 3] (row_stride >= 4), packed [count, 3]: inverse rotation and translation of
+ * [count, 4, 4] augmentation matrices (base.py:289-292) from one launch. */
+int bevamd_mat3_inverse_with_column(const float* m, long long mat_stride, long long row_stride, int count, float* out, float* col,
+                                    void* stream);
 
 /* The per-camera matrices bevamd_lss_geometry consumes, from the raw calibration (base.py:106, 118):
  * post_rot_inv[i] = inverse(post_rots[i]); combine[i] = camera2lidar_rots[i] @ inverse(intrins[i]) (product in the order
@@ -398,6 +409,14 @@ int bevamd_spconv_downsample(const int* indices, int n_cap, const int* n_dev, in
                              const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
                              const int* padding, int* out_indices, int out_cap, int* num_out_dev,
                              void* out_index, size_t out_index_bytes, int* nbr, int nbr_stride, void* stream);
+/* The same output set, count and rank index for an input set in ascending linear index that owns a lookup structure (src_kind 0:
+ * the x-plane directory of its sorted-key index, int32 [batch * in_shape[0] + 1]; 1: its rank-index words), in two launches
+ * instead of four and without the byte map of the general entry (csrc/spconv_indice.hip: sp_rank_tiles_from_rows_kernel).
+ * No neighbour table: bevamd_spconv_neighbors builds it from the output side.  Replaces the same reference lines. */
+int bevamd_spconv_downsample_sorted(const int* indices, int n_cap, const int* n_dev, int batch_size, const int* in_shape,
+                                    const int* out_shape, const int* ksize, const int* stride, const int* padding,
+                                    int src_kind, const void* src, int* out_indices, int out_cap, int* num_out_dev,
+                                    void* out_index, size_t out_index_bytes, void* stream);
 int bevamd_spconv_neighbors(const int* out_indices, int m_cap, const int* m_dev, int batch_size,
                             const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
                             const int* padding, int subm, int index_kind, const void* in_index,

@@ -232,3 +232,50 @@ def test_prepared_geometry_path_is_bit_identical(dev):
         assert torch.equal(enc(xp, cp, B, num_voxels=cnt, geometry=lvl2), want)
         with pytest.raises(RuntimeError):
             enc(xp[:100], cp[:100], B, num_voxels=cnt, geometry=lvl)
+
+
+@pytest.mark.parametrize("B,shape,n,ks,st,pd", [(3, (33, 30, 17), 2600, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                              (2, (40, 37, 5), 3000, (3, 3, 3), (2, 2, 2), (1, 1, 0)),
+                                              (2, (21, 19, 11), 900, (1, 1, 3), (1, 1, 2), (0, 0, 0)),
+                                              (1, (9, 9, 9), 729, (3, 3, 3), (2, 2, 2), (1, 1, 1)),      # every cell active
+                                              (5, (600, 600, 41), 60000, (3, 3, 3), (2, 2, 2), (1, 1, 1))])  # 2048-word tiles
+def test_downsample_of_a_sorted_level_equals_the_general_downsample(dev, B, shape, n, ks, st, pd):
+    """bevamd_spconv_downsample_sorted (LDS bitmap tiles from contiguous input row ranges; level 1 in key order: rows found through
+    the sorted-key directory, src_kind 0; later levels through their rank index, src_kind 1) = bevamd_spconv_downsample (byte map):
+    output rows, count and the outputs' rank-index words, bit for bit, with garbage rows beyond the live count."""
+    from bevfusion_amd import _capi
+
+    lib = _capi.load()
+    rng = np.random.default_rng(B * 1000 + n)
+    ind = _coords(rng, B, shape, n)
+    lin = ((ind[:, 0].astype(np.int64) * shape[0] + ind[:, 1]) * shape[1] + ind[:, 2]) * shape[2] + ind[:, 3]
+    ind = ind[np.argsort(lin)]
+    live = ind.shape[0]
+    cap = live + 333
+    buf = np.full((cap, 4), 7, np.int32)
+    buf[:live] = ind
+    coors = torch.from_numpy(buf).to(dev)
+    n_dev = torch.tensor([live], dtype=torch.int32, device=dev)
+
+    def chain(sorted_route):
+        fused._DOWN_SORTED = sorted_route
+        lvl = fused.Level(coors, cap, n_dev, B, list(shape), linear_order=True)
+        out, _ = lvl.downsample(list(ks), list(st), list(pd), want_nbr=False)
+        out2, _ = out.downsample([3, 3, 3], [2, 2, 2], [1, 1, 1], want_nbr=False)   # through the rank index of `out`
+        torch.cuda.synchronize()
+        res = []
+        for o in (out, out2):
+            m = int(o.n_dev.item())
+            nw = (B * int(np.prod(o.shape)) + 31) // 32
+            words = o.index[: nw * 8].view(torch.int32).reshape(nw, 2).cpu().numpy()
+            res.append((m, o.indices[:m].cpu().numpy(), words, o.shape))
+        return res
+
+    try:
+        a, b = chain(True), chain(False)
+    finally:
+        fused._DOWN_SORTED = True
+    for (ma, ia, wa, sa), (mb, ib, wb, sb) in zip(a, b):
+        assert ma == mb and sa == sb and ma > 0
+        assert np.array_equal(ia, ib)
+        assert np.array_equal(wa, wb)

@@ -214,3 +214,40 @@ def test_batched_raster_equals_the_per_sample_entry_point(dev, gold):
                                             _capi.stream_ptr(dev)), "depth_raster")
         assert torch.equal(got[b], one), b
     assert int((got != 0).sum()) > 1000 * B // 4
+
+
+def test_persistent_raster_map_is_left_clean(dev, gold):
+    """The module keeps ONE zero-initialised (winner, depth) map per device and size; every raster leaves it zero behind itself
+    (bevamd_depth_raster_batch_zero_ws: no fill launch).  Dense cloud, sparse cloud, empty cloud and the dense one again through
+    the same map: each equal to a raster over a map of its own."""
+    c = case(gold, "small")
+    lib = _capi.load()
+    pts = points_of(c)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    vt = make_vt(SMALL_CFG, dev)
+    iH, iW = SMALL_CFG["image_size"]
+    B = 2
+    l2i, ia, la = g(c["l2i"][:B]), g(c["ia"][:B]), g(c["la"][:B])
+    inv = torch.empty((B, 3, 3), device=dev)
+    tr = torch.empty((B, 3), device=dev)
+    _capi.check(lib.bevamd_mat3_inverse_with_column(_capi.ptr(la), 16, 4, B, _capi.ptr(inv), _capi.ptr(tr), _capi.stream_ptr(dev)),
+                "mat3_inverse_with_column")
+    inv2 = torch.empty((B, 3, 3), device=dev)
+    _capi.check(lib.bevamd_mat3_inverse(_capi.ptr(la), 16, 4, B, _capi.ptr(inv2), _capi.stream_ptr(dev)), "mat3_inverse")
+    assert torch.equal(inv, inv2) and torch.equal(tr, la[:, :3, 3])
+    clouds = [[g(pts[0]), g(pts[1])], [g(pts[0][:50]), g(pts[1][:7])], [g(pts[0][:0]), g(pts[1][:0])], [g(pts[0]), g(pts[1])]]
+    img = torch.zeros(B, 6, 1, 1, 1, device=dev)
+    wsb = lib.bevamd_depth_raster_workspace_bytes(6, iH, iW) * B
+    for pl in clouds:
+        got = vt.depth_raster(img, pl, l2i, ia, la)
+        import ctypes
+        ptrs = (ctypes.c_void_p * B)(*[p.data_ptr() for p in pl])
+        counts = (ctypes.c_int * B)(*[int(p.shape[0]) for p in pl])
+        exp = torch.empty((B, 6, 1, iH, iW), device=dev)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _capi.check(lib.bevamd_depth_raster_batch(ptrs, counts, B, 5, _capi.ptr(inv), _capi.ptr(tr), 3, _capi.ptr(l2i), _capi.ptr(ia),
+                                                  6, iH, iW, _capi.ptr(exp), _capi.ptr(ws), wsb, _capi.stream_ptr(dev)),
+                    "depth_raster_batch")
+        assert torch.equal(got, exp)
+    from bevfusion_amd import vtransforms
+    assert all(int(m.count_nonzero()) == 0 for m in vtransforms._RASTER_MAPS.values())
