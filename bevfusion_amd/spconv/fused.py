@@ -41,6 +41,8 @@ class NotThisCall(Exception):
 
 # How many convolutions ahead of the feature pass the rulebook chain is issued (see _Chain); -1: the whole chain up front.
 _CHAIN_LOOKAHEAD = int(os.environ.get("BEVAMD_SPCONV_CHAIN_LOOKAHEAD", "4"))
+# skip a wait on a geometry-stream event the main stream is already ordered behind (tuning switch)
+_DEDUPE_WAITS = os.environ.get("BEVAMD_SPCONV_DEDUPE_WAITS", "1") != "0"
 _GEOM_STREAMS = {}
 _PREFETCHING = [False]   # inside prefetch_geometry: products are built behind the fork point, nothing of this pass runs on the main stream yet
 
@@ -68,8 +70,11 @@ class Level:
     Buffers are allocated by the caller's (current-stream) allocator; `run_encoder` joins the two streams before it
     returns, so their reuse stays ordered."""
 
-    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False, status_pool=None, allow_slab=True):
+    def __init__(self, indices, n_cap, n_dev, batch, shape, gstream=None, linear_order=False, status_pool=None, allow_slab=True,
+                 sync=None):
         self.indices = indices
+        # shared by the levels of one pass: next event number, highest event number the main stream has waited for
+        self._sync = sync if sync is not None else {"seq": 0, "awaited": -1}
         self.allow_slab = bool(allow_slab)   # False: every layer of this chain of levels stays on the gather kernels
         self.frames_hint = None     # frames per step as the tilings count them, from the live row count of level 1 (see _frames_hint)
         self.chain = None           # _Chain issuing the rulebook products a few convolutions ahead of the feature pass
@@ -128,12 +133,22 @@ class Level:
             return None
         ev = torch.cuda.Event()
         ev.record(self.gstream)
+        ev._bevamd_seq = self._sync["seq"]     # position among the events of this pass (one geometry stream: totally ordered)
+        self._sync["seq"] += 1
         return ev
 
-    @staticmethod
-    def _await(ev):
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+    def _await(self, ev):
+        """Make the current stream wait for `ev` — unless it already waited, in this pass, for this or a LATER event of the geometry
+        stream (_DEDUPE_WAITS): the four layers of a level all ask for the same metadata, and every repeated wait is one more
+        cross-queue edge on a node of the captured graph."""
+        if ev is None:
+            return
+        seq = getattr(ev, "_bevamd_seq", None)
+        if _DEDUPE_WAITS and seq is not None:
+            if seq <= self._sync["awaited"]:
+                return
+            self._sync["awaited"] = seq
+        torch.cuda.current_stream().wait_event(ev)
 
     def ensure_index(self):
         if self.index is not None:
@@ -304,7 +319,7 @@ class Level:
                                                   self._stream_ptr())
         _capi.check(rc, "spconv_downsample")
         out = Level(out_indices, cap, num_out, self.batch, out_shape, gstream=self.gstream, status_pool=self._status_pool,
-                    allow_slab=self.allow_slab)
+                    allow_slab=self.allow_slab, sync=self._sync)
         out.frames_hint = self.frames_hint
         out.chain = self.chain
         out.index_kind, out.index, out.index_n_cap = INDEX_RANK, index, cap
@@ -630,7 +645,7 @@ def dense_bev(x):
     lib = _capi.load()
     lvl = x.level
     lvl.ensure_index()
-    Level._await(lvl.ready)
+    lvl._await(lvl.ready)
     C = x.features.shape[1]
     X, Y, Z = lvl.shape
     out = torch.empty((lvl.batch, C * Z, X, Y), dtype=x.features.dtype, device=x.features.device)
