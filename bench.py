@@ -51,16 +51,17 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed number of frames per step for the WHOLE job, split over the ranks with sharding.frames_for_rank "
                          "(strong scaling); default 0 = --batch frames on every GPU (weak scaling)")
-    ap.add_argument("--overlap", choices=["pipeline", "voxel", "head", "lidar", "none"], default="none",
-                    help="none (default): camera stages, then the whole LiDAR branch, back to back; pipeline: the stages of the two "
+    ap.add_argument("--overlap", choices=["pipeline", "voxel", "head", "lidar", "none"], default="voxel",
+                    help="voxel (default since round 4, see below); none: camera stages, then the whole LiDAR branch, back to back; pipeline: the stages of the two "
                          "independent branches interleaved so that each HBM-bound camera kernel has at most a light partner: bev_pool "
                          "runs first with only the voxelizer beside it (second HIP stream), the rulebook chain "
                          "(SparseEncoder.prepare_geometry) starts when bev_pool has finished and runs beside the depth raster and the "
                          "fused pooling, the convolutions follow after the join and run alone (measured at the end of round 3: 5.51-5.52 against 5.55 ms — "
                          "even the voxelizer alone costs bev_pool 24 %, 1.27 against 1.03 ms; not a gain); voxel: only the voxelizer (22 "
                          "short dependent launches, 0.3 ms) runs on a second HIP stream beside the depth raster / fused pooling stages — it is "
-                         "done long before bev_pool starts, whose roofline figure stays clean — and the encoder follows after the join (5.34-5.38 "
-                         "against 5.42-5.47 ms: the raster and the fused pooling pay 0.17 ms for the 0.3 ms hidden); "
+                         "done long before bev_pool starts, whose roofline figure stays clean — and the encoder follows after the join (round 3: 5.34-5.38 "
+                         "against 5.42-5.47 ms: the raster and the fused pooling pay 0.17 ms for the 0.3 ms hidden; round 4, with the column "
+                         "pooling kernels: 4.93-5.00 against 5.06 ms per 8 frames, 1.07 against 1.15 ms on one frame, A/B on one box: the default); "
                          "head: the LiDAR branch's head — "
                          "voxelization + the whole rulebook chain (SparseEncoder.prepare_geometry) — runs on a second HIP stream beside the "
                          "camera stages and the convolutions follow after the join (round 3: 5.23-5.33 against 5.42-5.55 ms per 8-frame step — the 21 "
@@ -874,10 +875,10 @@ def main():
             state["n_voxels_dev"] = state["head"][2]
             assert enc.last_path == "fused", enc.last_path_reason
         elif overlap_head:
-            graph_head = torch.cuda.CUDAGraph()
+            graph_head = new_graph()
             with torch.cuda.graph(graph_head):
                 state["head"] = lidar_head()
-            graph_tail = torch.cuda.CUDAGraph()
+            graph_tail = new_graph()
             with torch.cuda.graph(graph_tail):
                 state["lidar_bev"] = lidar_tail(*state["head"])
             state["n_voxels_dev"] = state["head"][2]
@@ -1060,22 +1061,45 @@ def main():
         return a.elapsed_time(b) / n
 
     extra = None
-    if rank == 0 and world == 1 and not args.no_extras and args.overlap == "none" and graph is not None:
+    def add_counts(a, b):
+        return None if a is None or b is None else {k: a[k] + b[k] for k in a}
+
+    if rank == 0 and world == 1 and not args.no_extras and ((args.overlap == "none" and graph is not None) or overlap_voxel):
         extra = {}
         t_extra = time.perf_counter()
         # (iv) the product's step: what a deployment runs per batch — raster + fused pooling + LiDAR branch — without the API-level
-        # bev_pool kernel on the materialised volume (the camera reduction is otherwise counted twice in `value`)
+        # bev_pool kernel on the materialised volume (the camera reduction is otherwise counted twice in `value`); same schedule as
+        # the headline step
         def product_step():
+            main_stream = torch.cuda.current_stream()
+            if overlap_voxel:
+                head_stream.wait_stream(main_stream)
+                with torch.cuda.stream(head_stream):
+                    graph_head.replay()
             with torch.no_grad():
                 state["depth_img"] = vt.depth_raster(img_stub, pts_list, t_l2i, t_ia, t_la)
             plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
-            graph.replay()
+            if overlap_voxel:
+                main_stream.wait_stream(head_stream)
+                graph_tail.replay()
+            else:
+                graph.replay()
 
         pm = timed(product_step, args.steps)
         extra["product_step"] = dict(ms_per_step=pm, frames_per_s=B * 1e3 / pm, frames=B,
-                                     note="depth raster + fused depth x context pooling + LiDAR branch (one graph replay); the "
-                                          "API-level bev_pool kernel of the headline step left out")
-        extra["lidar_graph"] = graph_node_count(graph)
+                                     note="depth raster + fused depth x context pooling + LiDAR branch (schedule of the headline "
+                                          "step); the API-level bev_pool kernel of the headline step left out")
+        extra["lidar_graph"] = (add_counts(graph_node_count(graph_head), graph_node_count(graph_tail)) if overlap_voxel
+                                else graph_node_count(graph))
+        if overlap_voxel:
+            # the LiDAR branch with nothing beside it (what stage_ms.lidar_branch measured up to round 3: under the default
+            # schedule that stage no longer contains the voxelizer, which runs beside the raster / fused pooling stages)
+            def lidar_alone():
+                graph_head.replay()
+                graph_tail.replay()
+
+            extra["lidar_branch_alone"] = dict(ms=kernel_ms(lidar_alone), frames=B,
+                                               note="voxelizer graph + encoder graph back to back on one stream, HIP events around 20 passes")
         # (i) BASELINE configs[1]: bev_pool on bf16 camera features, same plan, same launch
         if elem == 4:
             f16 = feats.bfloat16()
@@ -1093,42 +1117,67 @@ def main():
             bev1, fused1 = torch.empty((1, D, H, W, C), device=dev), torch.empty((1, D, H, W, C), device=dev)
             feats1, depth1, ctx1, pts1 = feats[:per].float(), depth_prob[:n_cam], ctx_cl[: n_cam * fh * fw], pts_list[:1]
 
-            def lidar1():
-                vf, vc, _, cnt = voxelize_batch_device(pts1, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
-                                                       cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
+            def vox1():
+                return voxelize_batch_device(pts1, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
+                                             cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
+
+            def enc1(vf, vc, _, cnt):
                 with torch.no_grad():
                     return enc(vf, vc, 1, num_voxels=cnt, coors_order=coors_order)
 
             for _ in range(2):
-                lidar1()
+                enc1(*vox1())
             side1 = torch.cuda.Stream()
             side1.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side1):
-                lidar1()
+                enc1(*vox1())
             torch.cuda.current_stream().wait_stream(side1)
             torch.cuda.synchronize()
+            # the schedule of the headline step: voxelizer (own graph, second stream) beside raster + fused pooling, or one graph
+            g1h = new_graph() if overlap_voxel else None
             g1 = new_graph()
-            with torch.cuda.graph(g1):
-                state["lidar_bev1"] = lidar1()
+            if overlap_voxel:
+                with torch.cuda.graph(g1h):
+                    state["vox1"] = vox1()
+                with torch.cuda.graph(g1):
+                    state["lidar_bev1"] = enc1(*state["vox1"])
+            else:
+                with torch.cuda.graph(g1):
+                    state["lidar_bev1"] = enc1(*vox1())
 
             def step1():
+                main_stream = torch.cuda.current_stream()
+                if overlap_voxel:
+                    head_stream.wait_stream(main_stream)
+                    with torch.cuda.stream(head_stream):
+                        g1h.replay()
                 with torch.no_grad():
                     vt.depth_raster(img_stub[:1], pts1, t_l2i[:1], t_ia[:1], t_la[:1])
                 plan1.launch_fused(depth1.reshape(-1), ctx1, dbins, fh, fw, out=fused1)
                 plan1.launch_forward(feats1, bev1)
+                if overlap_voxel:
+                    main_stream.wait_stream(head_stream)
+                g1.replay()
+
+            def lidar1_alone():
+                if overlap_voxel:
+                    g1h.replay()
                 g1.replay()
 
             m1 = timed(step1, 50, warm=5)
             ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            lidar1_alone()
             ev1[0].record()
             for _ in range(20):
-                g1.replay()
+                lidar1_alone()
             ev1[1].record()
             ev1[1].synchronize()
             extra["batch1_step"] = dict(ms_per_step=m1, frames_per_s=1e3 / m1, lidar_branch_ms=ev1[0].elapsed_time(ev1[1]) / 20,
-                                        lidar_graph=graph_node_count(g1),
-                                        note="the headline step (raster + fused pooling + bev_pool + LiDAR graph) on ONE frame")
-            del g1, plan1, bev1, fused1
+                                        lidar_graph=(add_counts(graph_node_count(g1h), graph_node_count(g1)) if overlap_voxel
+                                                     else graph_node_count(g1)),
+                                        note="the headline step (raster + fused pooling + bev_pool + LiDAR branch, same schedule) on "
+                                             "ONE frame; lidar_branch_ms: voxelizer + encoder back to back, nothing beside them")
+            del g1, g1h, plan1, bev1, fused1
         except Exception as e:   # a secondary figure must never take the headline down
             extra["batch1_step"] = dict(error=repr(e)[:300])
         # (iii) BASELINE configs[4]: 5 steps of the training step in the reference's default arithmetic, 4 frames

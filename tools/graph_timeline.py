@@ -32,8 +32,15 @@ def main():
     if len(marks) < back + 1:
         print("not enough steps in the trace")
         return
-    # the fill in front of the raster belongs to the step too: start one kernel earlier
-    lo, hi = marks[-back - 1] - 1, marks[-back] - 1
+    # the kernel in front of the raster (round 4: the inverse-rotation kernel; before: the map fill) belongs to the step too: start
+    # one kernel earlier — and, under the default schedule, at the voxelizer's key kernel if that started first on its own queue
+    def first_of_step(m):
+        lo = m - 1
+        for j in range(max(0, m - 4), m):
+            if "vox_key_batch" in rows[j][0] or "mat3_inverse" in rows[j][0]:
+                lo = min(lo, j)
+        return lo
+    lo, hi = first_of_step(marks[-back - 1]), first_of_step(marks[-back])
     seg = rows[lo:hi]
     t0 = seg[0][1]
     qs = sorted({r[3] for r in seg})
