@@ -258,6 +258,26 @@ def stored_layer_profile():
     return prof
 
 
+class quiet_gc:
+    """The timed region without the cyclic garbage collector (what `timeit` does): a full collection over the ~10^6 objects of a
+    process that has imported torch and built the models is a 100-ms host stall — seen as ONE 119-ms encoder forward among
+    5.8-ms ones in the 7th step of `--mode train-step --amp`, whose forward is paced by the host (per_step_ms in its JSON)."""
+
+    def __enter__(self):
+        import gc
+
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+
+        if self.was:
+            gc.enable()
+        return False
+
+
 def new_graph():
     """A CUDAGraph that keeps its hipGraph_t, so that its nodes can be counted (torch >= 2.8); plain otherwise."""
     try:
@@ -604,15 +624,18 @@ def train_step(args, rank, world, frame_ids, dev):
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(args.steps)]
     barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(evs[i])
-    torch.cuda.synchronize()
-    barrier()
-    elapsed_local = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(evs[i])
+        torch.cuda.synchronize()
+        barrier()
+        elapsed_local = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed_local, device=dev)
     frames_per_step = int(sum_over_ranks(B, device=dev))
     stage = {n: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i, n in enumerate(names)}
+    per_step_ms = [round(float(e[0].elapsed_time(e[len(names)])), 3) for e in evs]            # GPU time of every timed step
+    fwd_step_ms = [round(float(e[5].elapsed_time(e[6])), 3) for e in evs]                     # ... and of its encoder forward
     # the dominant streaming kernel of the step, timed on its own (the stage above also holds autograd's copy of the incoming gradient)
     for _ in range(3):
         plan.launch_backward(gout, C)
@@ -641,6 +664,8 @@ def train_step(args, rank, world, frame_ids, dev):
                                    f"voxelize {sum(p.shape[0] for p in pts)} points (cap {cfg['max_voxels'][0]}), SparseEncoder fp32 "
                                    f"train mode ({nparam} parameters) fwd+bwd, clip_grad_norm 35, AdamW",
                        "frames_per_step_per_gpu": B, "frames_per_step": frames_per_step, "stage_ms": stage,
+                       "per_step_ms": per_step_ms, "encoder_fwd_per_step_ms": fwd_step_ms,
+                       "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention; see quiet_gc)",
                        "gradient_allreduce": (f"DistributedDataParallel over torch.distributed nccl (= RCCL), world {world}, "
                                               f"{nparam * 4 / 1e6:.1f} MB per step") if world > 1 else "single rank: none"},
             "roofline": {"kernel": "bev_pool_bwd_points_vec_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -1018,12 +1043,13 @@ def main():
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(NSTAGE + 1)] for _ in range(args.steps)]
     barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(evs[i])
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(evs[i])
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
     stage_ms = [float(np.mean([e[s].elapsed_time(e[s + 1]) for e in evs])) for s in range(NSTAGE)]
     state["n_voxels"] = int(state["n_voxels_dev"].reshape(-1)[0])
     assert tuple(state["lidar_bev"].shape) == (B, 256, 180, 180)
@@ -1043,11 +1069,12 @@ def main():
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t) / n * 1e3
+        with quiet_gc():
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
 
     def kernel_ms(fn, n=20, warm=3):
         for _ in range(warm):
@@ -1242,6 +1269,7 @@ def main():
                             f"[{B},256,180,180]. bev_pool rank/sort/CSR precompute cached per calibration.",
                 "frames_per_step_per_gpu": B,
                 "frames_per_step": frames_per_step,
+                "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention; see quiet_gc)",
                 "parallelism": f"frames sharded over {world} rank(s), one process per GPU, no data-path collective"
                                + (f"; torch.distributed backend nccl (= RCCL) world size {world}" if world > 1 else ""),
                 "per_rank": per_rank,
