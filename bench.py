@@ -1001,6 +1001,13 @@ def main():
         if ev:
             ev[4].record()
 
+    # --overlap voxel: where the voxelizer's stream joins.  Several frames per step: in front of bev_pool — the voxelizer (0.3-0.5 ms
+    # beside the camera kernels) outlasts the raster + fused pooling stages by a few tens of microseconds since the raster got faster,
+    # and bev_pool's roofline figure is that of a kernel running alone (1.09 -> 1.03 ms; the wait shows in the fused pooling stage).
+    # One or two frames: in front of the encoder — the voxelizer (0.12 ms) is LONGER than the two camera stages, and bev_pool is
+    # the only thing left to hide it under (0.93-0.96 against 1.02-1.03 ms per single-frame step).
+    early_join = overlap_voxel and B >= 4
+
     def step(ev=None):
         if overlap_pipe:
             return step_pipeline(ev)
@@ -1020,13 +1027,16 @@ def main():
         if ev:
             ev[1].record()
         plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)      # camera: depth (x) context -> BEV
+        if early_join:
+            main_stream.wait_stream(head_stream)                          # join: the voxelizer has finished before bev_pool starts
         if ev:
             ev[2].record()
         plan.launch_forward(feats, bev)                                   # the API-level bev_pool op (one kernel; roofline)
         if ev:
             ev[3].record()
         if overlap_head:
-            main_stream.wait_stream(head_stream)                          # join
+            if not early_join:
+                main_stream.wait_stream(head_stream)                      # join
             graph_tail.replay()                                           # LiDAR: the 21 convolutions + dense tail
         elif overlap_lidar:
             main_stream.wait_stream(head_stream)                          # join: what is left of the LiDAR branch
@@ -1183,7 +1193,7 @@ def main():
                 plan1.launch_fused(depth1.reshape(-1), ctx1, dbins, fh, fw, out=fused1)
                 plan1.launch_forward(feats1, bev1)
                 if overlap_voxel:
-                    main_stream.wait_stream(head_stream)
+                    main_stream.wait_stream(head_stream)      # one frame: the join sits in front of the encoder (see early_join)
                 g1.replay()
 
             def lidar1_alone():
@@ -1289,8 +1299,10 @@ def main():
                 "overlap": ("pipeline: bev_pool first with the voxelizer beside it (second HIP stream), then depth raster + fused pooling with "
                             "the rulebook chain beside them, then the convolutions alone (stage_ms in the canonical order; `stages` names "
                             "the execution order)") if overlap_pipe else
-                           ("voxel: the voxelizer on a second HIP stream beside the depth raster / fused pooling stages (finished before "
-                            "bev_pool starts); the encoder, rulebook chain included, follows after the join") if overlap_voxel else
+                           ("voxel: the voxelizer on a second HIP stream beside the depth raster / fused pooling stages; "
+                            + ("the join sits in front of bev_pool, which runs alone; " if early_join else
+                               "the join sits in front of the encoder (1-3 frames per step: the voxelizer outlasts the two camera stages); ")
+                            + "the encoder, rulebook chain included, follows") if overlap_voxel else
                            ("head: voxelization + rulebook chain on a second HIP stream beside the camera stages (the camera stage times, "
                             "bev_pool's roofline figure included, are measured WITH that concurrency)") if overlap_head else
                            ("lidar: the whole LiDAR branch on a second HIP stream beside the camera stages (stage times overlap: the last "

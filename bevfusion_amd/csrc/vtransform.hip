@@ -171,6 +171,29 @@ __global__ __launch_bounds__(256) void depth_raster_batch_packed_kernel(RasterBa
     atomicMax(&packed[(((size_t)b * a.ncam + c) * a.ih + row) * a.iw + col], raster_pack(i, dist));
 }
 
+// The same with one thread per POINT and blockIdx.y = sample: the thread walks the cameras, so sample and camera are uniform across
+// the wave and the ~45 matrix words of a projection come through scalar loads instead of 45 per-lane loads per (point, camera)
+// pair (125 us per 8 x 310 k points x 6 cameras were mostly those loads).  Same arithmetic per pair; the 64-bit maximum does
+// not depend on the order the pairs arrive in.
+__global__ __launch_bounds__(256) void depth_raster_batch_points_kernel(RasterBatch rb, unsigned long long* __restrict__ packed) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rb.n[b]) return;
+  RasterArgs a;
+  a.points = rb.points[b];
+  a.aug_inv_rot = rb.aug_inv_rot + (size_t)b * 9;
+  a.aug_trans = rb.aug_trans + (size_t)b * rb.trans_stride;
+  a.lidar2image = rb.lidar2image + (size_t)b * rb.ncam * 16;
+  a.img_aug = rb.img_aug + (size_t)b * rb.ncam * 16;
+  a.n = rb.n[b]; a.nfeat = rb.nfeat; a.ncam = rb.ncam; a.ih = rb.ih; a.iw = rb.iw;
+  for (int c = 0; c < rb.ncam; ++c) {
+    int row, col;
+    float dist;
+    if (project(a, i, c, row, col, dist))
+      atomicMax(&packed[(((size_t)b * a.ncam + c) * a.ih + row) * a.iw + col], raster_pack(i, dist));
+  }
+}
+
 struct GeomArgs {
   const float* frustum;        // [D*fH*fW, 3] (u, v, d)
   const float* post_rot_inv;   // [ncam_total, 3, 3]  inverse(img_aug[:3,:3])
@@ -373,8 +396,16 @@ static int depth_raster_batch(const float* const* points, const int* num_points,
     rb.nfeat = num_features; rb.ncam = ncam; rb.ih = ih; rb.iw = iw; rb.trans_stride = trans_stride;
     const long long total = (long long)rb.start[rb.batch] * ncam;
     if (total == 0) continue;
-    dim3 grid(cdiv(total, 256)), block(256);
-    depth_raster_batch_packed_kernel<<<grid, block, 0, stream>>>(rb, packed + (size_t)b0 * per);
+    static const bool by_pairs = getenv("BEVAMD_RASTER_BY_PAIRS") && getenv("BEVAMD_RASTER_BY_PAIRS")[0] == '1';   // tuning: rounds 2-3
+    if (by_pairs) {
+      dim3 grid(cdiv(total, 256)), block(256);
+      depth_raster_batch_packed_kernel<<<grid, block, 0, stream>>>(rb, packed + (size_t)b0 * per);
+    } else {
+      int nmax = 0;
+      for (int j = 0; j < rb.batch; ++j) nmax = rb.n[j] > nmax ? rb.n[j] : nmax;
+      dim3 grid(cdiv(nmax, 256), rb.batch), block(256);
+      depth_raster_batch_points_kernel<<<grid, block, 0, stream>>>(rb, packed + (size_t)b0 * per);
+    }
     BEVAMD_LAUNCH_CHECK("depth_raster_batch_packed");
   }
   const size_t npix = per * batch, ub = (npix + 255) / 256;

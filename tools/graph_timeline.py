@@ -28,7 +28,8 @@ def main():
     rows = db.execute(f"select {sel} from kernels order by start").fetchall()
     print("# columns of `kernels`:", ", ".join(cols))
     # step boundaries: the packed raster kernel runs once per step
-    marks = [i for i, r in enumerate(rows) if "depth_raster_batch_packed" in r[0] or "depth_raster_batch_winner" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "depth_raster_batch_packed" in r[0] or "depth_raster_batch_points" in r[0]
+             or "depth_raster_batch_winner" in r[0]]
     if len(marks) < back + 1:
         print("not enough steps in the trace")
         return
