@@ -41,6 +41,9 @@ class NotThisCall(Exception):
 
 # How many convolutions ahead of the feature pass the rulebook chain is issued (see _Chain); -1: the whole chain up front.
 _CHAIN_LOOKAHEAD = int(os.environ.get("BEVAMD_SPCONV_CHAIN_LOOKAHEAD", "4"))
+# hold each strided layer's products behind the convolutions issued so far (see _Chain.advance)
+# (measured, off by default: 4.90 / 4.93 against 4.94 / 4.95 ms per 8-frame step, 0.98 against 0.96 ms on one frame)
+_CHAIN_HOLD = os.environ.get("BEVAMD_SPCONV_CHAIN_HOLD", "0") == "1"
 # skip a wait on a geometry-stream event the main stream is already ordered behind (tuning switch)
 _DEDUPE_WAITS = os.environ.get("BEVAMD_SPCONV_DEDUPE_WAITS", "1") != "0"
 _GEOM_STREAMS = {}
@@ -917,6 +920,8 @@ class _Chain:
 
     def __init__(self, enc, lvl, lookahead):
         mods = _chain_modules(enc)
+        self.strided = [not m.subm for m in mods]
+        self.main = torch.cuda.current_stream(lvl.device)
         self.pos = {id(m): i for i, m in enumerate(mods)}
         self.steps = _geometry_steps(enc, lvl)
         self.issued = 0
@@ -933,6 +938,14 @@ class _Chain:
         try:
             with torch.cuda.stream(self.gstream):
                 while self.issued <= upto and self.issued < self.total:
+                    if _CHAIN_HOLD and self.issued > 0 and self.strided[self.issued]:
+                        # The products of a strided layer (the next level's active set and everything built on it) start behind the
+                        # convolutions issued so far: they are not needed before the NEXT level's layers, and kept out from under
+                        # the layers they used to run beside — the strided layer of the level before (16 -> 32: 248 us beside the
+                        # level-3 set construction, 133 us alone); they land beside the first wide layers of the next level instead.
+                        ev = torch.cuda.Event()
+                        ev.record(self.main)
+                        self.gstream.wait_event(ev)
                     next(self.steps)
                     self.issued += 1
         finally:
