@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: the artefacts that go into profiles/ — whole suite, default bench line, kernel-trace stats, step timelines (8 frames, 1
+# the artefacts of a round that go into profiles/ (names carry r04: bump per round) — — whole suite, default bench line, kernel-trace stats, step timelines (8 frames, 1
 # frame), per-kernel PMC of the inference step, per-layer convolution profile, bev_pool traffic, train-step traces
 mkdir -p gpurun_out
 export TMPDIR=/tmp
