@@ -487,7 +487,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_seg_kernel(
 }
 
 // ---- one-sweep passes of the segmented sort ------------------------------------------------------------------------------
-// Three launches per pass (tile histograms, their scan in two launches... four with it, a scatter that ranks the tile AGAIN) become
+// The four launches of a pass (tile histograms, their scan in two launches, a scatter that ranks the tile AGAIN) become
 // one: the scatter kernel has its tile's digit counts the moment it has ranked the tile; what it lacks is the sum of the
 // counts of the tiles BEFORE it in its segment — obtained by look-back over the words those tiles publish (single_pass.h) — and
 // the digit totals of the whole segment, which depend only on the keys, not on their order, and are therefore counted for ALL
