@@ -122,6 +122,7 @@ _SIGNATURES = {
     "bevamd_radix_sort_workspace_bytes": (Z, [Z]),
     "bevamd_radix_sort_pairs_u32": (I, [P, P, P, P, Z, I, P, Z, P]),
     "bevamd_radix_sort_segmented_workspace_bytes": (Z, [P, I]),
+    "bevamd_radix_sort_segmented_lanes": (I, [P, I, P, P]),
     "bevamd_radix_sort_pairs_u32_segmented": (I, [P, P, P, P, P, I, I, P, Z, P]),
 }
 

@@ -960,6 +960,21 @@ int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* 
   return bevamd::radix_sort_pairs_u32(keys_in, vals_in, keys_out, vals_out, n, nbits, ws, ws_bytes,
                                       (hipStream_t)stream);
 }
+/* host-only: how the one-sweep passes deal the tiles of `nseg` segments to their lanes — tile_begin[nseg + 1] (first tile of every
+ * segment), lane_begin[9] (first tile of every lane; lanes own whole segments), returns the lane count (8 from 8 segments on,
+ * else 1) or a negative error code.  For tests of the partition (no GPU needed). */
+int bevamd_radix_sort_segmented_lanes(const int* counts, int nseg, unsigned* tile_begin, unsigned* lane_begin) {
+  bevamd::SortSegs sg;
+  if (!counts || !tile_begin || !lane_begin) {
+    bevamd::set_error("radix_sort_segmented_lanes: null argument");
+    return -BEVAMD_ERR_INVALID_ARG;
+  }
+  int rc = bevamd::sort_segs_init(sg, counts, nseg);
+  if (rc) return -rc;
+  for (int s = 0; s <= nseg; ++s) tile_begin[s] = sg.blk[s];
+  for (int x = 0; x <= 8; ++x) lane_begin[x] = sg.lane_blk[x];
+  return sg.lanes;
+}
 size_t bevamd_radix_sort_segmented_workspace_bytes(const int* counts, int nseg) {
   bevamd::SortSegs sg;
   if (!counts || bevamd::sort_segs_init(sg, counts, nseg) != BEVAMD_OK) return 0;

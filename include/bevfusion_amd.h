@@ -587,6 +587,9 @@ int bevamd_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, uint32_t* 
  * own by the launches of one sort: one digit-count pass over the keys + ONE launch per radix pass (one-sweep: tile offsets by
  * look-back; BEVAMD_SORT_ONESWEEP=0 / BEVAMD_SINGLE_PASS=0: histogram + scan + scatter launches per pass) */
 size_t bevamd_radix_sort_segmented_workspace_bytes(const int* counts, int nseg);
+/* host-only: the tiles of the segments (tile_begin[nseg + 1]) and how the one-sweep passes deal them to their lanes
+ * (lane_begin[9]: whole segments per lane); returns the lane count (8 from 8 segments on, else 1), negative on error */
+int bevamd_radix_sort_segmented_lanes(const int* counts, int nseg, unsigned* tile_begin, unsigned* lane_begin);
 int bevamd_radix_sort_pairs_u32_segmented(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                                           const int* counts, int nseg, int nbits, void* ws, size_t ws_bytes, void* stream);
 
