@@ -239,23 +239,104 @@ def dry_run_train(args, rank, world, frame_ids):
             "dry_run": True}), flush=True)
 
 
-def stored_layer_profile():
-    """Per-layer counter figures of the 21 convolutions from the newest committed rocprofv3 run (profiles/rNN_spconv_layers.json,
-    written by tools/spconv_layers_profile.py): in-graph microseconds from a kernel trace of the replayed step, HBM bytes from the
-    FETCH_SIZE / WRITE_SIZE passes next to the ideal and metadata bytes, L2 hit rate, MFMA busy.  A stored profile of an
-    8-frame step, not measured inside this run."""
-    import glob
+LINE_LIMIT = 4096   # bytes of the ONE JSON line on stdout; tests/test_bench_launch.py hard-fails above 8192
 
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_spconv_layers.json")))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as fh:
-            prof = json.load(fh)
-    except (OSError, ValueError):
-        return None
-    prof["source"] = os.path.join("profiles", os.path.basename(files[-1])) + " (stored profile, not measured in this run)"
-    return prof
+
+def _r(v, sig=5):
+    """floats to `sig` significant digits (the line is for parsing, the side file keeps full precision)"""
+    if isinstance(v, float):
+        v = float(f"{v:.{sig}g}")
+        return int(v) if abs(v) >= 1e6 and v == int(v) else v
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def compact_line(res, side_file=None):
+    """The ONE line the driver parses, from the full result `res` (which goes to the side file): the contract keys, the
+    roofline of the dominant kernel, the CPU baseline's figures, the secondary measurements as bare numbers.  No per-layer tables,
+    no thread sweeps, no prose notes (round 4's 23-KB line left BENCH_r04.parsed null).  Pure function: tested on the CPU."""
+    cfg = res.get("config") or {}
+    out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data")}
+    per_rank = cfg.get("per_rank") or []
+    ms = [r["ms_per_step"] for r in per_rank if isinstance(r, dict) and "ms_per_step" in r]
+    out["config"] = {k: cfg[k] for k in ("workload", "frames_per_step", "frames_per_step_per_gpu", "rccl_ranks", "stage_ms", "overlap",
+                                         "inputs", "hip_graph", "gradient_allreduce") if k in cfg}
+    if ms:
+        out["config"]["per_rank_ms_per_step"] = {"min": min(ms), "max": max(ms)}
+    rf = res.get("roofline")
+    if rf:
+        out["roofline"] = {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                  "algorithmic_bytes_per_launch", "kernel_ms", "measured") if k in rf}
+    else:
+        out["roofline"] = None
+    cb = res.get("cpu_baseline")
+    if cb:
+        keep = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "seconds_per_frame", "bev_pool_quickcumsum_ms",
+                                       "bev_pool_quickcumsum_threads", "voxelize_restated_ms", "voxelize_reference_cubic_ms")
+                if k in cb}
+        if "bev_pool_quickcumsum_spread" in cb:
+            keep["spread"] = cb["bev_pool_quickcumsum_spread"]
+        if "encoder_one_rulebook_per_stage_s" in cb:
+            keep["encoder_s"] = cb["encoder_one_rulebook_per_stage_s"]
+        keep["sample"] = cb.get("sample_short") or (cb.get("sample") or "")[:200]
+        out["cpu_baseline"] = keep
+    else:
+        out["cpu_baseline"] = None
+    ex = res.get("extra")
+    if ex:
+        e = {}
+        g = lambda name, key: (ex.get(name) or {}).get(key)
+        e["product_step_ms"] = g("product_step", "ms_per_step")
+        e["product_frames_per_s"] = g("product_step", "frames_per_s")
+        e["batch1_ms"] = g("batch1_step", "ms_per_step")
+        e["batch1_lidar_branch_ms"] = g("batch1_step", "lidar_branch_ms")
+        e["lidar_branch_alone_ms"] = g("lidar_branch_alone", "ms")
+        e["bf16_frac"] = g("bev_pool_bf16_features", "frac")
+        e["bf16_kernel_ms"] = g("bev_pool_bf16_features", "kernel_ms")
+        e["train_amp_ms"] = g("train_step_amp", "ms_per_step")
+        e["train_amp_frames"] = g("train_step_amp", "frames")
+        e["train_amp_bev_pool_bwd_frac"] = g("train_step_amp", "bev_pool_bwd_frac")
+        e["fused_pool_alone_ms"] = g("fused_pool", "alone_ms")
+        e["fused_pool_rigged_ms"] = g("fused_pool", "rigged_ms")
+        e["kernel_nodes"] = (ex.get("lidar_graph") or {}).get("kernel_nodes")
+        for name in ("batch1_step", "train_step_amp", "fused_pool"):
+            if (ex.get(name) or {}).get("error"):
+                e[name + "_error"] = ex[name]["error"][:120]
+        out["extra"] = {k: v for k, v in e.items() if v is not None}
+    rs = res.get("roofline_spconv")
+    if rs:
+        out["roofline_spconv"] = {k: rs.get(k) for k in ("total_us", "total_gflop", "tflops", "frac_mfma_peak", "n_layers") if k in rs}
+    if side_file:
+        out["full_result"] = side_file
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:           # never again an unparseable line: shed the optional parts, keep the contract
+        for k in ("roofline_spconv", "extra"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    return line
+
+
+def emit(res):
+    """Rank 0: full result -> profiles/bench_last_full.json (and gpurun_out/ when it exists, so that it travels back from a gpurun
+    visit), compact line -> stdout."""
+    side = None
+    for d in ("profiles", "gpurun_out"):
+        p = os.path.join(ROOT, d)
+        if os.path.isdir(p):
+            try:
+                with open(os.path.join(p, "bench_last_full.json"), "w") as fh:
+                    json.dump(res, fh, indent=1)
+                side = side or os.path.join(d, "bench_last_full.json")
+            except OSError:
+                pass
+    print(compact_line(res, side), flush=True)
 
 
 class quiet_gc:
@@ -531,6 +612,8 @@ def cpu_baseline_worker(tmp):
         parts.append("SparseEncoder: reference CPU build not available, stage omitted")
         total, kind = t_bev + t_vox, "port"
     out = dict(value=1.0 / total, unit="frames/s", cores=physical, kind=kind,
+               sample_short=f"ONE frame, stage by stage, child process bound to cores: QuickCumsum bev_pool (torch CPU, {threads} thr) "
+                            f"+ hard voxelize (serial C) + SparseEncoder (reference CPU functors, {physical} thr)",
                sample="one frame, stage by stage (BASELINE.md §3 protocol), in a child process with OMP_PLACES=cores OMP_PROC_BIND=close: "
                       + "; ".join(parts), seconds_per_frame=total,
                bev_pool_quickcumsum_ms=t_bev * 1e3, bev_pool_quickcumsum_runs_ms=[t * 1e3 for t in bev_runs],
@@ -731,7 +814,7 @@ def main():
     if args.mode == "train-step":
         res = train_step(args, rank, world, frame_ids, dev)
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            emit(res)
         if world > 1:
             import torch.distributed as dist
 
@@ -834,8 +917,8 @@ def main():
                     "N_in*Cin*2 + pairs*8 + K*Cin*Cout*2 + N_out*Cout*2 (SURVEY.md 8d). Peaks: 2.5 PFLOP/s dense fp16 MFMA, 8 TB/s. "
                     "The op is neither: rows live in L2 and 133 GFLOP/frame is < 0.1 ms of MFMA — fractions are for orientation.",
             "total_us": tot_us, "total_gflop": tot_gf, "tflops": tot_gf * 1e3 / tot_us, "frac_mfma_peak": tot_gf * 1e3 / tot_us / 2500.0,
+            "n_layers": len(layers),
             "layers": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in l.items()} for l in layers],
-            "stored_profile": stored_layer_profile(),
         }
 
     overlap_head = args.overlap == "head" and sp_dtype != torch.float32 and not args.no_graph
@@ -1279,6 +1362,9 @@ def main():
                             f"[{B},256,180,180]. bev_pool rank/sort/CSR precompute cached per calibration.",
                 "frames_per_step_per_gpu": B,
                 "frames_per_step": frames_per_step,
+                "inputs": "synthetic, resident in HBM; ONE calibration shared by all frames and ranks, camera rig without pitch/roll "
+                          "(the easy case of the column pooling: extra.fused_pool_rigged_ms times a pitched/rolled rig), the same "
+                          "point clouds every step (graph replay on static buffers)",
                 "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention; see quiet_gc)",
                 "parallelism": f"frames sharded over {world} rank(s), one process per GPU, no data-path collective"
                                + (f"; torch.distributed backend nccl (= RCCL) world size {world}" if world > 1 else ""),
@@ -1337,7 +1423,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(inp, pts_np, cfg, B, D, H, W)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+        emit(res)
 
     if world > 1:
         import torch.distributed as dist

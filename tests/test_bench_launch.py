@@ -84,3 +84,86 @@ def test_cpu_share_of_a_rank():
     # no topology: an even contiguous split; more ranks than CPUs still yields a non-empty share
     assert [cpus_for_rank(r, 2, list(range(8))) for r in range(2)] == [[0, 1, 2, 3], [4, 5, 6, 7]]
     assert cpus_for_rank(5, 8, [0, 1, 2]) == [2] and cpus_for_rank(0, 1, [3, 4]) == [3, 4]
+
+
+# ---- the ONE line the driver parses (a 23-KB line left BENCH_r04.parsed null) --------------------------------------
+CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config"}
+
+
+def _fat_result():
+    """a full result at least as large as round 4's: 21-layer tables, thread sweeps with raw runs, prose notes, 8 ranks"""
+    layers = [dict(layer=f"subm 64->64 K=27 #{i}", kernel="spconv_slabr_kernel<1, 64, 64, 4, 4, 2, 2, 168>", variant=2324410 + i,
+                   rows_in=2075436, rows_out=2075436, pairs=29641022, us=203.123456, gflop=126.123456, tflops=612.3456,
+                   frac_mfma_peak=0.2491234, useful_mfma_fraction=0.52, ideal_mb=502.8393, note="x" * 200) for i in range(21)]
+    return {
+        "metric": "frames/sec of the BEVFusion C+L hot path (6x256x704 cameras -> 360x360/180x180 BEV, ~310k LiDAR points); bev_pool HBM GB/s in roofline",
+        "value": 1624.123456789, "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 4.9258123456,
+        "ms_per_frame": 0.6157, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (bev_pool acc, voxelize) + fp16/f32-acc (sparse conv)", "data": "synthetic",
+        "config": {"workload": "w" * 600, "frames_per_step_per_gpu": 8, "frames_per_step": 64, "inputs": "i" * 300, "host_gc": "g" * 100,
+                   "parallelism": "p" * 100, "rccl_ranks": 8, "stages": ["s" * 80] * 4,
+                   "per_rank": [dict(rank=r, frames=8, ms_per_step=4.9 + 0.01 * r, frames_per_s=1600.0,
+                                     cpu_binding=dict(first=16 * r, last=16 * r + 15, n=16, source="sysfs")) for r in range(8)],
+                   "stage_ms": dict(depth_raster=0.114361234, fused_depth_context_pool=0.48084, bev_pool=1.0317, lidar_branch=3.2781),
+                   "camera_branch": {"note": "n" * 400}, "overlap": "o" * 300, "hip_graph": True,
+                   "fused_depth_context_bev": {"note": "n" * 300}},
+        "extra": {"product_step": dict(ms_per_step=3.87, frames_per_s=2065.7, frames=8, note="n" * 200),
+                  "lidar_graph": dict(nodes=60, kernel_nodes=60), "lidar_branch_alone": dict(ms=3.52, note="n" * 100),
+                  "bev_pool_bf16_features": dict(kernel_ms=0.61, frac=0.5425, note="n" * 100),
+                  "batch1_step": dict(ms_per_step=0.936, lidar_branch_ms=0.77, note="n" * 200),
+                  "train_step_amp": dict(ms_per_step=23.4, frames=4, bev_pool_bwd_frac=0.58, stage_ms={f"s{i}": 1.0 for i in range(8)}),
+                  "fused_pool": dict(alone_ms=0.25, rigged_ms=0.31), "wall_s": 25.0},
+        "roofline_spconv": {"note": "n" * 500, "total_us": 3143.276, "total_gflop": 1296.78, "tflops": 412.5, "frac_mfma_peak": 0.165,
+                            "n_layers": 21, "layers": layers},
+        "roofline": {"kernel": "bev_pool_fwd_cells_vec_kernel", "bound": "hbm", "achieved": 4834.9123, "peak": 8000.0, "unit": "GB/s",
+                     "frac": 0.60437, "traffic": 5672082986.666, "traffic_source": "t" * 300, "algorithmic_bytes_per_launch": 4988319168,
+                     "kernel_ms": 1.0317},
+        "cpu_baseline": {"value": 0.0571, "unit": "frames/s", "cores": 128, "kind": "reference", "sample": "s" * 900,
+                         "sample_short": "ONE frame, stage by stage", "seconds_per_frame": 17.5, "bev_pool_quickcumsum_ms": 481.7,
+                         "bev_pool_quickcumsum_runs_ms": [480.0] * 5, "bev_pool_quickcumsum_spread": 0.03,
+                         "bev_pool_quickcumsum_threads": 4,
+                         "bev_pool_quickcumsum_thread_sweep_one_camera": [dict(threads=t, median_ms=80.0, runs_ms=[80.0] * 3) for t in (4, 8, 16, 32, 64, 128)],
+                         "voxelize_restated_ms": 10.9, "voxelize_reference_cubic_ms": 238.8, "encoder_one_rulebook_per_stage_s": 17.0},
+    }
+
+
+def test_the_driver_line_is_compact_and_complete():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    full = _fat_result()
+    assert len(json.dumps(full)) > 15000                               # the shape that broke the driver's parser
+    line = bench.compact_line(full, "profiles/bench_last_full.json")
+    assert "\n" not in line and len(line) <= bench.LINE_LIMIT <= 4096, len(line)
+    res = json.loads(line)
+    assert CONTRACT_KEYS <= set(res)
+    assert res["value"] == 1624.1 and res["n_gpus"] == 8 and res["ms_per_step"] == 4.9258
+    assert set(res["config"]) >= {"workload", "frames_per_step", "rccl_ranks", "stage_ms", "overlap", "per_rank_ms_per_step"}
+    assert res["config"]["per_rank_ms_per_step"] == {"min": 4.9, "max": 4.97}
+    assert set(res["roofline"]) == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                    "kernel_ms"}
+    assert res["roofline"]["frac"] == 0.60437 and res["roofline"]["traffic"] == 5672100000
+    assert {"value", "unit", "cores", "kind", "sample", "seconds_per_frame", "bev_pool_quickcumsum_ms", "spread", "encoder_s"} <= set(res["cpu_baseline"])
+    assert {"product_step_ms", "batch1_ms", "bf16_frac", "train_amp_ms", "fused_pool_rigged_ms"} <= set(res["extra"])
+    assert set(res["roofline_spconv"]) == {"total_us", "total_gflop", "tflops", "frac_mfma_peak", "n_layers"}
+    assert res["full_result"] == "profiles/bench_last_full.json"
+    assert "\"layers\"" not in line and "thread_sweep" not in line and "stored_profile" not in line
+    # a pathological workload string cannot push the line over either: the optional blocks are shed, the contract stays
+    full["config"]["workload"] = "w" * 3000
+    res = json.loads(bench.compact_line(full))
+    assert CONTRACT_KEYS <= set(res) and res["roofline"] and res["cpu_baseline"]
+    # no stored (not-measured-in-this-run) profile is pulled into the live line any more
+    assert not hasattr(bench, "stored_layer_profile")
+
+
+def test_dry_run_lines_stay_below_the_hard_limit():
+    for flags in (("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"),
+                  ("--mode", "train-step", "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--global-batch", "32")):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env,
+                           timeout=300, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) < 8192, [len(ln) for ln in lines]
+        assert CONTRACT_KEYS <= set(json.loads(lines[0]))
