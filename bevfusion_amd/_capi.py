@@ -36,6 +36,7 @@ _SIGNATURES = {
     "bevamd_bev_pool_fused_schedule": (I, [P, P, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
     "bevamd_bev_pool_fused_forward_scheduled": (I, [P, P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_fused_columns_supported": (I, [I, I, I, I]),
+    "bevamd_bev_pool_fused_backward_columns_supported": (I, [I, I, I, I]),
     "bevamd_bev_pool_fused_columns_workspace_bytes": (Z, [I, I]),
     "bevamd_bev_pool_fused_columns_count": (I, [P, I, I, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_fused_columns_build": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
@@ -123,6 +124,7 @@ _SIGNATURES = {
     "bevamd_radix_sort_pairs_u32": (I, [P, P, P, P, Z, I, P, Z, P]),
     "bevamd_radix_sort_segmented_workspace_bytes": (Z, [P, I]),
     "bevamd_radix_sort_segmented_lanes": (I, [P, I, P, P]),
+    "bevamd_debug_lds_poison": (I, [ctypes.c_uint32, P]),
     "bevamd_radix_sort_pairs_u32_segmented": (I, [P, P, P, P, P, I, I, P, Z, P]),
 }
 

@@ -396,7 +396,8 @@ class BevPoolPlan:
         d_ctx = torch.empty_like(ctx)
         cop = self.cell_of_point()
         cols = None
-        if _FUSED_MODE == "columns" and self.n > 0 and fh * (c // 4) <= 1024 and c % 4 == 0:
+        if (_FUSED_MODE == "columns" and self.n > 0
+                and lib.bevamd_bev_pool_fused_backward_columns_supported(int(c), int(depth_bins), int(fh), int(fw))):
             cols = self.fused_columns(depth_bins, fh, fw, c, build=not torch.cuda.is_current_stream_capturing())
         if cols is not None:
             # column formulation (csrc/bev_pool_fused_cols.hip): the depth gradient comes back with an image column's values

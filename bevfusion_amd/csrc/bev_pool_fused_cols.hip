@@ -473,7 +473,9 @@ __global__ __launch_bounds__(BWD_THREADS) void bev_fused_bwd_cols_kernel(
           for (int q = 0; q < 4; ++q) {
             const bool ok = d0 + q < D && r[q] >= 0 && r[q] < nr;
             wgt[q] = ok ? wgt[q] : 0.f;
-            gv[q] = ((const float4*)s_g)[(size_t)(ok ? r[q] : 0) * lpr + j];
+            const float4 ld = ((const float4*)s_g)[(size_t)(ok ? r[q] : 0) * lpr + j];
+            // SELECT, not weight 0 alone: a column without a kept point (nr == 0) never loads s_g, and 0 * (stale NaN / Inf) = NaN
+            gv[q] = ok ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -503,7 +505,7 @@ static size_t bwd_cols_lds(int c, int depth_bins, int fh) {
 }
 
 static int cols_shape(int c, int depth_bins, int fh, int fw, ColDims& s, size_t& lds_bytes) {
-  if (c <= 0 || (c & 3) || (c >> 2) > COL_THREADS || fh <= 0 || fh > 32 || fw <= 0 || (fw % COL_WB) || depth_bins <= 0) return 0;
+  if (c <= 0 || (c & 3) || (c >> 2) > 64 || (c >> 2) > COL_THREADS || fh <= 0 || fh > 32 || fw <= 0 || (fw % COL_WB) || depth_bins <= 0) return 0;
   s.D = depth_bins; s.fH = fh; s.fW = fw; s.C = c;
   const int dpad = (depth_bins + 3) / 4 * 4;
   static int dh_max = 0;   // depth bins per tile (tuning: BEVAMD_FUSED_COLS_DH, a multiple of 4; 60 = two tiles for the 118 bins)
@@ -531,6 +533,14 @@ int bevamd_bev_pool_fused_columns_supported(int c, int depth_bins, int fh, int f
   ColDims s;
   size_t lds;
   return cols_shape(c, depth_bins, fh, fw, s, lds);
+}
+
+/* 1 if bevamd_bev_pool_fused_backward_columns takes this shape (its own limits: the (h, channel group) items of d_ctx fit four
+ * per lane, fewer than 65535 runs per column, the column's rows fit LDS); otherwise the caller keeps the point-wise backward. */
+int bevamd_bev_pool_fused_backward_columns_supported(int c, int depth_bins, int fh, int fw) {
+  if (c <= 0 || (c & 3) || fh <= 0 || fh > 32 || fw <= 0 || depth_bins <= 0) return 0;
+  if (fh * (c / 4) > 4 * BWD_THREADS || (long long)depth_bins * fh >= 65535) return 0;
+  return bwd_cols_lds(c, depth_bins, fh) <= 150 * 1024;
 }
 
 /* Column plan, step 1 (static per plan): row masks keep / end [cams * depth_bins * fw] and run_first (exclusive scan of the

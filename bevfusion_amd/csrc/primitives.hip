@@ -931,6 +931,18 @@ int radix_sort_pairs_u32_segmented(uint32_t* keys_a, uint32_t* vals_a, uint32_t*
 }  // namespace bevamd
 
 // ---- C-ABI test hooks for the primitives (used by tests/ only) --------------
+namespace bevamd {
+// test hook: every CU's LDS filled with `pattern` (LDS is not cleared between kernels: a kernel that reads a word it never wrote sees
+// what the previous tenant left) — tests poison it with NaN bits in front of kernels whose partial staging they want to prove harmless
+__global__ __launch_bounds__(1024) void lds_poison_kernel(uint32_t pattern, uint32_t* sink) {
+  extern __shared__ uint32_t lds_words[];
+  const int words = 160 * 1024 / 4;
+  for (int i = threadIdx.x; i < words; i += 1024) lds_words[i] = pattern;
+  __syncthreads();
+  if (lds_words[(threadIdx.x * 37) % words] != pattern && sink) sink[0] = 1;   // keeps the stores alive
+}
+}  // namespace bevamd
+
 extern "C" {
 const char* bevamd_last_error(void) { return bevamd::get_error(); }
 
@@ -999,5 +1011,16 @@ int bevamd_radix_sort_pairs_u32_segmented(uint32_t* keys_in, uint32_t* vals_in, 
     rc = bevamd::device_copy_u32(vals_out, rv, sg.off[nseg], (hipStream_t)stream);
   }
   return rc;
+}
+/* test hook: fill the LDS of every CU with `pattern` (2048 workgroups x 160 KiB). */
+int bevamd_debug_lds_poison(uint32_t pattern, void* stream) {
+  static bool attr = false;
+  if (!attr) {
+    BEVAMD_HIP_CHECK(hipFuncSetAttribute((const void*)bevamd::lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(bevamd::lds_poison_kernel, dim3(2048), dim3(1024), 160 * 1024, (hipStream_t)stream, pattern, (uint32_t*)nullptr);
+  BEVAMD_LAUNCH_CHECK("lds_poison_kernel");
+  return BEVAMD_OK;
 }
 }

@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
     const uint32_t* __restrict__ rowbase, int nfeat, VoxGrid g, uint32_t ncells,
     int max_points, int max_voxels, float* __restrict__ feats, int* __restrict__ coords4,
     int* __restrict__ num_points_per_voxel, uint16_t* __restrict__ rows16, int rows16_dtype, int rows16_pitch,
-    const uint32_t* __restrict__ first_total, int packed, int* __restrict__ counts, int* __restrict__ total) {
+    const uint32_t* __restrict__ first_total, int packed, int* __restrict__ counts, int* __restrict__ total,
+    const int* __restrict__ err_scan /*null or the look-back scans' flag*/, const int* __restrict__ err_sort /*... the one-sweep sort's*/) {
   const VoxRow vr = vox_locate(vb);
   const int b = vr.b;
   // rowbase == null: what vox_counts_batch_kernel computes, here — every thread the first output row of ITS sweep (uniform
@@ -458,7 +459,15 @@ __global__ __launch_bounds__(256) void vox_mean_batch_kernel(
       if (blockIdx.x == 0 && threadIdx.x == 0) counts[q] = (int)c;
       run += c;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && total) *total = (int)run;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (total) *total = (int)run;
+      // a single-pass kernel gave up waiting for a predecessor (bounded spin): the voxels are wrong — say so where every caller
+      // looks: counts = total = -1 (voxel.py raises on the host route; the encoder's first eager call reads its row counts)
+      if ((err_scan && *err_scan) || (err_sort && *err_sort)) {
+        for (int q = 0; q < vb.batch; ++q) counts[q] = -1;
+        if (total) *total = -1;
+      }
+    }
   }
   const uint32_t n = vr.n, j = vr.j;
   const bool in = vr.in;
@@ -558,7 +567,7 @@ static size_t voxelize_batch_ws_bytes(const SortSegs& sg) {
   size_t a = align_up(n * sizeof(uint32_t), 256);
   size_t s1 = radix_sort_segmented_workspace_bytes(sg), s2 = scan_workspace_bytes(n);
   // keys_a, vals_a, keys_b, vals_b, first (scanned in place), rowbase + total, the states of the two single-pass scans
-  return 5 * a + 2 * 256 + 2 * scan_lookback_state_bytes(n) + align_up(s1 > s2 ? s1 : s2, 256);
+  return 5 * a + 3 * 256 + 2 * scan_lookback_state_bytes(n) + align_up(s1 > s2 ? s1 : s2, 256);   // + the scans' error word
 }
 
 }  // namespace bevamd
@@ -738,8 +747,11 @@ int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num
   uint32_t* first = cv.take<uint32_t>(n);
   uint32_t* rowbase = cv.take<uint32_t>(VOX_MAX_BATCH);
   uint32_t* first_total = cv.take<uint32_t>(1);
-  unsigned long long* scan_state = (unsigned long long*)cv.take<char>(2 * scan_lookback_state_bytes(n));
+  // the two look-back scans' states + ONE more word behind them: their error flag (bit 0: a predecessor's word never arrived,
+  // single_pass.h), zeroed with the states by the key kernel and read by the mean kernel
+  unsigned long long* scan_state = (unsigned long long*)cv.take<char>(2 * scan_lookback_state_bytes(n) + 8);
   const size_t scan_state_words = 2 * scan_lookback_state_bytes(n) / 8;
+  int* scan_err = (int*)(scan_state + scan_state_words);
   void* sws = cv.base + cv.off;
   const size_t sws_bytes = ws_bytes - cv.off;
   const int nbits = bits_for((uint64_t)ncells + 1);
@@ -752,7 +764,7 @@ int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num
 
   const dim3 grid(vox_rows_grid(n)), block(256);
   vox_key_batch_kernel<<<grid, block, 0, stream>>>(vbt, num_features, g, ncells, keys_a, vals_a, first, sort_state, sort_words,
-                                                   scan_state, single ? scan_state_words : 0);
+                                                   scan_state, single ? scan_state_words + 1 : 0);
   BEVAMD_LAUNCH_CHECK("vox_key_batch");
   uint32_t *keys_s, *idx_s;
   rc = radix_sort_pairs_u32_segmented(keys_a, vals_a, keys_b, vals_b, sg, nbits, sws, sws_bytes, stream, &keys_s, &idx_s,
@@ -763,16 +775,16 @@ int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num
   uint32_t* surv = order == 1 ? (keys_s == keys_a ? keys_b : keys_a) : nullptr;   // the sort's other key buffer is free from here on
   if (single) {
     unsigned long long* state_b = scan_state + scan_state_words / 2;
-    rc = exclusive_scan_u32_lookback(first, first, n, first_total, scan_state, nullptr, stream);
+    rc = exclusive_scan_u32_lookback(first, first, n, first_total, scan_state, scan_err, stream);
     if (rc) return rc;
     if (order == 1) {
-      sp::scan_lookback_launch(SurvLoad{vbt, keys_s, idx_s, first, ncells, max_voxels}, surv, n, nullptr, state_b, nullptr, stream);
+      sp::scan_lookback_launch(SurvLoad{vbt, keys_s, idx_s, first, ncells, max_voxels}, surv, n, nullptr, state_b, scan_err, stream);
       BEVAMD_LAUNCH_CHECK("vox_survivors_scan");
     }
     vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, surv, nullptr, num_features, g, ncells,
                                                       max_points, max_voxels, feats, coords4, num_points_per_voxel,
                                                       (uint16_t*)rows16, rows16_dtype, rows16_pitch, first_total, packed,
-                                                      counts_dev, total_dev);
+                                                      counts_dev, total_dev, scan_err, sort_state ? (const int*)sort_state + 32 : nullptr);
     BEVAMD_LAUNCH_CHECK("vox_mean_batch");
     return BEVAMD_OK;
   }
@@ -789,7 +801,7 @@ int bevamd_voxelize_mean_batch_rows16(const float* const* points, const int* num
   vox_mean_batch_kernel<<<grid, block, 0, stream>>>(vbt, keys_s, idx_s, first, surv, rowbase, num_features, g, ncells,
                                                     max_points, max_voxels, feats, coords4, num_points_per_voxel,
                                                     (uint16_t*)rows16, rows16_dtype, rows16_pitch, first_total, packed,
-                                                    counts_dev, total_dev);
+                                                    counts_dev, total_dev, nullptr, nullptr);
   BEVAMD_LAUNCH_CHECK("vox_mean_batch");
   return BEVAMD_OK;
 }

@@ -361,6 +361,9 @@ def voxelize_batch(points_list, voxel_size, point_cloud_range, max_num_points, m
         return feats, coords, sizes, counts
 
     cnt = counts.tolist()  # the single host sync of the batch
+    if any(c < 0 for c in cnt):   # a single-pass kernel's bounded spin expired (csrc/single_pass.h): flagged, never silent
+        raise RuntimeError("voxelize_batch: the single-pass sort / scan kernels reported a stalled predecessor tile; "
+                           "results are invalid (set BEVAMD_SINGLE_PASS=0 for the multi-launch kernels)")
     feats = torch.cat([feats[k, : cnt[k]] for k in range(B)], 0)
     coords = torch.cat([coords[k, : cnt[k]] for k in range(B)], 0)
     sizes = torch.cat([sizes[k, : cnt[k]] for k in range(B)], 0)

@@ -386,7 +386,9 @@ class BaseDepthTransform(BaseTransform):
             # one zero-initialised (winner, depth) map per device and size, left zero by every raster (the unpack pass clears what
             # it reads): no fill launch per call — the rasters of a device are issued on one stream at a time (eager calls and
             # the replays of a captured graph included).  A first use under graph capture takes a fresh map and the fill.
-            key = (dev.index, int(wsb))
+            # Keyed by the issuing stream as well: rasters on two streams — an eager call beside a graph replay, two
+            # models — never share a map; a call that fails between scatter and unpack drops its map (it may hold stale words).
+            key = (dev.index, int(wsb), int(torch.cuda.current_stream(dev).cuda_stream))
             ws = _RASTER_MAPS.get(key)
             if ws is None and not torch.cuda.is_current_stream_capturing():
                 ws = _RASTER_MAPS[key] = torch.zeros(wsb, dtype=torch.uint8, device=dev)
@@ -394,6 +396,8 @@ class BaseDepthTransform(BaseTransform):
                 rc = lib.bevamd_depth_raster_batch_zero_ws(ptrs, counts, B, nfeat, _capi.ptr(inv_rot), _capi.ptr(trans), 3,
                                                            _capi.ptr(l2i), _capi.ptr(ia), n_cam, iH, iW, _capi.ptr(depth),
                                                            _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+                if rc != 0:
+                    _RASTER_MAPS.pop(key, None)
             else:
                 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
                 rc = lib.bevamd_depth_raster_batch(ptrs, counts, B, nfeat, _capi.ptr(inv_rot), _capi.ptr(trans), 3, _capi.ptr(l2i),

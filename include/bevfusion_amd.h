@@ -162,6 +162,7 @@ int bevamd_bev_pool_fused_forward_scheduled(const float* depth, const void* ctx,
  * Shapes: c % 4 == 0, fh <= 32, fw % 4 == 0 (bevamd_bev_pool_fused_columns_supported); plans with about as many runs as points
  * (a camera rolled by 90 degrees) should stay on the cell-centric kernels above. */
 int bevamd_bev_pool_fused_columns_supported(int c, int depth_bins, int fh, int fw);
+int bevamd_bev_pool_fused_backward_columns_supported(int c, int depth_bins, int fh, int fw);   /* the backward's own limits */
 size_t bevamd_bev_pool_fused_columns_workspace_bytes(int ncols, int nruns);
 int bevamd_bev_pool_fused_columns_count(const uint32_t* cell_of_point, int n, int depth_bins, int fh, int fw, int b, int d, int h,
                                         int w, uint32_t* keep, uint32_t* end, uint32_t* run_first, uint32_t* total_runs,
@@ -590,6 +591,9 @@ size_t bevamd_radix_sort_segmented_workspace_bytes(const int* counts, int nseg);
 /* host-only: the tiles of the segments (tile_begin[nseg + 1]) and how the one-sweep passes deal them to their lanes
  * (lane_begin[9]: whole segments per lane); returns the lane count (8 from 8 segments on, else 1), negative on error */
 int bevamd_radix_sort_segmented_lanes(const int* counts, int nseg, unsigned* tile_begin, unsigned* lane_begin);
+/* test hook (no reference counterpart): fill the LDS of every CU with `pattern`, so that a test can prove a kernel never consumes
+ * LDS words it did not write (0 * stale NaN in the column backward of the fused pooling). */
+int bevamd_debug_lds_poison(uint32_t pattern, void* stream);
 int bevamd_radix_sort_pairs_u32_segmented(uint32_t* keys_in, uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                                           const int* counts, int nseg, int nbits, void* ws, size_t ws_bytes, void* stream);
 

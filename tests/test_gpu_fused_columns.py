@@ -317,3 +317,48 @@ def test_column_backward_with_more_runs_than_fit_at_once(dev):
             bp._FUSED_MODE = old
         assert float((dd_t.permute(0, 2, 3, 1) - dd_p).abs().max()) <= 1e-4
         assert float((dc - dc_p).abs().max()) <= 1e-4 * (1 + float(dc_p.abs().max()))
+
+
+def test_column_backward_with_dropped_columns_and_poisoned_lds(dev):
+    """an image column without a kept point stages no gradient rows; its d_ctx items used to read LDS row 0 with weight 0
+    (0 * stale NaN = NaN).  Every CU's LDS is filled with NaN bits first; whole columns and whole cameras are dropped."""
+    lib = _capi.load()
+    assert lib.bevamd_bev_pool_fused_backward_columns_supported(80, 118, 32, 88) == 1
+    assert lib.bevamd_bev_pool_fused_backward_columns_supported(256, 118, 32, 88) == 0       # fh * c / 4 > 1024 items
+    assert lib.bevamd_bev_pool_fused_backward_columns_supported(80, 3000, 32, 88) == 0       # >= 65535 runs per column
+    rng = np.random.default_rng(11)
+    B, Dz, H, W = 1, 1, 6, 7
+    cams, D, fh, fw, c = 2, 9, 8, 8, 32
+    n = cams * D * fh * fw
+    coords = np.stack([rng.integers(0, H, n), rng.integers(0, W, n), np.zeros(n, np.int64), np.zeros(n, np.int64)], 1)
+    wcol = np.arange(n) % fw
+    coords[(wcol == 1) | (wcol == 6), 0] = -3                 # image columns w = 1, 6 dropped in both cameras
+    coords[n // 2:, 1] = W + 2                                # ... and the whole second camera
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, Dz, H, W)
+    depth = torch.from_numpy(rng.random((cams, D, fh, fw)).astype(np.float32)).to(dev)
+    ctx = torch.from_numpy(rng.standard_normal((cams * fh * fw, c)).astype(np.float32)).to(dev)
+    gout = torch.from_numpy(rng.standard_normal((B, Dz, H, W, c)).astype(np.float32)).to(dev)
+    cols = plan.fused_columns(D, fh, fw, c, force=True)
+    for pattern in (0x7FC00000, 0x7F800000, 0xFFFFFFFF):      # NaN, +Inf, NaN with every bit set
+        dd_t = torch.full((cams, fw, D, fh), 7.0, device=dev)
+        dc = torch.full_like(ctx, 7.0)
+        _capi.check(lib.bevamd_debug_lds_poison(pattern, _capi.stream_ptr(dev)), "lds_poison")
+        rc = lib.bevamd_bev_pool_fused_backward_columns(_capi.ptr(gout), _capi.ptr(depth), _capi.ptr(ctx), _capi.ptr(cols.keep),
+                                                        _capi.ptr(cols.end), _capi.ptr(plan.cell_of_point()), _capi.ptr(dd_t),
+                                                        _capi.ptr(dc), n, c, D, fh, fw, B, Dz, H, W, _capi.stream_ptr(dev))
+        _capi.check(rc, "bev_pool_fused_backward_columns")
+        assert bool(torch.isfinite(dc).all()) and bool(torch.isfinite(dd_t).all())
+        ok = ((coords[:, 0] >= 0) & (coords[:, 1] < W))
+        gn = gout.cpu().numpy().astype(np.float64)
+        grow = np.zeros((n, c))
+        grow[ok] = gn[0, 0, coords[ok, 0], coords[ok, 1]]
+        p = np.arange(n)
+        pix = (p // (D * fh * fw)) * fh * fw + (p % (D * fh * fw)) % (fh * fw)
+        cn = ctx.cpu().numpy().astype(np.float64)
+        want_dd = (grow * cn[pix]).sum(1).reshape(cams, D, fh, fw)
+        want_dc = np.zeros_like(cn)
+        np.add.at(want_dc, pix, depth.cpu().numpy().reshape(-1, 1).astype(np.float64) * grow)
+        assert np.max(np.abs(dd_t.permute(0, 2, 3, 1).cpu().numpy() - want_dd)) <= 1e-4
+        assert np.max(np.abs(dc.cpu().numpy() - want_dc)) <= 1e-4
+        dropped = want_dc.reshape(cams, fh, fw, c)[:, :, [1, 6]]
+        assert not dropped.any() and not dc.view(cams, fh, fw, c)[:, :, [1, 6]].any() and not dc.view(cams, fh, fw, c)[1].any()
