@@ -153,3 +153,34 @@ def lidar_points(seed=0, sweeps=10, cfg=CL_CONFIG):
     pts = pts[m]
     rng.shuffle(pts, axis=0)
     return np.ascontiguousarray(pts)
+
+
+def rigged_geometry(B, n_cam, D, fh, fw, seed, pitch_deg=1.5, roll_deg=1.0, rot_deg=5.4, flip=True):
+    """[B, n_cam, D, fh, fw, 3] lidar-frame frustum points (float64 restatement of base.py:92-135) of a rig whose cameras are
+    pitched / rolled a little (as mounted cameras are) and whose image augmentation rotates and flips (training-time
+    augmentation, transforms_3d.py:85-118): a column's rows then cross a few BEV cells."""
+    rng = np.random.default_rng(seed)
+    cfg = CL_CONFIG
+    iH, iW = cfg["image_size"]
+    rig = camera_rig(n_cam)
+    ds = np.arange(1.0, 1.0 + 0.5 * D, 0.5)[:D]
+    xs, ys = np.linspace(0, iW - 1, fw), np.linspace(0, iH - 1, fh)
+    fr = np.stack(np.broadcast_arrays(xs[None, None, :], ys[None, :, None], ds[:, None, None]), -1)     # [D, fh, fw, 3]
+    out = np.empty((B, n_cam, D, fh, fw, 3))
+    for b in range(B):
+        for n in range(n_cam):
+            a = math.radians(rng.uniform(-rot_deg, rot_deg))
+            s = 0.48 * rng.uniform(0.9, 1.1)
+            post_rot = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]]) * np.array([s, s, 1.0])
+            if flip and rng.random() < 0.5:
+                post_rot = np.diag([-1.0, 1.0, 1.0]) @ post_rot
+            post_tran = np.array([rng.uniform(-40, 0) + (iW if post_rot[0, 0] < 0 else 0), rng.uniform(-190, -160), 0.0])
+            pr, rr = math.radians(rng.uniform(-pitch_deg, pitch_deg)), math.radians(rng.uniform(-roll_deg, roll_deg))
+            rx = np.array([[1, 0, 0], [0, math.cos(pr), -math.sin(pr)], [0, math.sin(pr), math.cos(pr)]])
+            rz = np.array([[math.cos(rr), -math.sin(rr), 0], [math.sin(rr), math.cos(rr), 0], [0, 0, 1]])
+            c2l = rig["camera2lidar_rots"][n].astype(np.float64) @ rx @ rz
+            pts = (fr - post_tran) @ np.linalg.inv(post_rot).T
+            pts = np.concatenate([pts[..., :2] * pts[..., 2:3], pts[..., 2:3]], -1)
+            pts = pts @ (c2l @ np.linalg.inv(rig["intrins"][n].astype(np.float64))).T + rig["camera2lidar_trans"][n]
+            out[b, n] = pts
+    return out.astype(np.float32)
