@@ -35,3 +35,34 @@ def _built_library():
 
     oracle.build()
     yield
+
+
+_PARITY = {}
+
+
+def record_parity(name, observed, bar):
+    """GPU tests log the error they observed next to the bar they enforce; written at session end to
+    gpurun_out/parity_observed.json (copied to profiles/rNN_parity_observed.json per round)."""
+    e = _PARITY.setdefault(name, dict(observed=0.0, bar=float(bar), n=0))
+    e["observed"] = max(e["observed"], float(observed))
+    e["bar"] = float(bar)
+    e["n"] += 1
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        path = os.path.join(out, "parity_observed.json")
+        old = {}
+        if os.path.exists(path):
+            try:
+                old = json.load(open(path))
+            except (OSError, ValueError):
+                old = {}
+        old.update({k: dict(v, headroom=(v["bar"] / v["observed"] if v["observed"] > 0 else None)) for k, v in _PARITY.items()})
+        with open(path, "w") as fh:
+            json.dump(old, fh, indent=1, sort_keys=True)
