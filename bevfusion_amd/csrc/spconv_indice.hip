@@ -912,7 +912,7 @@ template <int BM, int KIND>
 __global__ __launch_bounds__(BM) void sp_slab_from_index_kernel(const int* __restrict__ indices, int m_cap,
                                                                 const int* __restrict__ m_dev, ConvGeom g, IndexRef ix,
                                                                 int2* __restrict__ hdr, uint16_t* __restrict__ slots,
-                                                                int* __restrict__ status) {
+                                                                int* __restrict__ status, int fmt) {
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   // Launches are sized by capacity (5-14x the live rows at 8 frames): nobody reads a dead block's metadata.  The live blocks
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(BM) void sp_slab_from_index_kernel(const int* __res
         }
         v[k] = r;
       }
-  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+  slab::slab_emit<BM>(v, blk, t, hdr, slots, status, fmt);
 }
 
 // The same from a RANK index with all 26 lookups of a row in flight together.  The generic kernel above compiles to one load, one
@@ -954,7 +954,7 @@ template <int BM>
 __global__ __launch_bounds__(BM) void sp_slab_from_rank_kernel(const int* __restrict__ indices, int m_cap,
                                                                const int* __restrict__ m_dev, ConvGeom g,
                                                                const uint2* __restrict__ words, int2* __restrict__ hdr,
-                                                               uint16_t* __restrict__ slots, int* __restrict__ status) {
+                                                               uint16_t* __restrict__ slots, int* __restrict__ status, int fmt) {
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   const int nblk = (m + BM - 1) / BM, per = (nblk + 7) >> 3;
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(BM) void sp_slab_from_rank_kernel(const int* __rest
     v[k] = r;
   }
   v[13] = live ? row : -1;
-  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+  slab::slab_emit<BM>(v, blk, t, hdr, slots, status, fmt);
 }
 
 
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __re
                                                                  const uint32_t* __restrict__ in_keys,
                                                                  const int* __restrict__ in_xstart, int in_n_cap,
                                                                  int2* __restrict__ hdr, uint16_t* __restrict__ slots,
-                                                                 int* __restrict__ status) {
+                                                                 int* __restrict__ status, int fmt) {
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   const int nblk = (m + BM - 1) / BM, per = (nblk + 7) >> 3;
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(BM) void sp_slab_from_sorted_kernel(const int* __re
     }
   }
   if (SUBM) v[13] = live ? row : -1;
-  slab::slab_emit<BM>(v, blk, t, hdr, slots, status);
+  slab::slab_emit<BM>(v, blk, t, hdr, slots, status, fmt);
 }
 
 }  // namespace bevamd
@@ -1417,7 +1417,10 @@ int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int
   const int k3[3] = {3, 3, 3}, one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
   int rc = make_geom(batch_size, shape, shape, k3, one, zero, nullptr, 1, g);
   if (rc) return rc;
+  const int fmt = slab::fmt_of_code(block_rows);   // upper half: slot format (spconv_slab_meta.h), 0 = raw / implied by 64-row blocks
+  block_rows = slab::rows_of_code(block_rows);
   BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_index: block_rows %d (64 | 128 | 256)", block_rows);
+  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128, "spconv_slab_build_from_index: slot format %d", fmt);
   BEVAMD_REQUIRE(index_kind == INDEX_HASH || index_kind == INDEX_RANK, "spconv_slab_build_from_index: index_kind %d", index_kind);
   BEVAMD_REQUIRE(m_cap >= 0, "spconv_slab_build_from_index: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
@@ -1425,9 +1428,9 @@ int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int
   const IndexRef ix = index_kind == INDEX_HASH ? hash_ref(index, index_n_cap, batch_size) : rank_ref(index);
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;   // a multiple of 8: XCD-contiguous block map
 #define BEVAMD_GO(BM, KIND) \
-  sp_slab_from_index_kernel<BM, KIND><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix, (int2*)hdr, (uint16_t*)slots, status)
+  sp_slab_from_index_kernel<BM, KIND><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix, (int2*)hdr, (uint16_t*)slots, status, fmt)
 #define BEVAMD_GO_RANK(BM) \
-  sp_slab_from_rank_kernel<BM><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix.words, (int2*)hdr, (uint16_t*)slots, status)
+  sp_slab_from_rank_kernel<BM><<<dim3(nblk), dim3(BM), 0, stream>>>(indices, m_cap, m_dev, g, ix.words, (int2*)hdr, (uint16_t*)slots, status, fmt)
   if (block_rows == 64) { if (index_kind == INDEX_HASH) BEVAMD_GO(64, INDEX_HASH); else BEVAMD_GO_RANK(64); }
   else if (block_rows == 128) { if (index_kind == INDEX_HASH) BEVAMD_GO(128, INDEX_HASH); else BEVAMD_GO_RANK(128); }
   else { if (index_kind == INDEX_HASH) BEVAMD_GO(256, INDEX_HASH); else BEVAMD_GO_RANK(256); }
@@ -1479,7 +1482,10 @@ int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, cons
   const int k3[3] = {3, 3, 3};
   int rc = make_geom(batch_size, in_shape, subm ? in_shape : out_shape, k3, stride, padding, nullptr, subm, g);
   if (rc) return rc;
+  const int fmt = slab::fmt_of_code(block_rows);   // upper half: slot format (spconv_slab_meta.h), 0 = raw / implied by 64-row blocks
+  block_rows = slab::rows_of_code(block_rows);
   BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_sorted: block_rows %d (64 | 128 | 256)", block_rows);
+  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128, "spconv_slab_build_from_sorted: slot format %d", fmt);
   BEVAMD_REQUIRE(m_cap >= 0 && in_n_cap >= 0, "spconv_slab_build_from_sorted: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(out_indices && in_index && hdr && slots, "spconv_slab_build_from_sorted: null buffer");
@@ -1487,7 +1493,7 @@ int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, cons
   const int* xstart = (const int*)((const char*)in_index + align_up((size_t)(in_n_cap > 0 ? in_n_cap : 1) * 4, 256));
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows + 7) / 8 * 8;
 #define BEVAMD_GO(BM, SUBM) \
-  sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, in_n_cap, (int2*)hdr, (uint16_t*)slots, status)
+  sp_slab_from_sorted_kernel<BM, SUBM><<<dim3(nblk), dim3(BM), 0, stream>>>(out_indices, m_cap, m_dev, g, keys, xstart, in_n_cap, (int2*)hdr, (uint16_t*)slots, status, fmt)
   if (block_rows == 64) { if (subm) BEVAMD_GO(64, true); else BEVAMD_GO(64, false); }
   else if (block_rows == 128) { if (subm) BEVAMD_GO(128, true); else BEVAMD_GO(128, false); }
   else { if (subm) BEVAMD_GO(256, true); else BEVAMD_GO(256, false); }

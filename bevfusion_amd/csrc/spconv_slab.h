@@ -97,6 +97,9 @@ struct Plan {
   static_assert(CAP % RPI == 0, "CAP must be a whole number of DMA instructions");
   static_assert((CAP + 1) * RB < 65536, "row offsets are 16-bit");
   static_assert(NW >= 2 && NW % 2 == 0, "two DMA roles");
+  // EXPERIMENTS.md B.17, root cause (round 5): metadata for 64-row blocks is written in the filter-stationary kernels' BAKED format
+  // (spconv_slab_meta.h); a kernel that reads raw slots from it is wrong by O(10).  spconv_slabr_kernel decodes it, this one does not.
+  static_assert(BM != BAKED_ROWS, "64-row blocks carry baked slot metadata: not decoded by the LDS-filter kernel");
   static_assert(DX * NX < 60 && WD * NWS < 60, "vmcnt is a 6-bit counter");
 };
 

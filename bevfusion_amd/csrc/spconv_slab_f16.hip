@@ -38,29 +38,34 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
   int n = 0, nr = 0;
   const slab::Shape* s = slab::shapes_of(cin, &n);
   const slab::ShapeR* r = slab::shapes_r_of(cin, &nr);
-  for (int i = 0; s && i < n && i < max_n; ++i) codes[i] = slab::variant_code(s[i]);
-  for (int i = 0; r && i < nr && n + i < max_n; ++i) codes[n + i] = slab::variant_code(r[i]);
-  for (int i = 0; r && i < nr && n + nr + i < max_n; ++i) codes[n + nr + i] = slab::variant_code(r[i]) + (slab::PERSIST_BASE - slab::REGW_BASE);
-  int nf = 0;
-#define BEVAMD_ROW(CAP) if (cin == 32) { if (n + 2 * nr + nf < max_n) codes[n + 2 * nr + nf] = slab::FSTAT_BASE + CAP; ++nf; }
+  int k = 0;
+  auto put = [&](int code) { if (k < max_n) codes[k] = code; ++k; };
+  for (int i = 0; s && i < n; ++i) put(slab::variant_code(s[i]));
+  for (int i = 0; r && i < nr; ++i) put(slab::variant_code(r[i]));
+  for (int i = 0; r && i < nr; ++i)   // persistent twins: plain shapes only (no kernel flags, no 64-row blocks)
+    if (slab::has_persistent_twin(r[i])) put(slab::variant_code(r[i]) + (slab::PERSIST_BASE - slab::REGW_BASE));
+#define BEVAMD_ROW(CAP) if (cin == 32) put(slab::FSTAT_BASE + CAP);
   BEVAMD_SLABF_SHAPES_32(BEVAMD_ROW)
 #undef BEVAMD_ROW
-  return n + 2 * nr + nf;
+  return k;
 }
 
 /* 1 if a voxel set on a [batch, X, Y, Z] grid whose rows are in ascending linear index can use the slab kernels: the input
  * range of a kernel plane is at most block_rows + (Y + 2) * Z + 2 rows, which must fit the 16-bit slots. */
 int bevamd_spconv_slab_grid_ok(const int* shape, int block_rows) {
+  block_rows = slab::rows_of_code(block_rows);
   if (!shape || block_rows <= 0) return 0;
   const long long bound = (long long)block_rows + ((long long)shape[1] + 2) * shape[2] + 2;
   return bound < 0xFFFE;
 }
 
 size_t bevamd_spconv_slab_hdr_bytes(int m_cap, int block_rows) {
+  block_rows = slab::rows_of_code(block_rows);
   if (m_cap <= 0 || block_rows <= 0) return 0;
   return (size_t)((m_cap + block_rows - 1) / block_rows) * slab::PLANES * sizeof(int2);
 }
 size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows) {
+  block_rows = slab::rows_of_code(block_rows);
   if (m_cap <= 0 || block_rows <= 0) return 0;
   return (size_t)((m_cap + block_rows - 1) / block_rows) * 27 * block_rows * sizeof(uint16_t);
 }
@@ -73,17 +78,20 @@ size_t bevamd_spconv_slab_slot_bytes(int m_cap, int block_rows) {
 int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const int* m_dev, int block_rows, void* hdr,
                              void* slots, int* status, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int fmt = slab::fmt_of_code(block_rows);   // upper half: slot format (spconv_slab_meta.h)
+  block_rows = slab::rows_of_code(block_rows);
   BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build: block_rows %d (64 | 128 | 256)", block_rows);
+  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128, "spconv_slab_build: slot format %d", fmt);
   BEVAMD_REQUIRE(m_cap >= 0 && nbr_stride >= m_cap, "spconv_slab_build: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(nbr && hdr && slots, "spconv_slab_build: null buffer");
   const unsigned nblk = (unsigned)((m_cap + block_rows - 1) / block_rows);
   if (block_rows == 64)
-    slab::slab_build_kernel<64><<<dim3(nblk), dim3(64), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);
+    slab::slab_build_kernel<64><<<dim3(nblk), dim3(64), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status, fmt);
   else if (block_rows == 128)
-    slab::slab_build_kernel<128><<<dim3(nblk), dim3(128), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);
+    slab::slab_build_kernel<128><<<dim3(nblk), dim3(128), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status, fmt);
   else
-    slab::slab_build_kernel<256><<<dim3(nblk), dim3(256), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status);
+    slab::slab_build_kernel<256><<<dim3(nblk), dim3(256), 0, stream>>>(nbr, nbr_stride, m_cap, m_dev, (int2*)hdr, (uint16_t*)slots, status, fmt);
   BEVAMD_LAUNCH_CHECK("spconv_slab_build");
   return BEVAMD_OK;
 }

@@ -121,11 +121,11 @@ static inline const Shape* find_shape(int cin, int variant) {
 // ---- register-filter kernels (spconv_slab_regw.h): variant = 1000000 + KC*10000 + MT*1000 + RW*100 + CW*10 + ID ----------
 struct ShapeR { int kc, mt, rw, cw, cap, id; };
 
-template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP>
+template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP, int FLAGS = 0>
 static int run_r(const SlabArgs& sa, hipStream_t stream) {
   typedef PlanR<KC, CIN, NT, MT, RW, CW, CAP> P;
   static_assert(P::BYTES <= 160 * 1024, "LDS plan exceeds the CU");
-  auto kern = &spconv_slabr_kernel<DT, KC, CIN, NT, MT, RW, CW, CAP>;
+  auto kern = &spconv_slabr_kernel<DT, KC, CIN, NT, MT, RW, CW, CAP, FLAGS>;
   static PerDevice pd = {};
   raise_lds_limit(pd, kern, P::BYTES);
   const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
@@ -153,8 +153,10 @@ static int run_p(const SlabArgs& sa, hipStream_t stream) {
 }
 
 #define BEVAMD_SLABR_SHAPES_32(X) X(32, 4, 4, 1, 384, 0) X(32, 2, 4, 1, 192, 0)
-#define BEVAMD_SLABR_SHAPES_64(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 2, 168, 2)
-#define BEVAMD_SLABR_SHAPES_128(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 4, 2, 320, 0)
+// IDs >= 4 carry kernel flags (spconv_slab_regw.h: 8 = baked slot metadata, block_rows code rows | FMT_BAKED128 << 16); (64, 2, 2, 2): 64-row blocks (one frame's
+// level 4 is 188 blocks of 128 rows on 256 CUs), reading the baked metadata the filter-stationary kernels share
+#define BEVAMD_SLABR_SHAPES_64(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 2, 168, 2) X(64, 4, 2, 2, 168, 8)
+#define BEVAMD_SLABR_SHAPES_128(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 2, 184, 8) X(64, 2, 2, 2, 120, 0)
 
 static inline const ShapeR* shapes_r_of(int cin, int* n) {
 #define BEVAMD_ROW(KC, MT, RW, CW, CAP, ID) {KC, MT, RW, CW, CAP, ID},
@@ -171,12 +173,14 @@ static inline const ShapeR* shapes_r_of(int cin, int* n) {
 }
 constexpr int REGW_BASE = 1000000, PERSIST_BASE = 2000000;
 static inline int variant_code(const ShapeR& s) { return REGW_BASE + s.kc * 10000 + s.mt * 1000 + s.rw * 100 + s.cw * 10 + s.id; }
+static inline bool has_persistent_twin(const ShapeR& s) { return (s.id & ~3) == 0 && s.rw * 16 * s.mt != BAKED_ROWS; }
 static inline const ShapeR* find_shape_r(int cin, int variant) {
-  if (variant >= PERSIST_BASE) variant -= PERSIST_BASE - REGW_BASE;   // the persistent kernels are built for the same shapes
+  const bool persistent = variant >= PERSIST_BASE;
+  if (persistent) variant -= PERSIST_BASE - REGW_BASE;   // the persistent kernels are built for the same (plain) shapes
   int n = 0;
   const ShapeR* s = shapes_r_of(cin, &n);
   for (int i = 0; s && i < n; ++i)
-    if (variant_code(s[i]) == variant) return s + i;
+    if (variant_code(s[i]) == variant) return (persistent && !has_persistent_twin(s[i])) ? nullptr : s + i;
   return nullptr;
 }
 // ---- filter-stationary kernels (spconv_slab_fstat.h), 32 -> 32: variant = 4000000 + CAP; 64-row blocks, BAKED slots --
@@ -222,7 +226,8 @@ static inline int block_rows_of(int cin, int variant) {
   if (variant >= FSTAT_BASE) return fstat_built(cin, variant) ? BAKED_ROWS : 0;
   if (variant >= REGW_BASE) {
     const ShapeR* r = find_shape_r(cin, variant);
-    return r ? r->rw * 16 * r->mt : 0;
+    if (!r) return 0;
+    return r->rw * 16 * r->mt + ((r->id & 8) ? (FMT_BAKED128 << FMT_SHIFT) : 0);   // flag 8: baked 128-byte-row slot format
   }
   const Shape* s = find_shape(cin, variant);
   return s ? s->nw * 16 * s->mt : 0;
@@ -269,14 +274,14 @@ int launch_r_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t 
   }
 #define BEVAMD_CODE(KC, MT, RW, CW, ID) (KC * 10000 + MT * 1000 + RW * 100 + CW * 10 + ID)
 #define BEVAMD_CASE32(KC, MT, RW, CW, CAP, ID)                                                                              \
-  if (cin == 32 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 32, 2, MT, RW, CW, CAP>(sa, stream); \
-  if (cin == 32 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 32, 2, MT, RW, CW, CAP>(sa, stream);
+  if (cin == 32 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 32, 2, MT, RW, CW, CAP, ((ID) & ~3)>(sa, stream); \
+  if constexpr (((ID) & ~3) == 0 && RW * 16 * MT != BAKED_ROWS) if (cin == 32 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 32, 2, MT, RW, CW, CAP>(sa, stream);
 #define BEVAMD_CASE64(KC, MT, RW, CW, CAP, ID)                                                                              \
-  if (cin == 64 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 64, 4, MT, RW, CW, CAP>(sa, stream); \
-  if (cin == 64 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 64, 4, MT, RW, CW, CAP>(sa, stream);
+  if (cin == 64 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 64, 4, MT, RW, CW, CAP, ((ID) & ~3)>(sa, stream); \
+  if constexpr (((ID) & ~3) == 0 && RW * 16 * MT != BAKED_ROWS) if (cin == 64 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 64, 4, MT, RW, CW, CAP>(sa, stream);
 #define BEVAMD_CASE128(KC, MT, RW, CW, CAP, ID)                                                                               \
-  if (cin == 128 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 128, 8, MT, RW, CW, CAP>(sa, stream); \
-  if (cin == 128 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 128, 8, MT, RW, CW, CAP>(sa, stream);
+  if (cin == 128 && variant == REGW_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_r<DT, KC, 128, 8, MT, RW, CW, CAP, ((ID) & ~3)>(sa, stream); \
+  if constexpr (((ID) & ~3) == 0 && RW * 16 * MT != BAKED_ROWS) if (cin == 128 && variant == PERSIST_BASE + BEVAMD_CODE(KC, MT, RW, CW, ID)) return run_p<DT, KC, 128, 8, MT, RW, CW, CAP>(sa, stream);
   BEVAMD_SLABR_SHAPES_32(BEVAMD_CASE32)
   BEVAMD_SLABR_SHAPES_64(BEVAMD_CASE64)
   BEVAMD_SLABR_SHAPES_128(BEVAMD_CASE128)

@@ -23,10 +23,21 @@ constexpr int BAKED_ROWS = 64;        // block size that implies the baked forma
 constexpr int BAKED_ROW_BYTES = 64;   // 32 channels of 16 bits
 __host__ __device__ __forceinline__ unsigned baked_entry(unsigned e) { return e * BAKED_ROW_BYTES | (((e >> 2) & 3u) << 4); }
 
+// Round 5: the same idea for the 128-byte staged rows (64 channels) of the register-filter kernels (spconv_slab_regw.h, flag
+// F_BAKED): entry = r*128 | (r & 7) << 4 with r = slot + 1 the LDS row (row 0 = the zero row), 0 = none; the address of a fragment
+// is (entry ^ piece*16) + buffer base = one v_xad_u32.  Requested with a FORMAT CODE in the upper half of `block_rows`
+// (block_rows = rows | FMT_BAKED128 << 16: what bevamd_spconv_slab_block_rows returns for such variants); ranges of more than 510
+// rows keep raw slots and say so in the header (HDR_RAW), like the 64-byte format.
+constexpr int FMT_SHIFT = 16;
+constexpr int FMT_BAKED128 = 1;
+__host__ __device__ __forceinline__ int rows_of_code(int code) { return code & 0xFFFF; }
+__host__ __device__ __forceinline__ int fmt_of_code(int code) { return (code >> FMT_SHIFT) & 0xFF; }
+__host__ __device__ __forceinline__ unsigned baked128_entry(unsigned r) { return r * 128u | ((r & 7u) << 4); }
+
 // One workgroup of BM threads per block; thread t holds the 27 neighbour rows v[] of output row blk*BM + t (-1 = none).
 template <int BM>
 __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, int2* __restrict__ hdr,
-                                          uint16_t* __restrict__ slots, int* __restrict__ status) {
+                                          uint16_t* __restrict__ slots, int* __restrict__ status, int fmt = 0) {
   __shared__ int s_lo[BM / 64][PLANES], s_hi[BM / 64][PLANES];
   const int w = t >> 6;
 #pragma unroll
@@ -55,13 +66,18 @@ __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, in
     int cnt = hi >= 0 ? hi - lo + 1 : 0;
     if (hi < 0) lo = 0;
     if (cnt > 0xFFFE) { cnt = 0xFFFE; overflow = true; }   // cannot happen for rows in linear-index order on grids the host admits
-    const bool baked = BM == BAKED_ROWS && (cnt + 1) * BAKED_ROW_BYTES <= 0xFFFF;
-    if (t == 0) hdr[(size_t)blk * PLANES + j] = make_int2(lo, BM == BAKED_ROWS && !baked ? (int)((unsigned)cnt | HDR_RAW) : cnt);
+    const bool wants128 = fmt == FMT_BAKED128;                 // wave-uniform (kernel argument)
+    const bool wants = wants128 || BM == BAKED_ROWS;
+    const bool baked = wants128 ? (cnt + 1) * 128 <= 0xFFFF : (BM == BAKED_ROWS && (cnt + 1) * BAKED_ROW_BYTES <= 0xFFFF);
+    if (t == 0) hdr[(size_t)blk * PLANES + j] = make_int2(lo, wants && !baked ? (int)((unsigned)cnt | HDR_RAW) : cnt);
 #pragma unroll
     for (int d = 0; d < TAPS; ++d) {
       const int k = j * TAPS + d, x = v[k];
       unsigned s = baked ? 0u : NO_SLOT;
-      if (x >= 0 && x - lo < cnt) s = baked ? baked_entry((unsigned)(x - lo) + 1u) : (unsigned)(x - lo);
+      if (x >= 0 && x - lo < cnt) {
+        const unsigned r = (unsigned)(x - lo) + 1u;
+        s = !baked ? r - 1u : wants128 ? baked128_entry(r) : baked_entry(r);
+      }
       slots[((size_t)blk * 27 + k) * BM + t] = (uint16_t)s;
     }
   }
@@ -72,7 +88,7 @@ __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, in
 template <int BM>
 __global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ nbr, int nbr_stride, int m_cap,
                                                         const int* __restrict__ m_dev, int2* __restrict__ hdr,
-                                                        uint16_t* __restrict__ slots, int* __restrict__ status) {
+                                                        uint16_t* __restrict__ slots, int* __restrict__ status, int fmt) {
   int m = m_dev ? *m_dev : m_cap;
   if (m > m_cap) m = m_cap;
   const int blk = blockIdx.x, t = threadIdx.x, row = blk * BM + t;
@@ -81,7 +97,7 @@ __global__ __launch_bounds__(BM) void slab_build_kernel(const int* __restrict__ 
   int v[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) v[k] = live ? nbr[(size_t)k * nbr_stride + row] : -1;
-  slab_emit<BM>(v, blk, t, hdr, slots, status);
+  slab_emit<BM>(v, blk, t, hdr, slots, status, fmt);
 }
 
 }  // namespace slab

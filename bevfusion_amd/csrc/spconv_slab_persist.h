@@ -36,6 +36,7 @@ struct PlanP {
   static constexpr int OFF_DUMP = OFF_EPI + NW * EpiScratch<NTW>::U4 * 16;
   static constexpr int BYTES = OFF_DUMP + 1024;
   static_assert(WD * NB + NX + NS < 60, "vmcnt is a 6-bit counter");
+  static_assert(RW * 16 * MT != BAKED_ROWS, "64-row blocks carry baked slot metadata (spconv_slab_meta.h): not decoded by the persistent kernel");
   // register budget handed to hipcc (waves per SIMD): what the LDS plan admits, but no more than the accumulators + filter
   // ring leave room for.  Without it the persistent kernels came out 50-80 registers above their one-block twins — one wave per
   // SIMD less — for no use.

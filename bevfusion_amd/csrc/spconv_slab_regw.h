@@ -53,9 +53,20 @@ struct PlanR {
   static_assert(TAPS % (WD + 1) == 0, "register ring must close over a plane");
 };
 
-template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP>
-__global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa) {
+// FLAGS (the bits of a shape's ID above 3; IDs 0-3 only tell equal shapes with different CAP apart):
+//   8  F_BAKED: the slot metadata arrives as LDS byte offsets with the bank swizzle folded in (spconv_slab_meta.h, FMT_BAKED128;
+//      the zero row is LDS row 0, staged row s is row s + 1).  The kernel issues ~47 instructions per 8 MFMAs without it, 22 of
+//      them the VALU arithmetic slot -> (row, swizzle) -> fragment address, and a SIMD starts one instruction of a wave about every
+//      4 cycles: the loop is ISSUE-bound (round 5: predicating the zero-row reads away removed 57 % of the bank-conflict cycles and
+//      made the kernel SLOWER, EXPERIMENTS.md C.2 — it is not the LDS).  With baked entries a fragment address is one v_xad_u32.
+//      A plane whose range does not fit one piece (> CAP rows) or whose header says raw takes the arithmetic path.
+constexpr int F_BAKED = 8;
+template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP, int FLAGS = 0>
+__global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64) ? 2 : 1) void spconv_slabr_kernel(SlabArgs sa) {
   typedef PlanR<KC, CIN, NT, MT, RW, CW, CAP> P;
+  constexpr bool BK = (FLAGS & F_BAKED) != 0;   // baked 128-byte-row metadata
+  static_assert(!BK || KC == 64, "the baked format describes 128-byte staged rows");
+  constexpr bool BAKED = !BK && P::BM == BAKED_ROWS;   // 64-row blocks: the metadata is in the filter-stationary kernels' baked format
   typedef WaveTile<DT, (CIN > 64 ? 64 : CIN), P::NTW, MT, (CIN > 64 ? 64 : CIN) / 32> WT;   // accumulators + epilogue only
   typedef typename Num<DT>::T T;
   extern __shared__ u32x4 lds[];
@@ -81,11 +92,13 @@ __global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa)
     for (int i = tid; i < N16; i += P::NW * 64) ((u32x4*)slot)[i] = src[i];
     if (tid < P::NXB * P::PPR) {
       const int b = tid / P::PPR, p = tid % P::PPR;
-      *(u32x4*)(L + P::OFF_X + b * P::XB + CAP * P::RB + p * 16) = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)(L + P::OFF_X + b * P::XB + (BK ? 0 : CAP * P::RB) + p * 16) = u32x4{0u, 0u, 0u, 0u};   // the zero row: last, or first (baked)
     }
   }
   const int2 hl = sa.hdr[(size_t)blk * PLANES + (lane < PLANES ? lane : 0)];
-  const int vlo = hl.x, vcnt = lane < PLANES ? hl.y : 0;
+  const int vlo = hl.x, vcnt = lane < PLANES ? ((BAKED || BK) ? (int)((unsigned)hl.y & ~HDR_RAW) : hl.y) : 0;
+  // baked metadata (spconv_slab_meta.h): a slot is (row + 1) * row bytes | swizzle bits, 0 = none — unless the plane's header says raw
+  const unsigned raw_planes = (BAKED || BK) ? (unsigned)__builtin_amdgcn_readfirstlane((int)__ballot(lane < PLANES && ((unsigned)hl.y & HDR_RAW))) : ~0u;
   const unsigned live_planes = (unsigned)__builtin_amdgcn_readfirstlane((int)__ballot(vcnt > 0));   // bit j: plane j has rows
   auto plane_lo = [&](int j) { return __builtin_amdgcn_readlane(vlo, j); };
   auto plane_cnt = [&](int j) { return __builtin_amdgcn_readlane(vcnt, j); };
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa)
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, sa.wimg_bytes, 0x00020000);
   char* const dump = L + P::OFF_DUMP;
   const unsigned lr = (unsigned)(lane / P::PPR), sp = (unsigned)(lane % P::PPR);
-  const unsigned lane_piece_off = (sp ^ RowSwz<KC>::of(lr)) * 16u;
+  const unsigned lane_piece_off = (sp ^ RowSwz<KC>::of(lr + (BK ? 1u : 0u))) * 16u;   // baked: staged row s lives in LDS row s + 1
   static_assert(P::RPI % 8 == 0, "swizzle must not depend on the instruction index");
   // rows of piece (j, q), channel pass h -> X buffer xb: exactly NX 1-KiB requests per wave (pieces past the range re-read
   // its last row into rows no slot refers to, or into the dump); a finished `u` sends all of them to the dump
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa)
     const int n = plane_cnt(j) - (u.done ? 0 : u.q * CAP);
     const unsigned rows = (unsigned)(n < CAP ? n : CAP);
     const unsigned soff = (unsigned)(plane_lo(j) + (u.done ? 0 : u.q * CAP)) * row_bytes + (unsigned)((u.done ? 0 : u.h) * KC * 2);
-    char* dst = L + P::OFF_X + xb * P::XB;
+    char* dst = L + P::OFF_X + xb * P::XB + (BK ? P::RB : 0);
 #pragma unroll
     for (int t = 0; t < P::NX; ++t) {
       const int i = w + t * P::NW;
@@ -142,13 +155,33 @@ __global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa)
   // just before the tap's first fragment read, one reduction unit later at the earliest.
   auto load_slots = [&](const Sub& u, int d, unsigned (&raw)[MT]) {
     const uint16_t* sl = slot + (u.j * TAPS + d) * P::BM + wr * 16 * MT + c;
+    const bool israw = !BAKED || ((raw_planes >> u.j) & 1u);   // wave-uniform
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) raw[mt] = (unsigned)sl[mt * 16];
+    for (int mt = 0; mt < MT; ++mt) {
+      const unsigned r = (unsigned)sl[mt * 16];
+      raw[mt] = (israw || BK) ? r : (r >> 6) - 1u;   // baked 0 -> 0xFFFFFFFF: outside any piece, like NO_SLOT (BK: decoded, if at all, in to_offsets)
+    }
   };
   auto to_offsets = [&](const Sub& u, const unsigned (&raw)[MT], unsigned (&xo)[MT]) {
     const unsigned pbase = (unsigned)(u.q * CAP);
     const unsigned plive = (unsigned)plane_cnt(u.j) - pbase;
     const unsigned prow = plive < (unsigned)CAP ? plive : (unsigned)CAP;   // rows of this piece
+    if constexpr (BK) {
+      const bool planeraw = (raw_planes >> u.j) & 1u;
+      if (!planeraw && u.q == 0 && plive <= (unsigned)CAP) {   // wave-uniform: the whole range is resident, the entries ARE the offsets
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xo[mt] = raw[mt];
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned sidx = planeraw ? raw[mt] : (raw[mt] >> 7) - 1u;   // baked 0 -> 0xFFFFFFFF
+          const unsigned e = sidx - pbase;
+          const unsigned r = e < prow ? e + 1u : 0u;                        // outside the piece: the zero row (row 0)
+          xo[mt] = baked128_entry(r);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       unsigned e = raw[mt] - pbase;        // NO_SLOT - pbase stays >= prow
@@ -156,6 +189,7 @@ __global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa)
       xo[mt] = e * P::RB + (RowSwz<KC>::of(e) << 20);
     }
   };
+  const unsigned piece_xor[2] = {(unsigned)g4 << 4, (unsigned)(4 + g4) << 4};   // baked: the lane's 16-byte piece of chunk 0 / 1
 
   // output channels [c0, c0 + 16*NTW) of the rows: the epilogue sees a narrower convolution
   Args aw = a;
@@ -189,8 +223,11 @@ __global__ __launch_bounds__(RW * CW * 64) void spconv_slabr_kernel(SlabArgs sa)
     auto fetch = [&](int i) {
       const int d = i / P::CH, cc = i % P::CH;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        xa[i & 1][mt] = *(const u32x4*)(X + (xo[d & 1][mt] & 0xFFFFFu) + (((unsigned)(cc * 4 + g4)) ^ (xo[d & 1][mt] >> 20)) * 16);
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned o = xo[d & 1][mt];
+        if constexpr (BK) xa[i & 1][mt] = *(const u32x4*)(X + (o ^ piece_xor[cc]));
+        else xa[i & 1][mt] = *(const u32x4*)(X + (o & 0xFFFFFu) + (((unsigned)(cc * 4 + g4)) ^ (o >> 20)) * 16);
+      }
     };
     to_offsets(sub[0], raw[0], xo[0]);
     fetch(0);

@@ -348,6 +348,8 @@ class SlabMeta:
     """Block metadata of a 3x3x3 SubM neighbour table over rows in ascending linear index (bevamd_spconv_slab_build)."""
 
     def __init__(self, hdr, slots, block_rows, status):
+        # block_rows: what bevamd_spconv_slab_block_rows returned — rows per block in the low half, the slot-format code in the
+        # upper half (0 = raw 16-bit slots / the 64-byte baked form implied by 64-row blocks, 1 = baked 128-byte rows)
         self.hdr, self.slots, self.block_rows, self.status = hdr, slots, block_rows, status
 
 

@@ -96,14 +96,20 @@ def test_host_side_tables_of_the_slab_kernels():
         regw = [v for v in got if 1000000 <= v < 2000000]
         pers = [v for v in got if 2000000 <= v < 3000000]
         fstat = [v for v in got if v >= 4000000]
-        assert regw and sorted(v + 1000000 for v in regw) == sorted(pers)      # every shape is built in both flavours
+        # every PLAIN shape is built in both flavours; shapes with kernel flags (ID >= 4: baked slot metadata) or 64-row blocks
+        # (baked metadata of the filter-stationary format) have no persistent twin
+        plain = [v for v in regw if v % 10 < 4 and (v // 100 % 10) * 16 * (v // 1000 % 10) != 64]
+        assert regw and sorted(v + 1000000 for v in plain) == sorted(pers)
         assert bool(fstat) == (cin == 32) and all(lib.bevamd_spconv_slab_block_rows(cin, v) == 64 for v in fstat)
         for v in got:
-            rows = lib.bevamd_spconv_slab_block_rows(cin, v)
-            assert rows in (128, 256) or v in fstat
+            code = lib.bevamd_spconv_slab_block_rows(cin, v)
+            rows, fmt = code & 0xFFFF, code >> 16                                        # upper half: slot format (1 = baked 128-byte rows)
+            assert rows in (128, 256) or v in fstat or (rows == 64 and v in regw)
+            assert fmt == (1 if (1000000 <= v < 2000000 and v % 10 >= 8) else 0)
             if 1000000 <= v < 3000000:                                                   # RW * 16 * MT from the code itself
                 assert rows == (v // 100 % 10) * 16 * (v // 1000 % 10)
-                assert lib.bevamd_spconv_slab_block_rows(cin, v % 1000000 + 2000000) == rows   # the persistent twin: same blocks
+                twin = lib.bevamd_spconv_slab_block_rows(cin, v % 1000000 + 2000000)
+                assert twin == (rows if v % 1000000 + 1000000 in plain else 0)            # the persistent twin: same blocks
         assert lib.bevamd_spconv_slab_block_rows(cin, 0) == lib.bevamd_spconv_slab_block_rows(cin, got[0])
         assert lib.bevamd_spconv_slab_block_rows(cin, 1999999) == 0            # not built
     assert lib.bevamd_spconv_slab_block_rows(48, 0) == 0
@@ -114,6 +120,8 @@ def test_host_side_tables_of_the_slab_kernels():
     assert lib.bevamd_spconv_slab_block_rows(64, 4000112) == 0                 # the filter-stationary kernels exist for 32 channels only
     assert lib.bevamd_spconv_slab_hdr_bytes(1000, 128) == 8 * 3 * 8
     assert lib.bevamd_spconv_slab_slot_bytes(1000, 128) == 8 * 27 * 128 * 2
+    assert lib.bevamd_spconv_slab_slot_bytes(1000, 128 | 1 << 16) == 8 * 27 * 128 * 2   # a format code does not change the sizes
+    assert lib.bevamd_spconv_slab_hdr_bytes(1000, 128 | 1 << 16) == 8 * 3 * 8 and lib.bevamd_spconv_slab_grid_ok(shape, 256 | 1 << 16) == 1
     assert lib.bevamd_spconv_slab_ablation_mask() == 0                         # shipped builds compile nothing out
 
 

@@ -189,7 +189,7 @@ def test_long_ranges_take_the_piece_loop(dev, c):
     base = run_gather(f, w, rb)
     for v in sops.slab_variants(c):
         out, meta = run_slab(f, w, rb, variant=v)
-        bm = meta.block_rows
+        bm = meta.block_rows & 0xFFFF          # the upper half is the slot-format code (baked 128-byte rows)
         nblk = (rb.num_out + bm - 1) // bm
         cnt = meta.hdr.cpu().numpy().view(np.int32).reshape(-1)[: nblk * 6].reshape(nblk, 3, 2)[:, :, 1] & 0x3FFFFFFF
         assert cnt.max() > (1.5 * bm if bm > 64 else 200), "the case must exercise multi-piece ranges"
