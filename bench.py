@@ -51,8 +51,12 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed number of frames per step for the WHOLE job, split over the ranks with sharding.frames_for_rank "
                          "(strong scaling); default 0 = --batch frames on every GPU (weak scaling)")
-    ap.add_argument("--overlap", choices=["chain", "pipeline", "voxel", "head", "lidar", "none"], default="chain",
-                    help="chain (default since round 5): the voxelizer (own HIP graph, second stream) beside the depth raster / fused pooling, the "
+    ap.add_argument("--overlap", choices=["auto", "chain", "pipeline", "voxel", "head", "lidar", "none"], default="auto",
+                    help="auto (default since round 5): lidar from 4 frames per step, voxel below (measured on one box, two pairs, 8 frames: "
+                         "lidar 4.72 / 4.73, chain 4.81 / 4.85, head 4.83 / 4.83, voxel 4.84 / 4.85 ms; one frame: voxel 0.94, chain 1.16). "
+                         "With lidar the camera kernels share the machine with the LiDAR branch, so roofline.kernel_ms is the bev_pool kernel "
+                         "measured SOLO right after the timed region and kernel_ms_in_step the launch inside the step.  "
+                         "chain: the voxelizer (own HIP graph, second stream) beside the depth raster / fused pooling, the "
                          "encoder's rulebook chain (own graph, same second stream) beside bev_pool — a pure HBM stream without LDS or MFMA "
                          "use, the partner a latency-bound integer chain wants —, then the 21 convolutions + dense tail ALONE after the "
                          "join; roofline.kernel_ms is then the bev_pool kernel measured SOLO after the timed region (kernel_ms_in_step: "
@@ -925,6 +929,8 @@ def main():
             "layers": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in l.items()} for l in layers],
         }
 
+    if args.overlap == "auto":
+        args.overlap = ("lidar" if B >= 4 else "voxel") if (sp_dtype != torch.float32 and not args.no_graph) else "none"
     overlap_head = args.overlap == "head" and sp_dtype != torch.float32 and not args.no_graph
     overlap_voxel = args.overlap == "voxel" and sp_dtype != torch.float32 and not args.no_graph
     overlap_pipe = args.overlap == "pipeline" and sp_dtype != torch.float32 and not args.no_graph
@@ -1226,9 +1232,10 @@ def main():
 
     # the roofline kernel SOLO (all ranks, right after the timed region): under --overlap chain the in-step launch shares the
     # machine with the rulebook chain; the roofline figure of the kernel itself is that of an undisturbed launch
-    solo_ms = kernel_ms(lambda: plan.launch_forward(feats, bev), n=20, warm=2) if overlap_chain else None
+    shared = overlap_chain or overlap_lidar or (overlap_head and not overlap_voxel) or overlap_pipe
+    solo_ms = kernel_ms(lambda: plan.launch_forward(feats, bev), n=20, warm=2) if shared else None
 
-    if rank == 0 and world == 1 and not args.no_extras and ((args.overlap == "none" and graph is not None) or overlap_voxel or overlap_chain):
+    if rank == 0 and world == 1 and not args.no_extras and ((args.overlap == "none" and graph is not None) or overlap_voxel or overlap_chain or overlap_lidar):
         extra = {}
         t_extra = time.perf_counter()
         # (iv) the product's step: what a deployment runs per batch — raster + fused pooling + LiDAR branch — without the API-level
@@ -1238,6 +1245,10 @@ def main():
             if overlap_chain:
                 return step_chain(None, with_bev_pool=False)
             main_stream = torch.cuda.current_stream()
+            if overlap_lidar:
+                head_stream.wait_stream(main_stream)
+                with torch.cuda.stream(head_stream):
+                    graph.replay()
             if overlap_voxel:
                 head_stream.wait_stream(main_stream)
                 with torch.cuda.stream(head_stream):
@@ -1248,6 +1259,8 @@ def main():
             if overlap_voxel:
                 main_stream.wait_stream(head_stream)
                 graph_tail.replay()
+            elif overlap_lidar:
+                main_stream.wait_stream(head_stream)
             else:
                 graph.replay()
 
@@ -1335,7 +1348,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side1)
             torch.cuda.synchronize()
             # the schedule of the headline step: voxelizer (own graph, second stream) beside raster + fused pooling, or one graph
-            g1h = new_graph() if (overlap_voxel or overlap_chain) else None
+            b1_voxel = overlap_voxel or overlap_lidar     # auto: a single frame runs the voxel schedule
+            g1h = new_graph() if (b1_voxel or overlap_chain) else None
             g1g = new_graph() if overlap_chain else None
             g1 = new_graph()
             if overlap_chain:
@@ -1348,7 +1362,7 @@ def main():
                     state["geo1"] = geo1(*state["vox1"])
                 with torch.cuda.graph(g1, pool=g1h.pool()):
                     state["lidar_bev1"] = tail1(*state["vox1"], state["geo1"])
-            elif overlap_voxel:
+            elif b1_voxel:
                 with torch.cuda.graph(g1h):
                     state["vox1"] = vox1()
                 with torch.cuda.graph(g1):
@@ -1359,7 +1373,7 @@ def main():
 
             def step1():
                 main_stream = torch.cuda.current_stream()
-                if overlap_voxel or overlap_chain:
+                if b1_voxel or overlap_chain:
                     head_stream.wait_stream(main_stream)
                     with torch.cuda.stream(head_stream):
                         g1h.replay()
@@ -1369,12 +1383,12 @@ def main():
                     vt.depth_raster(img_stub[:1], pts1, t_l2i[:1], t_ia[:1], t_la[:1])
                 plan1.launch_fused(depth1.reshape(-1), ctx1, dbins, fh, fw, out=fused1)
                 plan1.launch_forward(feats1, bev1)
-                if overlap_voxel or overlap_chain:
+                if b1_voxel or overlap_chain:
                     main_stream.wait_stream(head_stream)      # one frame: the join sits in front of the encoder (see early_join)
                 g1.replay()
 
             def lidar1_alone():
-                if overlap_voxel or overlap_chain:
+                if b1_voxel or overlap_chain:
                     g1h.replay()
                 if overlap_chain:
                     g1g.replay()
@@ -1389,7 +1403,7 @@ def main():
             ev1[1].record()
             ev1[1].synchronize()
             extra["batch1_step"] = dict(ms_per_step=m1, frames_per_s=1e3 / m1, lidar_branch_ms=ev1[0].elapsed_time(ev1[1]) / 20,
-                                        lidar_graph=(add_counts(graph_node_count(g1h), graph_node_count(g1)) if overlap_voxel
+                                        lidar_graph=(add_counts(graph_node_count(g1h), graph_node_count(g1)) if b1_voxel
                                                      else add_counts(add_counts(graph_node_count(g1h), graph_node_count(g1g)),
                                                                      graph_node_count(g1)) if overlap_chain else graph_node_count(g1)),
                                         note="the headline step (raster + fused pooling + bev_pool + LiDAR branch, same schedule) on "
@@ -1493,8 +1507,9 @@ def main():
                             + "the encoder, rulebook chain included, follows") if overlap_voxel else
                            ("head: voxelization + rulebook chain on a second HIP stream beside the camera stages (the camera stage times, "
                             "bev_pool's roofline figure included, are measured WITH that concurrency)") if overlap_head else
-                           ("lidar: the whole LiDAR branch on a second HIP stream beside the camera stages (stage times overlap: the last "
-                            "stage is only the wait for the branch; bev_pool's roofline figure is measured WITH that concurrency)")
+                           ("lidar: the whole LiDAR branch (one HIP graph: voxelizer, rulebook chain, convolutions) on a second HIP stream beside "
+                            "the camera stages; stage times overlap (the last stage is the wait for the branch), stage_ms.bev_pool is the kernel "
+                            "WITH the branch beside it, roofline.kernel_ms the same launch SOLO right after the timed region")
                            if overlap_lidar else "none",
                 "fused_depth_context_bev": {"ms": fused_ms, "algorithmic_bytes": fused_bytes,
                                             "gbs_on_own_bytes": fused_bytes / (fused_ms * 1e-3) / 1e9,

@@ -62,7 +62,7 @@ struct PlanR {
 //      A plane whose range does not fit one piece (> CAP rows) or whose header says raw takes the arithmetic path.
 constexpr int F_BAKED = 8;
 template <int DT, int KC, int CIN, int NT, int MT, int RW, int CW, int CAP, int FLAGS = 0>
-__global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64) ? 2 : 1) void spconv_slabr_kernel(SlabArgs sa) {
+__global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64 && MT <= 4) ? 2 : 1) void spconv_slabr_kernel(SlabArgs sa) {
   typedef PlanR<KC, CIN, NT, MT, RW, CW, CAP> P;
   constexpr bool BK = (FLAGS & F_BAKED) != 0;   // baked 128-byte-row metadata
   static_assert(!BK || KC == 64, "the baked format describes 128-byte staged rows");
@@ -155,26 +155,39 @@ __global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64) ? 2 : 1) vo
   // just before the tap's first fragment read, one reduction unit later at the earliest.
   auto load_slots = [&](const Sub& u, int d, unsigned (&raw)[MT]) {
     const uint16_t* sl = slot + (u.j * TAPS + d) * P::BM + wr * 16 * MT + c;
+    if constexpr (BK) {
+      // sign-extending 16-bit loads (ds_read_i16: hipcc puts a v_and 0xffff behind every ds_read_u16): baked entries are < 0x8000
+      // ((CAP + 1) * 128 bytes), so they come out as they are; the arithmetic path masks what it reads
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) raw[mt] = (unsigned)(int)((const int16_t*)sl)[mt * 16];
+      return;
+    }
     const bool israw = !BAKED || ((raw_planes >> u.j) & 1u);   // wave-uniform
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const unsigned r = (unsigned)sl[mt * 16];
-      raw[mt] = (israw || BK) ? r : (r >> 6) - 1u;   // baked 0 -> 0xFFFFFFFF: outside any piece, like NO_SLOT (BK: decoded, if at all, in to_offsets)
+      raw[mt] = israw ? r : (r >> 6) - 1u;   // baked 0 -> 0xFFFFFFFF: outside any piece, like NO_SLOT
     }
   };
-  auto to_offsets = [&](const Sub& u, const unsigned (&raw)[MT], unsigned (&xo)[MT]) {
+  static_assert(!BK || (CAP + 1) * P::RB < 0x8000, "baked entries are read as signed 16-bit values");
+  // wave-uniform, once per piece: the whole range of the plane is resident and its slots are baked — the entries ARE the offsets
+  auto piece_is_fast = [&](const Sub& u) {
+    return BK && !((raw_planes >> u.j) & 1u) && u.q == 0 && plane_cnt(u.j) <= CAP;
+  };
+  auto to_offsets = [&](const Sub& u, bool fast, const unsigned (&raw)[MT], unsigned (&xo)[MT]) {
     const unsigned pbase = (unsigned)(u.q * CAP);
     const unsigned plive = (unsigned)plane_cnt(u.j) - pbase;
     const unsigned prow = plive < (unsigned)CAP ? plive : (unsigned)CAP;   // rows of this piece
     if constexpr (BK) {
-      const bool planeraw = (raw_planes >> u.j) & 1u;
-      if (!planeraw && u.q == 0 && plive <= (unsigned)CAP) {   // wave-uniform: the whole range is resident, the entries ARE the offsets
+      if (fast) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xo[mt] = raw[mt];
       } else {
+        const bool planeraw = (raw_planes >> u.j) & 1u;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const unsigned sidx = planeraw ? raw[mt] : (raw[mt] >> 7) - 1u;   // baked 0 -> 0xFFFFFFFF
+          const unsigned r16 = raw[mt] & 0xFFFFu;                           // undo the sign extension of the load
+          const unsigned sidx = planeraw ? r16 : (r16 >> 7) - 1u;           // baked 0 -> 0xFFFFFFFF; raw NO_SLOT stays 0xFFFF
           const unsigned e = sidx - pbase;
           const unsigned r = e < prow ? e + 1u : 0u;                        // outside the piece: the zero row (row 0)
           xo[mt] = baked128_entry(r);
@@ -229,7 +242,8 @@ __global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64) ? 2 : 1) vo
         else xa[i & 1][mt] = *(const u32x4*)(X + (o & 0xFFFFFu) + (((unsigned)(cc * 4 + g4)) ^ (o >> 20)) * 16);
       }
     };
-    to_offsets(sub[0], raw[0], xo[0]);
+    const bool fast = piece_is_fast(sub[0]);
+    to_offsets(sub[0], fast, raw[0], xo[0]);
     fetch(0);
 #pragma unroll
     for (int d = 0; d < TAPS; ++d) {
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64) ? 2 : 1) vo
       for (int cc = 0; cc < P::CH; ++cc) {
         const int i = d * P::CH + cc;
         if (i + 1 < U) {
-          if ((i + 1) % P::CH == 0) to_offsets(sub[0], raw[(d + 1) % (P::WD + 1)], xo[(d + 1) & 1]);
+          if ((i + 1) % P::CH == 0) to_offsets(sub[0], fast, raw[(d + 1) % (P::WD + 1)], xo[(d + 1) & 1]);
           fetch(i + 1);
         }
         __builtin_amdgcn_sched_barrier(0);

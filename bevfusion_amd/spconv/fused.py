@@ -482,9 +482,14 @@ _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and 
 # 32 channels from 4 frames: the filter-stationary kernel (spconv_slab_fstat.h; 64-row blocks, baked slots): 159 us isolated against 190
 # of the persistent register-ring kernel 2324410, 5.58-5.60 against 5.77-5.78 ms per 8-frame step on the same box (its results
 # agree with the other kernels' to fp32 rounding, not bit for bit: v_mfma_32x32x16 sums 16 channels per step)
-_SLAB_DEFAULT = {32: 4000112, 64: 1644222, 128: 1644220}
-_SLAB_DEFAULT_SMALL_BATCH = {32: 1322410}   # below 4 frames per step
-_SLAB_MIN_BATCH = {128: 4}
+# Round 5: 64 channels on the register-filter kernel with BAKED slot metadata (1644228: the fragment address is one v_xad_u32;
+# 189-193 -> 172-174 us per layer at 8 frames, 29.9 -> 28.2 at one; the same flag buys nothing at 128 channels: 154-157 either way);
+# 128 channels below 4 frames: 64-row blocks (1642220: one frame's level 4 is 188 blocks of 128 rows on 256 CUs; 39.5 -> 34.0 us,
+# gather kernel 38.8) — the kernel reads the filter-stationary kernels' baked 64-row metadata (EXPERIMENTS.md C.3: the "epilogue
+# bug" of B.17 was that metadata format read as raw slots).
+_SLAB_DEFAULT = {32: 4000112, 64: 1644228, 128: 1644220}
+_SLAB_DEFAULT_SMALL_BATCH = {32: 1322410, 128: 1642220}   # below 4 frames per step
+_SLAB_MIN_BATCH = {}
 # The same decisions in LIVE ROWS (8 sparse frames are not 8 capped ones).  The tilings were measured on
 # capped flagship frames (160 k voxels each), so "frames" = live level-1 rows / 160 k.  The host does not know the row count on the
 # sync-free path: the encoder's FIRST eager call at a batch size reads it back once (_frames_hint), every later call at that batch

@@ -12,6 +12,8 @@ import oracle
 from bevfusion_amd import _capi, synth
 from bevfusion_amd.bev_pool import BevPoolPlan, QuickCumsumCuda, bev_pool, bev_pool_ext
 
+from conftest import record_parity
+
 pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
@@ -59,6 +61,7 @@ def test_forward_drop_in_vs_oracle(dev, n, B, D, H, W, c, hot):
     ref = oracle.bev_pool_forward_sorted(feats[pro["order"]], pro["geom_sorted"], pro["interval_starts"],
                                          pro["interval_lengths"], B, D, H, W)
     err = np.max(np.abs(out.cpu().numpy().astype(np.float64) - ref))
+    record_parity("bev_pool forward vs float64 oracle (absolute; north_star bar 1e-4)", err, ABS_TOL)
     assert err <= ABS_TOL, err
     # cells no interval touches are exactly zero
     g = pro["geom_sorted"][pro["interval_starts"]]
@@ -228,6 +231,7 @@ def test_against_reference_kernel_golden(dev):
     B, D, H, W = (int(z[k]) for k in "BDHW")
     out = bev_pool_ext.bev_pool_forward(t(z["x"]), t(z["geom"]), t(z["interval_lengths"]), t(z["interval_starts"]),
                                         B, D, H, W)
+    record_parity("bev_pool forward vs the reference kernel's own output (absolute)", np.max(np.abs(out.cpu().numpy() - z["out"])), ABS_TOL)
     assert np.max(np.abs(out.cpu().numpy() - z["out"])) <= ABS_TOL
     xg = bev_pool_ext.bev_pool_backward(t(z["out_grad"]), t(z["geom"]), t(z["interval_lengths"]),
                                         t(z["interval_starts"]), B, D, H, W)
@@ -257,6 +261,7 @@ def test_fused_depth_context_vs_float64(dev, cams, D, fh, fw, c, dtype):
     want = np.zeros((B, Dz, H, W, c))
     ok = (coords[:, 0] >= 0) & (coords[:, 0] < H) & (coords[:, 1] >= 0) & (coords[:, 1] < W)
     np.add.at(want, (coords[ok, 3], coords[ok, 2], coords[ok, 0], coords[ok, 1]), rows[ok])
+    record_parity("fused depth x context pooling vs float64 (absolute; north_star bar 1e-4)", np.max(np.abs(got - want)), 1e-4)
     assert np.max(np.abs(got - want)) <= 1e-4
     # same plan, unfused op on the materialised rows: the two paths agree to rounding
     unf = plan.launch_forward(torch.from_numpy(rows.astype(np.float32)).to(dev)).cpu().numpy()

@@ -1,7 +1,7 @@
 """Direct oracle parity of exactly what the driver's bench times ("next round" item 3).
 
   (i)   >= 4 frames per step — the regime in which `fused._slab_variant_for` picks the filter-stationary 32-channel kernel (4000112)
-        and the 128-channel slab kernel (1644220), with level 1 in key order (narrow slab kernels 3000256 / 3000128): per level,
+        and the 128-channel slab kernel (1644220; 64 channels: 1644228, baked slot metadata), with level 1 in key order (narrow slab kernels 3000256 / 3000128): per level,
         the fp16 output of the first SubM layer and of the strided convolution leaving the level, each against
         `oracle.indice_conv` (float64) on the GPU's own stage input, <= 2e-3 * (1 + max|ref|);
   (ii)  the bench's exact shape — 8 full 10-sweep clouds at the 160 k cap (1.28 M level-1 rows): the fused key-ordered path
@@ -28,7 +28,13 @@ from bevfusion_amd.spconv.modules import SparseSequential
 from bevfusion_amd.voxel import voxelize_batch_device
 from test_gpu_keyorder import flagship_encoder
 
+from conftest import record_parity
+
 pytestmark = pytest.mark.gpu
+# Bars = 2 x the largest error observed on an MI355X (profiles/r05_parity_observed.json, written by these tests through
+# conftest.record_parity), relative to 1 + max|reference|
+BAR_LAYER = 2e-3      # one fp16 rounding of a sum of <= 27 * 128 products (observed values: see the profile)
+BAR_ENCODER = 1e-2    # 21 layers end to end
 CFG = synth.CL_CONFIG
 
 
@@ -47,7 +53,7 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
     lvl = fused.Level(c, c.shape[0], tot.reshape(-1)[:1].int().contiguous(), B, list(CFG["sparse_shape"]), linear_order=True)
     ind, shape = c[:n].cpu().numpy(), list(CFG["sparse_shape"])
     widths = [16, 32, 64, 128]
-    expect = {16: 3000256, 32: 4000112, 64: 1644222, 128: 1644220}
+    expect = {16: 3000256, 32: 4000112, 64: 1644228, 128: 1644220}
     down = [((3, 3, 3), (2, 2, 2), (1, 1, 1), 32), ((3, 3, 3), (2, 2, 2), (1, 1, 1), 64), ((3, 3, 3), (2, 2, 2), (1, 1, 0), 128),
             ((1, 1, 3), (1, 1, 2), (0, 0, 0), 128)]
     x = torch.zeros((lvl.n_cap, 16), dtype=torch.float16, device=dev)
@@ -63,7 +69,8 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
         _, sp, sn, _ = oracle.get_indice_pairs(ind, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
         ref = oracle.indice_conv(x[:n].float().cpu().numpy(), w.float().cpu().numpy(), sp, sn, n)
         err = float(np.max(np.abs(got.float().cpu().numpy() - ref)))
-        assert err <= 2e-3 * (1 + np.abs(ref).max()), (stage, "subm", err)
+        record_parity(f"flagship 4-frame step, SubM {cw}->{cw} variant {variant} vs float64 oracle (fp16)", err / (1 + np.abs(ref).max()), BAR_LAYER)
+        assert err <= BAR_LAYER * (1 + np.abs(ref).max()), (stage, "subm", err)
         # the strided convolution leaving the level, through the kernel the fused path uses for it
         oi, op, on, oshape = oracle.get_indice_pairs(ind, B, shape, ks, st, pd, [1, 1, 1], 0, order="cuda")
         K = int(np.prod(ks))
@@ -82,7 +89,8 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
                                        variant=fused._variant_for(B, K, cw, cout))
         refy = oracle.indice_conv(x[:n].float().cpu().numpy(), ws.float().cpu().numpy(), op, on, m)
         erry = float(np.max(np.abs(y[:m].float().cpu().numpy() - refy)))
-        assert erry <= 2e-3 * (1 + np.abs(refy).max()), (stage, "strided", erry)
+        record_parity(f"flagship 4-frame step, strided conv leaving level {stage + 1} vs float64 oracle (fp16)", erry / (1 + np.abs(refy).max()), BAR_LAYER)
+        assert erry <= BAR_LAYER * (1 + np.abs(refy).max()), (stage, "strided", erry)
         x = torch.relu(y).contiguous()
         x[m:] = 0
         lvl, ind, shape = nxt, oi, list(oshape)
@@ -107,7 +115,8 @@ def test_bench_shape_eight_full_clouds_fused_vs_modules_and_oracle_levels(dev):
     assert tuple(got.shape) == (B, 256, 180, 180)
     assert torch.equal(got, first)                                       # key-ordered == first-appearance fused path, bit for bit
     err = float((got.float() - ref.float()).abs().max())
-    assert err <= 1e-2 * (1 + float(ref.float().abs().max())), err
+    record_parity("bench shape (8 x 160 k voxels): fused encoder vs module path (fp16, dense BEV)", err / (1 + float(ref.float().abs().max())), BAR_ENCODER)
+    assert err <= BAR_ENCODER * (1 + float(ref.float().abs().max())), err
     # level chain at this shape vs the oracle
     ind = c1[:n].cpu().numpy()
     lvl = fused.Level(c1, c1.shape[0], t1.reshape(-1)[:1].int().contiguous(), B, list(CFG["sparse_shape"]), linear_order=True)
@@ -205,5 +214,6 @@ def test_encoder_dense_output_vs_float64_oracle_chain(dev, order):
     g = got.double().cpu().numpy()
     assert not np.isnan(g).any()
     err = float(np.max(np.abs(g - ref)))
-    assert err <= 1e-2 * (1 + np.abs(ref).max()), err
+    record_parity("whole encoder vs float64 oracle chain (fp16, dense BEV)", err / (1 + np.abs(ref).max()), BAR_ENCODER)
+    assert err <= BAR_ENCODER * (1 + np.abs(ref).max()), err
     assert not g[np.abs(ref).sum(1, keepdims=True).repeat(g.shape[1], 1) == 0].any()   # nothing outside the oracle's active BEV cells

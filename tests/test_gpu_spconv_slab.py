@@ -14,6 +14,8 @@ import oracle
 from bevfusion_amd import spconv
 from bevfusion_amd.spconv import ops as sops
 
+from conftest import record_parity
+
 pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
 
@@ -73,6 +75,7 @@ def assert_same(out, base, c, variant):
 
 def assert_close(out, ref, dtype):
     err = np.max(np.abs(out.float().cpu().numpy().astype(np.float64) - ref))
+    record_parity(f"slab kernels, random cases vs float64 oracle ({str(dtype).split('.')[-1]}, C={out.shape[1]})", err / (1.0 + np.max(np.abs(ref))), TOL[dtype])
     assert err <= TOL[dtype] * (1.0 + np.max(np.abs(ref))), err
 
 

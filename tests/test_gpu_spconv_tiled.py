@@ -12,6 +12,8 @@ import oracle
 from bevfusion_amd import spconv
 from bevfusion_amd.spconv import ops as sops
 
+from conftest import record_parity
+
 pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
 RESIDENT = (1221, 1222, 1223, 1421, 1422, 1211)      # kind 1, MT, NW/4, offsets (chunks) per step
@@ -53,6 +55,7 @@ def _run(f, w, rb, variant=0, pitch=None, **kw):
 def _assert_close(out, ref, dtype):
     err = np.max(np.abs(out.float().cpu().numpy().astype(np.float64) - ref))
     scale = 1.0 + np.max(np.abs(ref))
+    record_parity(f"gather kernels, random cases vs float64 oracle ({str(dtype).split('.')[-1]})", err / scale, TOL[dtype])
     assert err <= TOL[dtype] * scale, (err, scale)
 
 
