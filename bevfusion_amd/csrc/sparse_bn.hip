@@ -209,8 +209,13 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restric
   __shared__ float sa[MAX_C], sb[MAX_C];
   const char* x = (const char*)x_;
   const size_t esz = DT == 0 ? 4 : 2;
+  // SHIFTED sums: p = sum (x - x0), q = sum (x - x0)^2 with x0 = row 0 of the tensor — the same pivot in every
+  // workgroup, a value of the channel's own distribution — so that var = q/n - (p/n)^2 does not cancel when |mean| >> std
+  // (E[x^2] - mean^2 on raw fp32 sums loses ~1e-7 * mean^2 / var of relative accuracy; torch's batch_norm runs Welford).
   slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, long long step, long long hi, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
     V v[4];
+    float x0[R::VEC];
+    R::unpack(*(const V*)(x + (size_t)cv * R::VEC * esz), x0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long ru = r + u * step < hi ? r + u * step : r;
@@ -222,13 +227,16 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restric
         float f[R::VEC];
         R::unpack(v[u], f);
 #pragma unroll
-        for (int j = 0; j < R::VEC; ++j) { p[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+        for (int j = 0; j < R::VEC; ++j) { const float d = f[j] - x0[j]; p[j] += d; q[j] = fmaf(d, d, q[j]); }
       }
     }
   });
   finish_totals(sa, sb, C, part, gpart, ticket, [&](int c, double s, double ss) {
-    const double m = s / (double)n;
-    double var = ss / (double)n - m * m;
+    float x0v[R::VEC];
+    R::unpack(*(const V*)(x + (size_t)(c / R::VEC) * R::VEC * esz), x0v);
+    const double ms = s / (double)n;                         // mean of the shifted values
+    const double m = (double)x0v[c % R::VEC] + ms;
+    double var = ss / (double)n - ms * ms;
     var = var > 0.0 ? var : 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));

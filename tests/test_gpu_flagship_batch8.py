@@ -129,8 +129,8 @@ def test_fused_encoder_eight_frames_vs_module_path_and_oracle_levels(dev):
         assert enc.last_path == "modules"
     assert tuple(got.shape) == (B8, 256, 180, 180)
     err = float((got.float() - ref.float()).abs().max())
-    record_parity("8 flagship frames: fused encoder vs module path (fp16, dense BEV)", err / (1 + float(ref.float().abs().max())), 1e-2)
-    assert err <= 1e-2 * (1 + float(ref.float().abs().max())), err
+    record_parity("8 flagship frames: fused encoder vs module path (fp16, dense BEV)", err / (1 + float(ref.float().abs().max())), 4e-4)
+    assert err <= 4e-4 * (1 + float(ref.float().abs().max())), err     # observed 1.8e-4 (was 1e-2)
     # level chain of the fused path vs the oracle at 8 frames
     n = int(tot.item())
     ind = c[:n].cpu().numpy()
@@ -180,8 +180,8 @@ def test_flagship_frame_stage_by_stage_vs_oracle(dev):
         _, sp, sn, _ = oracle.get_indice_pairs(ind, 1, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), [1, 1, 1], 1, order="cuda")
         ref = oracle.indice_conv(x[:n].float().cpu().numpy(), w.float().cpu().numpy(), sp, sn, n)
         err = float(np.max(np.abs(got.float().cpu().numpy() - ref)))
-        record_parity(f"flagship frame, SubM {cw}->{cw} vs float64 oracle (fp16)", err / (1 + np.abs(ref).max()), 2e-3)
-        assert err <= 2e-3 * (1 + np.abs(ref).max()), (stage, "subm", err)
+        record_parity(f"flagship frame, SubM {cw}->{cw} vs float64 oracle (fp16)", err / (1 + np.abs(ref).max()), 6e-4)
+        assert err <= 6e-4 * (1 + np.abs(ref).max()), (stage, "subm", err)       # observed <= 2.5e-4 (was 2e-3)
         # (b) the strided convolution leaving the level
         oi, op, on, oshape = oracle.get_indice_pairs(ind, 1, shape, ks, st, pd, [1, 1, 1], 0, order="cuda")
         nxt, nbr = lvl.downsample(list(ks), list(st), list(pd))
@@ -193,8 +193,8 @@ def test_flagship_frame_stage_by_stage_vs_oracle(dev):
                                    variant=fused._variant_for(1, K, cw, cout))
         refy = oracle.indice_conv(x[:n].float().cpu().numpy(), ws.float().cpu().numpy(), op, on, m)
         erry = float(np.max(np.abs(y[:m].float().cpu().numpy() - refy)))
-        record_parity(f"flagship frame, strided conv leaving level {stage + 1} vs float64 oracle (fp16)", erry / (1 + np.abs(refy).max()), 2e-3)
-        assert erry <= 2e-3 * (1 + np.abs(refy).max()), (stage, "strided", erry)
+        record_parity(f"flagship frame, strided conv leaving level {stage + 1} vs float64 oracle (fp16)", erry / (1 + np.abs(refy).max()), 6e-4)
+        assert erry <= 6e-4 * (1 + np.abs(refy).max()), (stage, "strided", erry)   # observed <= 2.6e-4 (was 2e-3)
         # next level: the GPU's own output is the next stage's input (ReLU'd like the network's activations)
         x = torch.relu(y).contiguous()
         x[m:] = 0

@@ -3,7 +3,7 @@
   (i)   >= 4 frames per step — the regime in which `fused._slab_variant_for` picks the filter-stationary 32-channel kernel (4000112)
         and the 128-channel slab kernel (1644220; 64 channels: 1644228, baked slot metadata), with level 1 in key order (narrow slab kernels 3000256 / 3000128): per level,
         the fp16 output of the first SubM layer and of the strided convolution leaving the level, each against
-        `oracle.indice_conv` (float64) on the GPU's own stage input, <= 2e-3 * (1 + max|ref|);
+        `oracle.indice_conv` (float64) on the GPU's own stage input, <= 6e-4 * (1 + max|ref|) (2 x the observed error, profiles/r05_parity_observed.json);
   (ii)  the bench's exact shape — 8 full 10-sweep clouds at the 160 k cap (1.28 M level-1 rows): the fused key-ordered path
         against the module-by-module path, its level chain (active sets, row order, counts) against the oracle, and the dense
         output bit-identical to the fused first-appearance path;
@@ -33,8 +33,8 @@ from conftest import record_parity
 pytestmark = pytest.mark.gpu
 # Bars = 2 x the largest error observed on an MI355X (profiles/r05_parity_observed.json, written by these tests through
 # conftest.record_parity), relative to 1 + max|reference|
-BAR_LAYER = 2e-3      # one fp16 rounding of a sum of <= 27 * 128 products (observed values: see the profile)
-BAR_ENCODER = 1e-2    # 21 layers end to end
+BAR_LAYER = 6e-4      # observed <= 2.9e-4 on every layer: one fp16 rounding of a sum of <= 27 * 128 products (was 2e-3)
+BAR_ENCODER = 4e-4    # observed 1.8e-4 (fused vs module path) / 1.0e-4 (vs the float64 oracle chain), 21 layers end to end (was 1e-2)
 CFG = synth.CL_CONFIG
 
 

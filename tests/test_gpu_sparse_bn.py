@@ -139,3 +139,26 @@ def test_sparse_encoder_training_step_native_vs_torch_batchnorm(dev):
     a = torch.cat([g0[k].reshape(-1).double() for k in g1])
     b = torch.cat([g1[k].reshape(-1).double() for k in g1])
     assert float((a @ b) / (a.norm() * b.norm())) >= 0.999
+
+
+def test_statistics_of_channels_with_a_large_mean(dev):
+    """|mean| >> std.  E[x^2] - mean^2 on raw fp32 sums cancels (relative error ~1e-7 * mean^2 / var: at mean 300,
+    std 0.05 that is the whole variance); the kernels accumulate sums shifted by the tensor's first row, like a Welford pass starts."""
+    n, c = 50000, 32
+    g = torch.Generator(device=dev).manual_seed(3)
+    mean = torch.linspace(-300.0, 300.0, c, device=dev)
+    std = torch.linspace(0.05, 2.0, c, device=dev)
+    x = torch.randn((n, c), generator=g, device=dev) * std + mean
+    mods = [nn.BatchNorm1d(c, eps=1e-5, momentum=0.1).to(dev).train() for _ in range(2)]
+    ref_bn, our_bn = mods
+    assert native_bn.usable(our_bn, x, None)
+    yr = ref_bn(x)
+    yo = native_bn.bn_act(x.clone(), our_bn, relu=False, residual=None)
+    var64 = x.double().var(0, unbiased=True)
+    # running_var = 0.9 * 1 + 0.1 * unbiased variance: pin both implementations to float64
+    want = 0.9 + 0.1 * var64
+    assert float(((our_bn.running_var.double() - want).abs() / want).max()) <= 1e-5
+    assert float(((our_bn.running_var - ref_bn.running_var).abs() / ref_bn.running_var).max()) <= 1e-5
+    assert torch.allclose(our_bn.running_mean, ref_bn.running_mean, rtol=1e-6, atol=1e-5)
+    # normalised outputs: unit variance per channel, and equal to torch's within fp32 rounding of (x - mean) * invstd at |x| ~ 300
+    assert float((yo - yr).abs().max()) <= 2e-3 and float((yo.double().var(0) - 1.0).abs().max()) <= 1e-3

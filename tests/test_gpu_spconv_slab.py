@@ -1,7 +1,7 @@
 """GPU parity of the slab (staged-rows) submanifold convolution (csrc/spconv_slab.h, through the C ABI): against the CPU
 oracle (oracle.indice_conv, float64 accumulate) and against the gather kernel it replaces (bevamd_spconv_conv_forward_tiled).
 
-Bars: |err| <= tol * (1 + max|ref|), tol = 2e-3 (fp16) / 1.6e-2 (bf16); BIT-IDENTICAL to the gather kernel for the variants
+Bars: |err| <= tol * (1 + max|ref|), tol = 1e-3 (fp16) / 8e-3 (bf16); BIT-IDENTICAL to the gather kernel for the variants
 that stage whole rows (same summation order), within 2 ulps (of the largest magnitude) of it for the ones that run the channels in 32- / 64-wide passes
 (pass-major order: Cin = 128 always, Cin = 64 with 32-channel rows); every built variant; ranges longer than the
 staging buffer (pieces), empty kernel lines, ragged last block, device-side row count, fused epilogue; block metadata
@@ -17,7 +17,7 @@ from bevfusion_amd.spconv import ops as sops
 from conftest import record_parity
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}   # 2 x the observed maxima 4.8e-4 / 3.7e-3 (profiles/r05_parity_observed.json; 2e-3 / 1.6e-2 until round 4)
 
 
 def sorted_indices(rng, B, shape, n, dense_planes=()):
@@ -261,7 +261,7 @@ def test_epilogue_and_device_row_count(dev, c):
     y = (torch.from_numpy(ref).to(dev).to(dtype).float() + bias.float()).to(dtype).float()
     y = (y * scale + shift).to(dtype).float()
     y = torch.relu((y + res.float()).to(dtype).float())
-    assert float((out.float() - y).abs().max()) <= 4 * TOL[dtype] * (1 + float(y.abs().max()))
+    assert float((out.float() - y).abs().max()) <= 8 * TOL[dtype] * (1 + float(y.abs().max()))   # several rounding points (the bar of rounds 1-4)
     # live row count on the device, launch bounded by the capacity: rows past it stay untouched
     live = m - 77
     m_dev = torch.tensor([live], dtype=torch.int32, device=dev)

@@ -2,7 +2,7 @@
 (oracle.indice_conv, float64 accumulate): every kernel variant, the flattened-reduction shapes (Cin 8/16), the
 epilogue (bias, folded BatchNorm, residual, ReLU), device-side row counts, padded pitches, ragged tile counts.
 
-Bar: |err| <= tol * (1 + max|ref|) with tol = 2e-3 (fp16) / 1.6e-2 (bf16) — one 16-bit rounding of the result;
+Bar: |err| <= tol * (1 + max|ref|) with tol = 1e-3 (fp16) / 8e-3 (bf16) — one 16-bit rounding of the result;
 bit-reproducible run to run; variants agree bit-for-bit with each other (same summation order)."""
 import numpy as np
 import pytest
@@ -15,7 +15,7 @@ from bevfusion_amd.spconv import ops as sops
 from conftest import record_parity
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}   # 2 x the observed maxima 4.8e-4 / 3.7e-3 (profiles/r05_parity_observed.json; 2e-3 / 1.6e-2 until round 4)
 RESIDENT = (1221, 1222, 1223, 1421, 1422, 1211)      # kind 1, MT, NW/4, offsets (chunks) per step
 STREAM = (2111, 2112, 2113, 2121, 2122, 2123, 2211, 2212, 2213, 2221, 2222)
 
@@ -112,7 +112,7 @@ def test_epilogue_bias_bn_residual_relu(dev, cin, cout, dtype):
     want = (ref + bias.float().numpy()) * scale.numpy() + shift.numpy() + res.float().numpy()
     out = _run(f, w, rb, bias=bias.to(dev), bn_scale=scale.to(dev), bn_shift=shift.to(dev), residual=res.to(dev), relu=True)
     err = np.max(np.abs(out.float().cpu().numpy() - np.maximum(want, 0)))
-    assert err <= 4 * TOL[dtype] * (1 + np.max(np.abs(want))), err          # four rounding points
+    assert err <= 8 * TOL[dtype] * (1 + np.max(np.abs(want))), err          # four rounding points (the bar of rounds 1-4: TOL was halved in round 5)
     assert float(out.float().min()) >= 0.0
     # each operand alone
     out = _run(f, w, rb, bn_scale=scale.to(dev), bn_shift=shift.to(dev))
