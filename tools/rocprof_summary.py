@@ -35,6 +35,34 @@ def pmc_from_csv(path):
     return acc
 
 
+def solo_split(path, needle="bev_pool_fwd_cells_vec_kernel"):
+    """The roofline kernel runs in two settings in one bench process (round 5): inside the timed step, where it shares the machine
+    with the LiDAR branch, and SOLO right after the timed region (20 + 2 back-to-back launches: what roofline.kernel_ms reports).
+    A launch is solo when no other kernel overlaps it in time.  -> (n_solo, avg_us_solo, n_shared, avg_us_shared) or None"""
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    mine = [(s, e) for n, s, e in rows if needle in n]
+    if not mine:
+        return None
+    others = [(s, e) for n, s, e in rows if needle not in n]
+    import bisect
+
+    starts = [s for s, _ in others]
+    # running maximum of the end times: overlap test against everything that started before
+    maxend, m = [], 0
+    for _, e in others:
+        m = max(m, e)
+        maxend.append(m)
+    solo, shared = [], []
+    for s, e in mine:
+        i = bisect.bisect_left(starts, e)          # kernels that started before this one ended
+        j = bisect.bisect_left(starts, s)          # ... of which these started before it did
+        overl = (i > j) or (j > 0 and maxend[j - 1] > s)
+        (shared if overl else solo).append((e - s) / 1e3)
+    avg = lambda v: sum(v) / len(v) if v else float("nan")
+    return len(solo), avg(solo), len(shared), avg(shared)
+
+
 def main():
     d = sys.argv[1]
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -44,6 +72,12 @@ def main():
     print(f"{'kernel':78s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_ms':>10s} {'%':>6s}")
     for r in rows:
         print(f"{r[0][:78]:78s} {r[1]:6d} {r[2]:10.2f} {r[3]:10.2f} {r[4]:10.2f} {r[5]:10.3f} {100 * r[5] / tot:6.2f}")
+    if dbs:
+        sp = solo_split(dbs[0])
+        if sp and sp[0] and sp[2]:
+            print(f"\n# bev_pool_fwd_cells_vec_kernel by setting: SOLO launches (nothing else on the GPU; what roofline.kernel_ms reports) "
+                  f"n={sp[0]} avg {sp[1]:.2f} us; launches inside the step (LiDAR branch beside them; roofline.kernel_ms_in_step) "
+                  f"n={sp[2]} avg {sp[3]:.2f} us — the table's average above mixes the two")
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         print(f"\n# PMC ({os.path.relpath(f, d)}): mean counter value per dispatch")
         for k, cs in pmc_from_csv(f).items():
