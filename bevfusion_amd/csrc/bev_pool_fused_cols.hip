@@ -109,6 +109,27 @@ __global__ __launch_bounds__(256) void bev_fused_prow_start_kernel(const uint32_
   prow_start[c] = lo;
 }
 
+// Round 5: a run that is ALONE in its cell needs no second pass — its partial row IS the cell (x + 0 is exact, so the bits are the
+// ones pass 2 would have stored).  On the benchmark rig 453 888 runs fall into 363 752 cells: four cells of five hold one run.
+// Such a run's entry in slot_of_run becomes (1 << 31 | output row of its cell); pass 1 stores it straight into `out`, pass 2
+// skips one-run cells: 145 MB of partial rows written and read back per 8 frames shrink to the multi-run cells' share.
+constexpr uint32_t RUN_DIRECT = 0x80000000u;
+__global__ __launch_bounds__(256) void bev_fused_mark_single_kernel(const uint32_t* __restrict__ sorted_keys,
+                                                                    const uint32_t* __restrict__ prow_start, uint32_t nruns,
+                                                                    uint32_t per_frame, int D, int H, int W,
+                                                                    uint32_t* __restrict__ slot_of_run) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= nruns) return;
+  const uint32_t slot = slot_of_run[i];
+  const uint32_t cell = sorted_keys[slot];                      // frame-major: b * per_frame + (x * W + y) * D + z
+  if (prow_start[cell + 1] - prow_start[cell] != 1u) return;
+  const uint32_t b = cell / per_frame;
+  uint32_t local = cell - b * per_frame;
+  const uint32_t gz = local % (uint32_t)D; local /= (uint32_t)D;
+  const uint32_t gy = local % (uint32_t)W, gx = local / (uint32_t)W;
+  slot_of_run[i] = RUN_DIRECT | (((b * (uint32_t)D + gz) * (uint32_t)H + gx) * (uint32_t)W + gy);   // row of out [b, z, x, y, :]
+}
+
 // ---- pass 1 ---------------------------------------------------------------------------------------------------------------
 struct alignas(16) CU4 { uint32_t x, y, z, w; };
 
@@ -120,7 +141,7 @@ template <bool CTX_BF16>
 __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
     const float* __restrict__ depth, const void* __restrict__ ctx_, const uint32_t* __restrict__ keep,
     const uint32_t* __restrict__ endm, const uint32_t* __restrict__ run_first, const uint32_t* __restrict__ slot_of_run,
-    float* __restrict__ partial, ColDims s) {
+    float* __restrict__ partial, float* __restrict__ out, ColDims s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int C = s.C, fH = s.fH, lpr = C >> 2;
   float* s_ctx = lds;                                        // [fH][4][C]
@@ -255,7 +276,8 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
         if ((en[j] >> e) & 1u) {
           const uint32_t slot = slot_of_run[rf[j]];
           ++rf[j];
-          ((float4*)partial)[(size_t)slot * lpr + cv] = acc[j];
+          float4* dst = (slot & RUN_DIRECT) ? (float4*)out + (size_t)(slot & ~RUN_DIRECT) * lpr : (float4*)partial + (size_t)slot * lpr;
+          dst[cv] = acc[j];   // alone in its cell: straight into the output row
           acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -291,7 +313,7 @@ __device__ __forceinline__ float4 reduce_rows(const float4* __restrict__ p, int 
 __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __restrict__ partial,
                                                                const uint32_t* __restrict__ prow_start, uint32_t ncells,
                                                                float* __restrict__ out, int lpr, int rpi, int B, int D, int H, int W,
-                                                               int C) {
+                                                               int C, int direct) {
   const int lane = threadIdx.x & 63;
   const int slot = lane / lpr, cv = lane - slot * lpr;
   if (slot >= rpi) return;
@@ -308,8 +330,9 @@ __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __r
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* p0 = partial + (size_t)s0 * lpr + cv;
     const float4* p1 = partial + (size_t)s1 * lpr + cv;
-    const float4 a = len0 > 0 ? p0[0] : z, b = len0 > 1 ? p0[lpr] : z;
-    const float4 c = len1 > 0 ? p1[0] : z, d = len1 > 1 ? p1[lpr] : z;
+    // (a one-run cell's row went straight to `out` in pass 1: its slot of `partial` was never written and is not read)
+    const float4 a = len0 > (direct ? 1 : 0) ? p0[0] : z, b = len0 > 1 ? p0[lpr] : z;
+    const float4 c = len1 > (direct ? 1 : 0) ? p1[0] : z, d = len1 > 1 ? p1[lpr] : z;
     // same association as reduce_rows for <= 2 rows: (a + b) + (0 + 0)
     acc0 = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     acc1 = make_float4(c.x + d.x, c.y + d.y, c.z + d.z, c.w + d.w);
@@ -327,8 +350,9 @@ __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __r
     // out[b, z, x, y, :] (bev_pool_cuda.cu:33-35)
     *((float4*)(out + ((((size_t)b * D + gz) * H + gx) * W + gy) * (size_t)C) + cv) = acc;
   };
-  store(c0, acc0);
-  if (ok1) store(c1, acc1);
+  // a cell with exactly one run was stored by pass 1 (RUN_DIRECT): nothing to do here (direct == 0: plans built without the marks)
+  if (!(direct && len0 == 1)) store(c0, acc0);
+  if (ok1 && !(direct && len1 == 1)) store(c1, acc1);
 }
 
 // ---- backward by columns ---------------------------------------------------------------------------------------------------
@@ -577,7 +601,8 @@ int bevamd_bev_pool_fused_columns_count(const uint32_t* cell_of_point, int n, in
 }
 
 /* Column plan, step 2: slot_of_run [nruns] (position of every run in the (frame, cell)-sorted order; stable: runs of a cell
- * stay in (camera, d, w, h) order) and prow_start [b*d*h*w + 1] (CSR of the sorted runs over FRAME-MAJOR cells:
+ * stay in (camera, d, w, h) order; round 5: a run that is ALONE in its cell carries 1 << 31 | row of `out` instead, and the forward
+ * stores it straight into the output) and prow_start [b*d*h*w + 1] (CSR of the sorted runs over FRAME-MAJOR cells:
  * cell = frame * d*h*w + (x * w + y) * d + z).  nruns = the value step 1 left in total_runs.
  * ws: bevamd_bev_pool_fused_columns_workspace_bytes(n / fh, nruns). */
 int bevamd_bev_pool_fused_columns_build(const uint32_t* cell_of_point, const uint32_t* endm, const uint32_t* run_first, int n,
@@ -617,6 +642,11 @@ int bevamd_bev_pool_fused_columns_build(const uint32_t* cell_of_point, const uin
   bev_fused_prow_start_kernel<<<dim3(cdiv((long long)ncells + 1, 256)), dim3(256), 0, stream>>>(sorted_keys, (uint32_t)nruns, ncells,
                                                                                                prow_start);
   BEVAMD_LAUNCH_CHECK("bev_fused_prow_start");
+  if (nruns > 0 && ncells < RUN_DIRECT) {   // runs alone in their cell: slot -> (1 << 31 | output row), see bev_fused_mark_single_kernel
+    bev_fused_mark_single_kernel<<<dim3(cdiv(nruns, 256)), dim3(256), 0, stream>>>(sorted_keys, prow_start, (uint32_t)nruns,
+                                                                                   ncells / (uint32_t)b, d, h, w, slot_of_run);
+    BEVAMD_LAUNCH_CHECK("bev_fused_mark_single");
+  }
   return BEVAMD_OK;
 }
 
@@ -660,15 +690,15 @@ int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, i
     const int total = s.BN * s.nwb * s.ndh;
     const dim3 grid(((total + 7) / 8) * 8), block(COL_THREADS);
     if (ctx_is_bf16)
-      bev_fused_cols_kernel<true><<<grid, block, lds_bytes, stream>>>(depth, ctx, keep, endm, run_first, slot_of_run, partial, s);
+      bev_fused_cols_kernel<true><<<grid, block, lds_bytes, stream>>>(depth, ctx, keep, endm, run_first, slot_of_run, partial, out, s);
     else
-      bev_fused_cols_kernel<false><<<grid, block, lds_bytes, stream>>>(depth, ctx, keep, endm, run_first, slot_of_run, partial, s);
+      bev_fused_cols_kernel<false><<<grid, block, lds_bytes, stream>>>(depth, ctx, keep, endm, run_first, slot_of_run, partial, out, s);
     BEVAMD_LAUNCH_CHECK("bev_fused_cols");
   }
   const int lpr = c / 4, rpi = 64 / lpr > 0 ? 64 / lpr : 0;
   BEVAMD_REQUIRE(rpi > 0, "bev_pool_fused_forward_columns: c=%d needs more than 64 lanes per row", c);
   bev_fused_reduce_kernel<<<dim3(cdiv(cdiv(ncells, 2 * rpi), 4)), dim3(256), 0, stream>>>((const float4*)partial, prow_start, ncells, out,
-                                                                                     lpr, rpi, b, d, h, w, c);
+                                                                                     lpr, rpi, b, d, h, w, c, ncells < RUN_DIRECT ? 1 : 0);
   BEVAMD_LAUNCH_CHECK("bev_fused_reduce");
   return BEVAMD_OK;
 }

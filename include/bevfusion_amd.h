@@ -157,7 +157,8 @@ int bevamd_bev_pool_fused_forward_scheduled(const float* depth, const void* ctx,
  * Plan (static per calibration, built from cell_of_point of bevamd_bev_pool_cell_of_point):
  *   _columns_count : keep / end [cams*depth_bins*fw] row masks (bit h: row kept by the range mask / row closes a run),
  *                    run_first [cams*depth_bins*fw] (runs before the column), total_runs (device uint32);
- *   _columns_build : slot_of_run [nruns] (position of a run in the stable (frame, cell) order), prow_start [b*d*h*w + 1]
+ *   _columns_build : slot_of_run [nruns] (position of a run in the stable (frame, cell) order; a run alone in its cell: 1 << 31 |
+ *                    its row of out, stored by pass 1 directly — round 5), prow_start [b*d*h*w + 1]
  *                    (CSR over frame-major cells).  nruns = *total_runs read back once by the caller (plan time).
  * Shapes: c % 4 == 0, fh <= 32, fw % 4 == 0 (bevamd_bev_pool_fused_columns_supported); plans with about as many runs as points
  * (a camera rolled by 90 degrees) should stay on the cell-centric kernels above. */

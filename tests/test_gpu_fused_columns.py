@@ -105,9 +105,17 @@ def test_column_plan_against_numpy(dev):
     order = np.argsort(run_keys, kind="stable")
     slot = np.empty_like(order)
     slot[order] = np.arange(order.shape[0])
-    assert np.array_equal(cols.slot_of_run.cpu().numpy()[: cols.nruns], slot)
     start = np.searchsorted(run_keys[order], np.arange(B * per_frame + 1), side="left")
     assert np.array_equal(cols.prow_start.cpu().numpy(), start)
+    # round 5: a run that is alone in its cell carries (1 << 31 | row of out [b, z, x, y]) instead of its slot
+    cell_of_run = run_keys                                            # frame-major: b * per_frame + (x * W + y) * Dz + z
+    alone = (start[cell_of_run + 1] - start[cell_of_run]) == 1
+    b_, local = cell_of_run // per_frame, cell_of_run % per_frame
+    gz, gy, gx = local % Dz, (local // Dz) % W, local // (Dz * W)
+    out_row = ((b_ * Dz + gz) * H + gx) * W + gy
+    want = np.where(alone, (1 << 31) | out_row, slot).astype(np.uint32)
+    assert alone.any() and (~alone).any()
+    assert np.array_equal(cols.slot_of_run.cpu().numpy()[: cols.nruns].view(np.uint32), want)
 
 
 rigged_geometry = synth.rigged_geometry   # moved into the package: bench.py times the fused pooling on such a rig too

@@ -160,5 +160,6 @@ def test_statistics_of_channels_with_a_large_mean(dev):
     assert float(((our_bn.running_var.double() - want).abs() / want).max()) <= 1e-5
     assert float(((our_bn.running_var - ref_bn.running_var).abs() / ref_bn.running_var).max()) <= 1e-5
     assert torch.allclose(our_bn.running_mean, ref_bn.running_mean, rtol=1e-6, atol=1e-5)
-    # normalised outputs: unit variance per channel, and equal to torch's within fp32 rounding of (x - mean) * invstd at |x| ~ 300
-    assert float((yo - yr).abs().max()) <= 2e-3 and float((yo.double().var(0) - 1.0).abs().max()) <= 1e-3
+    # normalised outputs: variance var / (var + eps) per channel, and equal to torch's within fp32 rounding of (x - mean) * invstd at |x| ~ 300
+    vb = x.double().var(0, unbiased=False)
+    assert float((yo - yr).abs().max()) <= 2e-3 and float((yo.double().var(0, unbiased=False) - vb / (vb + 1e-5)).abs().max()) <= 1e-3

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r05_tests.log 2>&1
 echo "== tests rc=$?"; grep -E "^E |FAILED|passed|failed" gpurun_out/r05_tests.log | tail -4 | cut -c1-300
-timeout 900 python bench.py > gpurun_out/r05_bench.log 2>gpurun_out/r05_bench.err
+timeout 900 python bench.py > gpurun_out/r05_bench.log 2>gpurun_out/r05_bench.err; cp gpurun_out/bench_last_full.json gpurun_out/r05_bench_full.json
 echo "== bench rc=$?"; grep "^{" gpurun_out/r05_bench.log | tail -1 > gpurun_out/r05_bench_line.json; cut -c1-300 gpurun_out/r05_bench_line.json
 # kernel-trace stats + timeline of the default step
 rm -rf gpurun_out/prof_r05
@@ -24,7 +24,7 @@ head -3 gpurun_out/r05_step_timeline_batch1.txt | tail -1
 bash tools/pmc_bench.sh infer --no-graph > gpurun_out/r05_pmc_run.log 2>&1
 cp gpurun_out/pmcb_infer.txt gpurun_out/r05_pmc_infer_per_kernel.txt; cp gpurun_out/pmcb_infer.json gpurun_out/r05_pmc_infer_per_kernel.json
 head -12 gpurun_out/r05_pmc_infer_per_kernel.txt | cut -c1-160
-python tools/spconv_layers_profile.py gpurun_out/prof_r05 gpurun_out/pmcb_infer gpurun_out/r05_bench_line.json gpurun_out/r05_spconv_layers.json > gpurun_out/r05_spconv_layers.txt 2>&1
+python tools/spconv_layers_profile.py gpurun_out/prof_r05 gpurun_out/pmcb_infer gpurun_out/r05_bench_full.json gpurun_out/r05_spconv_layers.json > gpurun_out/r05_spconv_layers.txt 2>&1
 head -30 gpurun_out/r05_spconv_layers.txt | cut -c1-200
 python tools/update_bev_pool_traffic.py gpurun_out/pmcb_infer.json 5 > gpurun_out/r05_bev_pool_traffic.log 2>&1; cp profiles/bev_pool_traffic.json gpurun_out/r05_bev_pool_traffic.json; tail -4 gpurun_out/r05_bev_pool_traffic.log
 # training step: lines + kernel trace of the --amp step

@@ -37,7 +37,11 @@ def groups(seq):
 
 def main():
     trace_dir, pmc_dir, bench_json, out = sys.argv[1:5]
-    line = json.loads(open(bench_json).read().strip().split("\n")[-1])
+    text = open(bench_json).read().strip()
+    try:
+        line = json.loads(text)                       # the full result of a run (profiles/bench_last_full.json, round 5)
+    except ValueError:
+        line = json.loads(text.split("\n")[-1])       # a bench line of rounds 1-4
     layers = line["roofline_spconv"]["layers"]
     assert len(layers) == NL
     db = sqlite3.connect(glob.glob(os.path.join(trace_dir, "**", "*.db"), recursive=True)[0])
