@@ -913,15 +913,17 @@ def main():
     roofline_spconv = None
     if sp_dtype != torch.float32:
         _fused.LAYER_PROFILE = []
+        _fused.LAYER_PROFILE_REPS = 5    # 5 back-to-back launches per layer between the events (a single launch behind a sync runs down-clocked)
         try:
             lidar_branch()
             layers = _fused.summarize_layer_profile(_fused.LAYER_PROFILE, elem_bytes=2)
         finally:
             _fused.LAYER_PROFILE = None
+            _fused.LAYER_PROFILE_REPS = 1
         tot_us, tot_gf = sum(l["us"] for l in layers), sum(l["gflop"] for l in layers)
         roofline_spconv = {
-            "note": "21 convolutions of the SparseEncoder, one eager pass with the rulebooks already built (HIP events per launch, "
-                    "host-serialised: slightly above the in-graph times). FLOP = 2*pairs*Cin*Cout (real pairs only); ideal bytes = "
+            "note": "21 convolutions of the SparseEncoder, one eager pass with the rulebooks already built (HIP events around 5 back-to-back "
+                    "launches of every layer, nothing beside them). FLOP = 2*pairs*Cin*Cout (real pairs only); ideal bytes = "
                     "N_in*Cin*2 + pairs*8 + K*Cin*Cout*2 + N_out*Cout*2 (SURVEY.md 8d). Peaks: 2.5 PFLOP/s dense fp16 MFMA, 8 TB/s. "
                     "The op is neither: rows live in L2 and 133 GFLOP/frame is < 0.1 ms of MFMA — fractions are for orientation.",
             "total_us": tot_us, "total_gflop": tot_gf, "tflops": tot_gf * 1e3 / tot_us, "frac_mfma_peak": tot_gf * 1e3 / tot_us / 2500.0,

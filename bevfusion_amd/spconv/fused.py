@@ -52,6 +52,10 @@ _PREFETCHING = [False]   # inside prefetch_geometry: products are built behind t
 # Per-layer profile (bench.py's `roofline_spconv`): set to a list and every fused convolution appends a record with HIP events
 # around its launch and, after a sync, its pair count.  None (default) = no overhead.  Only meaningful in eager passes.
 LAYER_PROFILE = None
+# launches per layer between the two HIP events of a profiled pass (the launch is idempotent: it reads its inputs and writes `out`).
+# One launch behind a device-wide sync starts on an idle, down-clocked GPU: round 5 measured 206-223 us for a 64 -> 64 layer that takes
+# 172-176 us back to back (tools/time_slab_variant.py) and 186-192 us inside the replayed graph.  bench.py profiles with 5.
+LAYER_PROFILE_REPS = 1
 
 
 def geometry_stream(device):
@@ -413,22 +417,24 @@ def _conv(conv, x, bn=None, relu=False, residual=None):
                    start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True),
                    n_in=lvl.n_dev, n_out=out_lvl.n_dev, n_in_cap=lvl.n_cap, n_out_cap=out_lvl.n_cap, nbr=nbr)
         rec["start"].record()
-    if slab_variant is not None:
-        rows = ops.slab_block_rows(cin, slab_variant)
-        meta = lvl.subm_slab(rows) if conv.subm else lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, rows)
-        ops.sparse_conv_slab(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
-                             residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out, variant=slab_variant)
-    elif slots_meta:
-        meta = lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, _GATHER_SLOT_ROWS)
-        ops.sparse_conv_tiled_slots(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
-                                    residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
-                                    variant=_variant_for(_frames_equivalent(lvl), K, cin, cout))
-    else:
-        ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
-                              residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
-                              variant=_variant_for(_frames_equivalent(lvl), K, cin, cout))
+    for _ in range(LAYER_PROFILE_REPS if rec is not None else 1):
+        if slab_variant is not None:
+            rows = ops.slab_block_rows(cin, slab_variant)
+            meta = lvl.subm_slab(rows) if conv.subm else lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, rows)
+            ops.sparse_conv_slab(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
+                                 residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out, variant=slab_variant)
+        elif slots_meta:
+            meta = lvl.down_slab(conv.kernel_size, conv.stride, conv.padding, _GATHER_SLOT_ROWS)
+            ops.sparse_conv_tiled_slots(x.features, image, meta, out_lvl.n_cap, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
+                                        residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
+                                        variant=_variant_for(_frames_equivalent(lvl), K, cin, cout))
+        else:
+            ops.sparse_conv_tiled(x.features, image, nbr, out_lvl.n_cap, K, cin, cout, bias=bias, bn_scale=scale, bn_shift=shift,
+                                  residual=residual, relu=relu, num_out_dev=out_lvl.n_dev, out=out,
+                                  variant=_variant_for(_frames_equivalent(lvl), K, cin, cout))
     if rec is not None:
         rec["end"].record()
+        rec["reps"] = LAYER_PROFILE_REPS
         LAYER_PROFILE.append(rec)
     return FusedTensor(out, out_lvl)
 
@@ -443,7 +449,7 @@ def summarize_layer_profile(records, elem_bytes=2):
         n_in = int(r["n_in"].item()) if r["n_in"] is not None else r["n_in_cap"]
         n_out = int(r["n_out"].item()) if r["n_out"] is not None else r["n_out_cap"]
         pairs = int((r["nbr"][:, :n_out] >= 0).sum().item())
-        us = r["start"].elapsed_time(r["end"]) * 1e3
+        us = r["start"].elapsed_time(r["end"]) * 1e3 / max(int(r.get("reps", 1)), 1)
         flop = 2.0 * pairs * r["cin"] * r["cout"]
         ideal = n_in * r["cin"] * elem_bytes + pairs * 8 + r["K"] * r["cin"] * r["cout"] * elem_bytes + n_out * r["cout"] * elem_bytes
         out.append(dict(layer=f"{'subm' if r['subm'] else 'conv'} {r['cin']}->{r['cout']} K={r['K']}", kernel=r["kernel"],
