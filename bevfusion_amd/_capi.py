@@ -93,6 +93,10 @@ _SIGNATURES = {
     "bevamd_spconv_filter_image_elems": (Z, [I, I, I, I]),
     "bevamd_spconv_make_filter_image": (I, [P, I, I, I, I, I, P, P]),
     "bevamd_spconv_conv_forward_tiled": (I, [P, I, I, I, P, P, I, I, P, I, I, I, P, I, P, P, P, P, I, I, I, P]),
+    "bevamd_spconv_f32x3_supported": (I, [I, I]),
+    "bevamd_spconv_filter_image3_elems": (Z, [I, I, I, I]),
+    "bevamd_spconv_make_filter_image3": (I, [P, I, I, I, I, P, P]),
+    "bevamd_spconv_conv_forward_f32x3": (I, [P, I, I, P, P, I, I, P, I, I, I, P, I, P, P, P, P, I, I, P]),
     "bevamd_spconv_conv_forward_tiled_slots": (I, [P, I, I, I, P, P, P, I, I, P, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_pad_cast_rows": (I, [P, I, I, I, I, P, P]),
     "bevamd_spconv_slab_set_profile_buffer": (None, [P]),

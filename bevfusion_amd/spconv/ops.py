@@ -7,6 +7,8 @@ Two layers:
   * `sparse_conv_ext.*` and the reference-named helpers (`get_indice_pairs`, `indice_conv`,
     `indice_conv_backward`, ...) with the reference's exact signatures and array shapes, for drop-in use.
 """
+import os
+
 import torch
 
 from .. import _capi
@@ -455,6 +457,59 @@ def _pad_channels(features, pitch):
     return torch.nn.functional.pad(features, (0, pitch - features.shape[1]))
 
 
+# fp32 features on the bf16 matrix cores by three-way operand splitting (csrc/spconv_tile_f32x3.hip, round 5): x = hi + mid + lo
+# exactly, six MFMAs per product, fp32 accumulate — error of the order of one fp32 rounding, 2.5-4 x the rate of the exact-chain fp32
+# kernel on the encoder's layers.  BEVAMD_SPCONV_F32X3 = "auto" (default: from _F32X3_MIN_ROWS output rows on, where the fp32
+# training step spends its time; small problems keep the exact-chain kernel), "1" (whenever the shape is served), "0" (never).
+_F32X3 = os.environ.get("BEVAMD_SPCONV_F32X3", "auto")
+_F32X3_MIN_ROWS = 4096
+
+
+def f32x3_supported(cin, cout):
+    return bool(_capi.load().bevamd_spconv_f32x3_supported(int(cin), int(cout)))
+
+
+def make_filter_image3(filters, transpose_io=False):
+    """fp32 filter [kx,ky,kz,Cin,Cout] -> the three bf16 images (hi, mid, lo by truncation) in MFMA-fragment order."""
+    lib = _capi.load()
+    f = filters.detach().contiguous().float()
+    _require_cuda(f, "filters")
+    cin, cout = f.shape[-2], f.shape[-1]
+    K = f.numel() // (cin * cout)
+    with torch.cuda.device(f.device):
+        elems = lib.bevamd_spconv_filter_image3_elems(K, cin, cout, int(transpose_io))
+        if elems == 0:
+            raise RuntimeError(f"no f32x3 kernel for {cin} -> {cout} channels")
+        img = torch.empty(elems, dtype=torch.int16, device=f.device)
+        rc = lib.bevamd_spconv_make_filter_image3(_capi.ptr(f), K, cin, cout, int(transpose_io), _capi.ptr(img), _capi.stream_ptr(f.device))
+    _capi.check(rc, "spconv_make_filter_image3")
+    return img
+
+
+def sparse_conv_f32x3(features, image3, nbr, num_out, kernel_volume, cin, cout, bias=None, bn_scale=None, bn_shift=None,
+                      residual=None, relu=False, num_out_dev=None, out=None):
+    """fp32 rows [N, cin] (cin = 16 | 32 | 64 | 128) x make_filter_image3 -> fp32 [num_out, cout], same fused epilogue contract."""
+    _require_cuda(features, "features")
+    lib = _capi.load()
+    if features.dtype != torch.float32:
+        raise RuntimeError("sparse_conv_f32x3: fp32 features only")
+    features = features.contiguous()
+    if out is None:
+        out = torch.empty((num_out, cout), dtype=torch.float32, device=features.device)
+    if num_out == 0:
+        return out
+    bias = None if bias is None else bias.float().contiguous()
+    residual = None if residual is None else residual.float().contiguous()
+    with torch.cuda.device(features.device):
+        rc = lib.bevamd_spconv_conv_forward_f32x3(
+            _capi.ptr(features), features.stride(0), features.shape[0], _capi.ptr(image3), _capi.ptr(nbr), nbr.shape[1], int(num_out),
+            _capi.ptr(num_out_dev), int(kernel_volume), int(cin), int(cout), _capi.ptr(out), out.stride(0), _capi.ptr(bias),
+            _capi.ptr(bn_scale), _capi.ptr(bn_shift), _capi.ptr(residual), 0 if residual is None else residual.stride(0),
+            int(bool(relu)), _capi.stream_ptr(features.device))
+    _capi.check(rc, "spconv_conv_forward_f32x3")
+    return out
+
+
 def sparse_conv(features, filters, nbr, num_out, bias=None, bn_scale=None, bn_shift=None, residual=None, relu=False,
                 prepared=None, transpose_io=False):
     """out[o] = epilogue(sum_k features[nbr[k, o]] @ W[k]) — one fused launch.  filters [kx,ky,kz,Cin,Cout]."""
@@ -478,6 +533,10 @@ def sparse_conv(features, filters, nbr, num_out, bias=None, bn_scale=None, bn_sh
             residual = residual.to(features.dtype)
         return sparse_conv_tiled(feats, image, nbr, num_out, K, cin, cout, bias=bias, bn_scale=bn_scale,
                                  bn_shift=bn_shift, residual=residual, relu=relu)
+    if (prepared is None and features.dtype == torch.float32 and _F32X3 != "0" and f32x3_supported(cin, cout)
+            and (_F32X3 == "1" or num_out >= _F32X3_MIN_ROWS)):
+        return sparse_conv_f32x3(features, make_filter_image3(filters, transpose_io), nbr, num_out, K, cin, cout, bias=bias,
+                                 bn_scale=bn_scale, bn_shift=bn_shift, residual=residual, relu=relu)
     if prepared is None:
         prepared = prepare_filters(filters, transpose_io)
     out = torch.empty((num_out, cout), dtype=features.dtype, device=features.device)

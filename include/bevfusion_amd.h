@@ -464,6 +464,21 @@ int bevamd_spconv_conv_forward(const void* features, int dtype, const void* prep
                                int cin, int cout, void* out, const void* bias, const float* bn_scale,
                                const float* bn_shift, const void* residual, int relu, void* stream);
 
+/* fp32 sparse convolution on the bf16 matrix cores by three-way operand splitting (round 5).  Replaces
+ * sparse_conv_ext.indice_conv_fp32 and the input-gradient half of indice_conv_backward_fp32 (spconv/src/all.cc:28-31 ->
+ * spconv_ops.h:260-456) for fp32 rows of exactly 16 | 32 | 64 | 128 channels, cout <= 128: x = hi + mid + lo (bf16 pieces by
+ * truncation, exact), six v_mfma_f32_16x16x32_bf16 per product with fp32 accumulation — error of the order of one fp32 rounding.
+ * image: bevamd_spconv_make_filter_image3 of the fp32 filters [K, cin, cout] (transpose_io = 1: the input-gradient pass on the
+ * transposed table); nbr / epilogue operands as bevamd_spconv_conv_forward (all fp32).  csrc/spconv_tile_f32x3.hip. */
+int bevamd_spconv_f32x3_supported(int cin, int cout);
+size_t bevamd_spconv_filter_image3_elems(int kernel_volume, int cin, int cout, int transpose_io);   /* uint16 elements */
+int bevamd_spconv_make_filter_image3(const float* filters, int kernel_volume, int cin, int cout, int transpose_io, void* image,
+                                     void* stream);
+int bevamd_spconv_conv_forward_f32x3(const float* features, int feat_stride, int num_in, const void* image, const int* nbr,
+                                     int nbr_stride, int num_out, const int* num_out_dev, int kernel_volume, int cin, int cout,
+                                     float* out, int out_stride, const float* bias, const float* bn_scale, const float* bn_shift,
+                                     const float* residual, int residual_stride, int relu, void* stream);
+
 /* Tiled forward for 16-bit features (dtype 1 = fp16, 2 = bf16; channels <= 128) — the kernel the modules
  * use at inference.  Same operator as bevamd_spconv_conv_forward (sparse_conv_ext.indice_conv_half /
  * fused_indice_conv_half, all.cc:28-37 -> spconv_ops.h:260-361), with
