@@ -2,7 +2,7 @@
 VERDICT r4 item 8) through the C ABI.
 
 Reference op: spconv_ops.h:260-361 indiceConv<float> and the input-gradient half of :363-456 indiceConvBackward<float>.  Bars: the
-fp32 bar of the exact-chain kernel, 2e-5 * (1 + max|ref|) against the float64 oracle; 1e-5 against the exact-chain fp32 kernel
+4e-6 * (1 + max|ref|) against the float64 oracle (the exact-chain kernel's own bar is 2e-5); 5e-6 against the exact-chain fp32 kernel
 (spconv_conv.hip) on the same inputs; the split itself exact (hi + mid + lo == w bit for bit); bit-reproducible run to run."""
 import numpy as np
 import pytest
@@ -15,7 +15,7 @@ from conftest import record_parity
 from test_gpu_spconv import _random_indices
 
 pytestmark = pytest.mark.gpu
-BAR64, BAR32 = 2e-5, 1e-5
+BAR64, BAR32 = 4e-6, 5e-6      # observed on an MI355X: <= 1.2e-6 against float64, <= 1.9e-6 against the exact-chain kernel (profiles/r05_parity_observed.json)
 
 
 def bf16_to_f32(u16):
@@ -114,8 +114,8 @@ def test_autograd_goes_through_the_split_kernels(dev, subm):
     y, gi, gw = (a.astype(np.float64) for a in res["1"])
     yref = oracle.indice_conv(f, w, pairs, num, oi.shape[0])
     assert np.abs(y - yref).max() <= BAR64 * (1 + np.abs(yref).max())
-    record_parity(f"spconv f32x3 input gradient vs float64 oracle (subm={subm})", np.abs(gi - gi_ref).max() / (1 + np.abs(gi_ref).max()), 5e-5)
-    assert np.abs(gi - gi_ref).max() <= 5e-5 * (1 + np.abs(gi_ref).max())
+    record_parity(f"spconv f32x3 input gradient vs float64 oracle (subm={subm})", np.abs(gi - gi_ref).max() / (1 + np.abs(gi_ref).max()), 4e-6)
+    assert np.abs(gi - gi_ref).max() <= 4e-6 * (1 + np.abs(gi_ref).max())        # observed 7.6e-7
     assert np.abs(gw - gw_ref).max() <= 2e-4 * (1 + np.abs(gw_ref).max())
     assert np.abs(y - res["0"][0]).max() <= BAR32 * (1 + np.abs(yref).max()) and np.abs(gi - res["0"][1]).max() <= BAR32 * (1 + np.abs(gi_ref).max())
     assert np.array_equal(res["1"][2], res["0"][2])               # the filter gradient does not depend on the forward's flavour
