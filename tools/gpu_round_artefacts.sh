@@ -37,4 +37,7 @@ rm -rf gpurun_out/prof_r05t
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r05t -o b -- python $R/bench.py --mode train-step --amp --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_r05t_run.log 2>&1)
 python tools/rocprof_summary.py gpurun_out/prof_r05t > gpurun_out/r05_train_step_amp_kernel_trace_stats.txt 2>&1
 head -12 gpurun_out/r05_train_step_amp_kernel_trace_stats.txt | cut -c1-150
+rm -rf gpurun_out/prof_r05tf
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r05tf -o b -- python $R/bench.py --mode train-step --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_r05tf_run.log 2>&1)
+python tools/rocprof_summary.py gpurun_out/prof_r05tf > gpurun_out/r05_train_step_fp32_kernel_trace_stats.txt 2>&1
 find gpurun_out -name "*.db" -delete; find gpurun_out/pmcb_infer -name "*.csv" -size +4M -delete
