@@ -278,7 +278,7 @@ def compact_line(res, side_file=None):
     rf = res.get("roofline")
     if rf:
         out["roofline"] = {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                  "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_in_step", "measured") if k in rf}
+                                                  "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_in_step", "frac_in_step", "measured") if k in rf}
     else:
         out["roofline"] = None
     cb = res.get("cpu_baseline")
@@ -1537,8 +1537,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": roof_ms,
                 "kernel_ms_in_step": kern_ms,
-                "measured": ("solo: HIP events around 20 back-to-back launches right after the timed region (in the step the rulebook "
-                             "chain runs beside the kernel: kernel_ms_in_step)") if solo_ms is not None else
+                "frac_in_step": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "measured": ("solo: HIP events around 20 back-to-back launches right after the timed region (inside the step the LiDAR "
+                             "branch shares the machine with the kernel: kernel_ms_in_step, frac_in_step)") if solo_ms is not None else
                             "in the step: HIP events around the one launch of every timed step, nothing beside it",
             },
         }

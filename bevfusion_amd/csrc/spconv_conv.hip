@@ -297,12 +297,39 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(const typename E
 //     48 floats apart (consecutive rows 16 banks apart: the two 32-lane halves of a read hit disjoint banks).
 // Slab partials part[s][k][ci][co] and the fixed-order reduce are unchanged: deterministic, no atomics.
 // ---------------------------------------------------------------------------
+// Round 5, X3 flavour (fp32 rows only): the same walk, the products on the bf16 matrix cores by three-way operand splitting
+// (see spconv_tile_f32x3.hip: x = hi + mid + lo exactly, six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block instead of eight
+// v_mfma_f32_16x16x4_f32 at the fp32 vector rate: 96 against 256 MFMA cycles).  One MFMA reduces all 32 rows of the tile: lane
+// (i = l15, g = l4) supplies rows r = e * 4 + g (e = 0..7) of its channel — consecutive g are consecutive rows, 16 banks apart
+// with the 48-float row pitch, so the eight column reads are conflict-free; out_grad's fragments are split ONCE per tile and reused
+// by the wave's offsets.
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wg_split3(const float (&v)[8], wg_u32x4& hi, wg_u32x4& mid, wg_u32x4& lo) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = __float_as_uint(v[e]) & 0xFFFF0000u;
+    const float r1 = v[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+    l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    hi[p] = __builtin_amdgcn_perm(h[2 * p + 1], h[2 * p], 0x07060302u);
+    mid[p] = __builtin_amdgcn_perm(m[2 * p + 1], m[2 * p], 0x07060302u);
+    lo[p] = __builtin_amdgcn_perm(l[2 * p + 1], l[2 * p], 0x07060302u);
+  }
+}
+__device__ __forceinline__ f32x4 wg_mfma_bf16(const wg_u32x4& a, const wg_u32x4& b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
 constexpr int WG2_R = 32;          // rows per tile
 constexpr int WG2_NW = 4;          // waves per workgroup; wave w owns kernel offsets w, w + 4, ...
 constexpr int WG2_TARGET_WGS = 768;
 constexpr int WG2_MAX_SLABS = 256;
 
-template <int DT, int CIT, int COT, int KPW>
+template <int DT, int CIT, int COT, int KPW, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void spconv_wgrad2_kernel(const typename Elem<DT>::T* __restrict__ feat,
                                                             const typename Elem<DT>::T* __restrict__ gout,
                                                             const int* __restrict__ nbr, int nbr_stride, int m, int K, int cin,
@@ -366,6 +393,16 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad2_kernel(const typename El
       idx[kk] = (k < K && o < rend) ? nbr[(size_t)k * nbr_stride + o] : -1;
     }
     __syncthreads();   // the tile's out_grad is in place; (double buffer: nobody still reads the buffer the NEXT tile overwrites)
+    wg_u32x4 bh[COT], bm[COT], bl[COT];   // X3: out_grad fragments of the tile (rows e*4 + l4 of channel t*16 + l15), split once
+    if constexpr (X3) {
+#pragma unroll
+      for (int t = 0; t < COT; ++t) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fb[buf][(e * 4 + l4) * LDB + t * 16 + l15];
+        wg_split3(v, bh[t], bm[t], bl[t]);
+      }
+    }
     float4 nx[NLD];
     auto gather = [&](int kk) {
 #pragma unroll
@@ -390,18 +427,40 @@ __global__ __launch_bounds__(256, 2) void spconv_wgrad2_kernel(const typename El
       if (live) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tile is written (wave-private: no barrier)
         __builtin_amdgcn_wave_barrier();
+        if constexpr (X3) {
 #pragma unroll
-        for (int q = 0; q < R / 4; ++q) {
-          const int r = q * 4 + l4;
-          float a[CIT], b[COT];
+          for (int ta = 0; ta < CIT; ++ta) {
+            float v[8];
 #pragma unroll
-          for (int t = 0; t < CIT; ++t) a[t] = fa[w][r * LDA + t * 16 + l15];
+            for (int e = 0; e < 8; ++e) v[e] = fa[w][(e * 4 + l4) * LDA + ta * 16 + l15];
+            wg_u32x4 ah, am, al;
+            wg_split3(v, ah, am, al);
 #pragma unroll
-          for (int t = 0; t < COT; ++t) b[t] = fb[buf][r * LDB + t * 16 + l15];
+            for (int tb = 0; tb < COT; ++tb) {
+              f32x4 c = acc[kk][ta][tb];
+              c = wg_mfma_bf16(al, bh[tb], c);   // smallest terms first
+              c = wg_mfma_bf16(am, bm[tb], c);
+              c = wg_mfma_bf16(ah, bl[tb], c);
+              c = wg_mfma_bf16(am, bh[tb], c);
+              c = wg_mfma_bf16(ah, bm[tb], c);
+              c = wg_mfma_bf16(ah, bh[tb], c);
+              acc[kk][ta][tb] = c;
+            }
+          }
+        } else {
 #pragma unroll
-          for (int ta = 0; ta < CIT; ++ta)
+          for (int q = 0; q < R / 4; ++q) {
+            const int r = q * 4 + l4;
+            float a[CIT], b[COT];
 #pragma unroll
-            for (int tb = 0; tb < COT; ++tb) acc[kk][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[kk][ta][tb], 0, 0, 0);
+            for (int t = 0; t < CIT; ++t) a[t] = fa[w][r * LDA + t * 16 + l15];
+#pragma unroll
+            for (int t = 0; t < COT; ++t) b[t] = fb[buf][r * LDB + t * 16 + l15];
+#pragma unroll
+            for (int ta = 0; ta < CIT; ++ta)
+#pragma unroll
+              for (int tb = 0; tb < COT; ++tb) acc[kk][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[kk][ta][tb], 0, 0, 0);
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next offset overwrites the tile
         __builtin_amdgcn_wave_barrier();
@@ -714,6 +773,15 @@ static bool wgrad2_plan(int K, int cin, int cout, Wgrad2Plan& p, bool wide = fal
   p.max_slabs = sl < 1 ? 1 : sl > WG2_MAX_SLABS ? WG2_MAX_SLABS : sl;
   return true;
 }
+// BEVAMD_SPCONV_F32X3: 0 never, 1 whenever served, anything else (default) auto = from 4 096 rows on (ops.py reads the same variable)
+static int f32x3_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("BEVAMD_SPCONV_F32X3");
+    mode = !e ? 2 : (e[0] == '0' && !e[1]) ? 0 : (e[0] == '1' && !e[1]) ? 1 : 2;
+  }
+  return mode;
+}
 static bool wgrad_wide_enabled() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("BEVAMD_SPCONV_WGRAD_WIDE"); on = e ? atoi(e) != 0 : 1; }
@@ -764,9 +832,18 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
     nslabs = (num_out + rows_per_slab - 1) / rows_per_slab;
     float* part = (float*)ws;
     dim3 grid(nslabs, wp.nci, wp.nco), block(wp.nw * 64);
-#define BEVAMD_WG2(DT, T, CIT, COT, KPW) \
-  spconv_wgrad2_kernel<DT, CIT, COT, KPW><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
-                                                                      kernel_volume, cin, cout, wp.cinp, wp.coutp, rows_per_slab, part)
+    // fp32 rows from 4 096 on: the products on the bf16 matrix cores by three-way operand splitting (X3; BEVAMD_SPCONV_F32X3 = 0 | 1 | auto
+    // as for the forward / input gradient: one switch for the fp32 training path)
+    const bool x3 = dtype == DT_F32 && f32x3_mode() != 0 && (f32x3_mode() == 1 || num_out >= 4096);
+#define BEVAMD_WG2(DT, T, CIT, COT, KPW)                                                                                              \
+  do {                                                                                                                               \
+    if (x3) /* this macro is only expanded for DT_F32 */                                                                             \
+      spconv_wgrad2_kernel<DT, CIT, COT, KPW, true><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
+                                                                                        kernel_volume, cin, cout, wp.cinp, wp.coutp, rows_per_slab, part); \
+    else                                                                                                                             \
+      spconv_wgrad2_kernel<DT, CIT, COT, KPW><<<grid, block, 0, stream>>>((const T*)features, (const T*)out_grad, nbr, nbr_stride, num_out, \
+                                                                          kernel_volume, cin, cout, wp.cinp, wp.coutp, rows_per_slab, part); \
+  } while (0)
 #define BEVAMD_WG2_K(DT, T, CIT, COT)                                                          \
   do {                                                                                        \
     if (wp.kpw == 1) BEVAMD_WG2(DT, T, CIT, COT, 1); else if (wp.kpw == 2) BEVAMD_WG2(DT, T, CIT, COT, 2); \
