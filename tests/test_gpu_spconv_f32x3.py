@@ -162,5 +162,5 @@ def test_filter_gradient_on_the_split_kernels(dev, cin, cout):
     assert torch.equal(outs[0], outs[1])                                   # slab partials + fixed-order reduce: deterministic
     got = outs[0].cpu().numpy().astype(np.float64)
     err = np.abs(got - gw_ref).max() / (1 + np.abs(gw_ref).max())
-    record_parity(f"spconv fp32 filter gradient (X3 from 4096 rows) vs float64 oracle ({cin}->{cout})", err, 2e-5)
-    assert err <= 2e-5
+    record_parity(f"spconv fp32 filter gradient (X3 from 4096 rows) vs float64 oracle ({cin}->{cout})", err, 1e-6)
+    assert err <= 1e-6      # observed on an MI355X: <= 3.0e-7 (profiles/r05_parity_observed.json)
