@@ -34,7 +34,9 @@ def usable(bn, feats, residual=None):
 
 
 def _workspace(dev, c):
-    key = (dev, c)
+    # keyed by the issuing stream as well: the partial sums and the ticket word of a launch must not be shared by two
+    # BatchNorm calls running concurrently on different streams of one device (two models, an eager call beside a graph replay)
+    key = (dev.index, int(c), int(torch.cuda.current_stream(dev).cuda_stream))
     if key not in _WS:
         nbytes = int(_capi.load().bevamd_sparse_bn_workspace_bytes(c))
         _WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)   # zeroed once: the ticket word; every launch leaves it zero
