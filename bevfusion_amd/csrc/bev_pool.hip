@@ -62,7 +62,15 @@ __device__ __forceinline__ void decode_rank(uint32_t r, const BevDims& s, int& g
 // Sum rows [0,len) of one cell.  The calling lane takes rows r0, r0+step, ... and the 16-byte
 // column vector cv; U independent loads in flight per lane.  INDEXED: row r is ord[r], else rows
 // are contiguous from `first_row`.
-template <typename VecT, int VEC, int U, bool INDEXED>
+__device__ __forceinline__ void opaque_use(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void opaque_use(U4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void set_zero(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void set_zero(U4& v) { v.x = v.y = v.z = v.w = 0u; }
+
+// TAILP: the < U rows a lane has left after the unrolled trips go out as ONE batch of predicated loads (row indices first,
+// then the rows; a missing row adds +0: the same bits as the one-at-a-time loop) instead of one load per round trip — most
+// cells of a camera frustum are shorter than one unrolled trip, so for them this IS the whole walk.
+template <typename VecT, int VEC, int U, bool INDEXED, bool TAILP = false>
 __device__ __forceinline__ void accumulate_rows(Acc<VEC>& acc, const VecT* __restrict__ x,
                                                 const uint32_t* __restrict__ ord, size_t first_row, int len,
                                                 int r0, int step, int cv, int lpr) {
@@ -77,10 +85,34 @@ __device__ __forceinline__ void accumulate_rows(Acc<VEC>& acc, const VecT* __res
 #pragma unroll
     for (int u = 0; u < U; ++u) acc_add(acc, a[u]);
   }
-  for (; r < len; r += step) {
-    size_t row = INDEXED ? (size_t)ord[r] : first_row + (size_t)r;
-    VecT a0 = x[row * lpr + cv];
-    acc_add(acc, a0);
+  if constexpr (TAILP && U > 1) {
+    if (r < len) {
+      uint32_t rows[U - 1];
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        const int rr = r + u * step;
+        const int rc = rr < len ? rr : len - 1;                       // clamped: the index load itself is unconditional
+        rows[u] = INDEXED ? ord[rc] : (uint32_t)(first_row + (size_t)rc);
+      }
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) asm volatile("" : "+v"(rows[u]));   // (hipcc would sink an index load into its row's branch)
+      VecT a[U - 1];
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) {
+        set_zero(a[u]);
+        if (r + u * step < len) a[u] = x[(size_t)rows[u] * lpr + cv];
+      }
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) opaque_use(a[u]);                // every load issued before the first add waits
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u) acc_add(acc, a[u]);
+    }
+  } else {
+    for (; r < len; r += step) {
+      size_t row = INDEXED ? (size_t)ord[r] : first_row + (size_t)r;
+      VecT a0 = x[row * lpr + cv];
+      acc_add(acc, a0);
+    }
   }
 }
 
@@ -154,16 +186,67 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_intervals_scalar_kernel(
 // ---------------------------------------------------------------------------
 // forward over the cell CSR (native path): one launch writes every output cell
 // ---------------------------------------------------------------------------
-template <typename VecT, int VEC, int U>
-__global__ __launch_bounds__(256) void bev_pool_fwd_cells_vec_kernel(
+// SW > 0 = XCD-striped walk.  Workgroups go to the 8 XCDs round-robin (workgroup i -> XCD i % 8) and every XCD has its own
+// L2, so in plain order the half cache lines that the row runs of neighbouring cells share (a 320-byte row is 2.5 lines) are
+// fetched from HBM once per XCD that needs them.  Here the launch is one padded line of `pb` workgroups per (frame, grid row
+// x), pb % 8 == 0, and the 4-cell groups of a row are dealt so that stripe t (SW neighbouring groups) of EVERY grid row runs
+// on XCD t % 8: the cells on either side of a run end — the same stripe one grid row on, or the neighbouring group of the
+// stripe — then meet in ONE L2.  A row's groups rarely divide by 8 * SW (360 cells = 90 groups): the stripes left over after
+// the last full round of 8 are dealt from a start that rotates with the line, so that every XCD gets the same number of
+// groups over 8 lines (dealt from XCD 0 every time, two XCDs would carry 12 groups a row against 11: measured +6 % time).
+template <int SW>
+__device__ __forceinline__ bool striped_group(uint32_t p, uint32_t line, uint32_t rb, uint32_t shift, uint32_t& j) {
+  constexpr uint32_t G = 8u * SW;
+  const uint32_t stripes = (rb + SW - 1) / SW, full = stripes & ~7u, extra = stripes - full;
+  const uint32_t c = p / G, q = p - c * G, m = q >> 3;               // chunk of 8 stripes, member of the stripe
+  const uint32_t x = ((q & 7u) - shift) & 7u;                        // XCD q % 8 takes stripe x of the chunk
+  uint32_t st = c * 8u + x;
+  if (st >= full) {                                                  // the last, partial round
+    const uint32_t k = (x - line * extra) & 7u;
+    if (k >= extra) return false;
+    st = full + k;
+  }
+  j = st * SW + m;
+  return j < rb;
+}
+
+// TX > 1 = a workgroup of 4 * TX waves takes a TX x 4 tile of cells (TX neighbouring grid rows): the lines shared across
+// a grid-row boundary inside the tile are asked for by ONE compute unit, whichever XCD it sits on, and the launch order stays
+// the plain one.
+template <typename VecT, int VEC, int U, int SW = 0, bool TAILP = false, int TX = 1>
+__global__ __launch_bounds__(256 * TX) void bev_pool_fwd_cells_vec_kernel(
     const VecT* __restrict__ x, const uint32_t* __restrict__ order, const uint32_t* __restrict__ cell_start,
-    uint32_t ncells, float* __restrict__ out, int lpr, int rpi, BevDims s) {
+    uint32_t ncells, float* __restrict__ out, int lpr, int rpi, BevDims s, uint32_t pb = 0, uint32_t rot_rows = 0) {
   // cells are numbered b-fastest (the reference's rank); waves walk them frame-major, so that neighbouring waves read one
   // frame's slab of the feature volume and write neighbouring output rows (ncells = B*D*H*W)
-  const uint32_t lin = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (lin >= ncells) return;
-  const uint32_t per_frame = ncells / (uint32_t)s.B;
-  const uint32_t cell = (lin % per_frame) * (uint32_t)s.B + lin / per_frame;
+  uint32_t cell;
+  if constexpr (TX > 1) {
+    static_assert(SW == 0, "tiles or stripes");
+    const uint32_t w = threadIdx.x >> 6, tx = w >> 2, ty = w & 3u;
+    const uint32_t row_cells = (uint32_t)s.W * (uint32_t)s.D, rb = (row_cells + 3u) >> 2;
+    const uint32_t lp = ((uint32_t)s.H + TX - 1) / TX;               // tile rows per frame
+    const uint32_t lineg = blockIdx.x / rb, j = blockIdx.x - lineg * rb;
+    const uint32_t f = lineg / lp, xr = (lineg - f * lp) * TX + tx;
+    const uint32_t in_row = j * 4u + ty;
+    if (xr >= (uint32_t)s.H || in_row >= row_cells) return;
+    cell = (xr * row_cells + in_row) * (uint32_t)s.B + f;
+  } else if constexpr (SW == 0) {
+    const uint32_t lin = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (lin >= ncells) return;
+    const uint32_t per_frame = ncells / (uint32_t)s.B;
+    cell = (lin % per_frame) * (uint32_t)s.B + lin / per_frame;
+  } else {
+    const uint32_t line = blockIdx.x / pb, p = blockIdx.x - line * pb;   // line = frame * H + grid row
+    const uint32_t row_cells = (uint32_t)s.W * (uint32_t)s.D;
+    uint32_t j;
+    // rot_rows > 0: the stripe -> XCD map moves on by one XCD every rot_rows lines (a hot stripe — the cells beside the ego
+    // vehicle — then visits every XCD instead of loading one; the lines where it moves lose the sharing with the line before)
+    if (!striped_group<SW>(p, line, (row_cells + 3u) >> 2, rot_rows ? line / rot_rows : 0u, j)) return;
+    const uint32_t in_row = j * 4u + (threadIdx.x >> 6);
+    if (in_row >= row_cells) return;
+    const uint32_t f = line / (uint32_t)s.H, xr = line - f * (uint32_t)s.H;
+    cell = (xr * row_cells + in_row) * (uint32_t)s.B + f;
+  }
   const int lane = threadIdx.x & 63;
   const int slot = lane / lpr;
   const int cv = lane - slot * lpr;
@@ -173,7 +256,7 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_cells_vec_kernel(
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
   if (len > 0) {  // wave-uniform
-    if (slot < rpi) accumulate_rows<VecT, VEC, U, true>(acc, x, order + start, 0, len, slot, rpi, cv, lpr);
+    if (slot < rpi) accumulate_rows<VecT, VEC, U, true, TAILP>(acc, x, order + start, 0, len, slot, rpi, cv, lpr);
     fold_slots<VEC>(acc, lane, lpr, rpi);
   }
   if (slot == 0) {
@@ -581,7 +664,11 @@ static int prepare_tail(PrepBuffers& pb, int n, BevDims s, uint32_t ncells, uint
 }
 
 // variant: 0 = default (tuned), 1 = wave-per-cell U4, 2 = wave-per-cell U8,
-//          3 = coop NW4 U4, 4 = coop NW4 U8, 5 = coop NW8 U4, 6 = coop NW8 U2, 7 = coop NW4 U2
+//          3 = coop NW4 U4, 4 = coop NW4 U8, 5 = coop NW8 U4, 6 = coop NW8 U2, 7 = coop NW4 U2,
+//          14 / 15 = wave-per-cell U4 / U8 with the tail rows as one predicated batch (the defaults: bf16 / fp32),
+//          16 / 17 = XCD-striped walk, stripes of 2 groups, U4 / U8, batched tail;  18 / 19 = stripes of 1 group;
+//          + 100 * R on 16-19: the stripe -> XCD map moves on every R lines;  23 / 25 = 2 x 4 cell tiles, U8 / U4.
+//          (the striped and tiled walks cut the L2 -> fabric fetch counter by 3-7 % and are SLOWER: EXPERIMENTS C.7)
 template <typename VecT, int VEC>
 static int launch_cells_vec(const void* x, const uint32_t* order, const uint32_t* cell_start, uint32_t ncells,
                             float* out, int lpr, int rpi, BevDims s, int variant, hipStream_t stream) {
@@ -590,11 +677,36 @@ static int launch_cells_vec(const void* x, const uint32_t* order, const uint32_t
   bev_pool_fwd_cells_coop_kernel<VecT, VEC, U, NW>                                                         \
       <<<dim3(cdiv(ncells, NW)), dim3(NW * 64), (size_t)NW * NW * lpr * VEC * sizeof(float), stream>>>(    \
           xv, order, cell_start, ncells, out, lpr, rpi, s)
-  switch (variant) {
+  const uint32_t rot = (uint32_t)(variant / 100);   // striped walks: variant + 100 * R = the stripe map moves on every R lines
+  switch (variant % 100) {
     case 1: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 4><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
                 xv, order, cell_start, ncells, out, lpr, rpi, s); break;
     case 2: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 8><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
                 xv, order, cell_start, ncells, out, lpr, rpi, s); break;
+#define BEVAMD_STRIPED(U, SW, TP)                                                                                     \
+  {                                                                                                                   \
+    const uint32_t pb = cdiv(cdiv(cdiv((uint32_t)s.W * (uint32_t)s.D, 4u), SW), 8u) * 8u * SW;                       \
+    bev_pool_fwd_cells_vec_kernel<VecT, VEC, U, SW, TP>                                                               \
+        <<<dim3(pb * (uint32_t)s.H * (uint32_t)s.B), dim3(256), 0, stream>>>(xv, order, cell_start, ncells, out, lpr, rpi, s, pb, rot); \
+  }
+    case 14: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 4, 0, true><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
+                 xv, order, cell_start, ncells, out, lpr, rpi, s); break;
+    case 15: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 8, 0, true><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
+                 xv, order, cell_start, ncells, out, lpr, rpi, s); break;
+    case 16: BEVAMD_STRIPED(4, 2, true); break;
+    case 17: BEVAMD_STRIPED(8, 2, true); break;
+    case 18: BEVAMD_STRIPED(4, 1, true); break;
+    case 19: BEVAMD_STRIPED(8, 1, true); break;
+#define BEVAMD_TILED(U, TX)                                                                                           \
+  {                                                                                                                   \
+    const uint32_t rb = cdiv((uint32_t)s.W * (uint32_t)s.D, 4u), lp = cdiv((uint32_t)s.H, TX);                        \
+    bev_pool_fwd_cells_vec_kernel<VecT, VEC, U, 0, true, TX>                                                          \
+        <<<dim3(rb * lp * (uint32_t)s.B), dim3(256 * TX), 0, stream>>>(xv, order, cell_start, ncells, out, lpr, rpi, s); \
+  }
+    case 23: BEVAMD_TILED(8, 2); break;
+    case 25: BEVAMD_TILED(4, 2); break;
+#undef BEVAMD_TILED
+#undef BEVAMD_STRIPED
     case 3: BEVAMD_COOP(4, 4); break;
     case 4: BEVAMD_COOP(8, 4); break;
     case 5: BEVAMD_COOP(4, 8); break;
@@ -741,9 +853,10 @@ int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint
   const uint32_t ncells = (uint32_t)((unsigned long long)b * d * h * w);
   BevDims s{b, d, h, w, c};
   const int vec = x_is_bf16 ? 8 : 4;
-  // measured on MI355X (tools/sweep_bev_pool.py, profiles/): one wave per cell wins everywhere; 8 loads in
-  // flight pay off for fp32 rows on a single-frame grid (131 vs 150 us), 4 otherwise.
-  if (variant == 0) variant = (!x_is_bf16 && ncells <= 200000u) ? 2 : 1;
+  // measured on MI355X (tools/sweep_bev_pool.py, profiles/r05_bev_pool_variant_sweep.txt): one wave per cell in plain launch
+  // order with the tail rows as one batch of predicated loads wins everywhere — 8 loads per lane for fp32 rows (3 rows per
+  // wave instruction: 954 vs 999 us at 8 frames, 129 vs 131 at one), 4 for bf16 rows (6 rows per instruction: 565 vs 590 us).
+  if (variant == 0) variant = x_is_bf16 ? 14 : 15;
   if (vec_path_ok(c, vec, x, out)) {
     int lpr = c / vec, rpi = 64 / lpr;
     return x_is_bf16 ? launch_cells_vec<U4, 8>(x, order, cell_start, ncells, out, lpr, rpi, s, variant, stream)

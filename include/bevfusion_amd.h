@@ -193,8 +193,10 @@ int bevamd_bev_pool_fused_backward(const float* out_grad, const float* depth, co
                                    const uint32_t* cell_of_point, float* d_depth, float* d_ctx, int n, int c,
                                    int depth_bins, int fh, int fw, int b, int d, int h, int w, void* stream);
 
-/* Tuning hook of the same kernel family (bench sweeps only): variant 0 = shipped default,
- * 1/2 = one wave per cell (4/8 loads in flight), 3..7 = workgroup-cooperative flavours. */
+/* Tuning hook of the same kernel family (bench sweeps only): variant 0 = shipped default (15 for fp32 rows, 14 for bf16),
+ * 1/2 = one wave per cell (4/8 loads in flight), 3..7 = workgroup-cooperative flavours, 14/15 = 1/2 with the tail rows of a
+ * cell as one batch of predicated loads, 16..19 (+ 100 * R) = XCD-striped walks, 23/25 = 2 x 4 cell tiles
+ * (csrc/bev_pool.hip::launch_cells_vec; every one-wave-per-cell variant returns the same bits). */
 int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint32_t* order,
                                         const uint32_t* cell_start, float* out, int n, int c, int b,
                                         int d, int h, int w, int variant, void* stream);

@@ -144,6 +144,47 @@ def test_full_op_matches_oracle(dev, n, B, D, H, W, c, hot):
     assert torch.equal(view, out)
 
 
+# wave per cell (1, 2), cooperative (3-7), batched tails (14, 15 = the defaults), XCD-striped (16-19; + 100 * lines per step of
+# the rotating stripe map), 2 x 4 cell tiles (23, 25)
+FORWARD_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 14, 15, 16, 17, 18, 19, 23, 25, 118, 219, 316, 817)
+
+
+@pytest.mark.parametrize("n,B,D,H,W,c,hot", [
+    (20000, 1, 1, 40, 40, 80, 3000),      # rows of 10 groups of 4 cells: padded to 16 (SW 2) / 16 (SW 4) workgroups per line
+    (9000, 3, 1, 7, 13, 80, 600),         # 13 cells per grid row: the last group of a row is ragged, 3 frames
+    (9000, 2, 3, 5, 33, 64, None),        # W * D = 99 cells per row over z
+    (300, 1, 1, 3, 3, 12, None),          # fewer cells than one striped line
+    (6000, 8, 1, 6, 50, 256, 900),
+])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_every_forward_variant_matches_oracle_and_variant_1(dev, n, B, D, H, W, c, hot, bf16):
+    """The tuned walks (bevamd_bev_pool_forward_cells_tuned) only renumber workgroups / batch the tail loads: every cell's
+    rows are added in the same order, so all of them return the SAME BITS, and those are within the bar of float64."""
+    feats, coords = _case(n * 3 + c, n, B, D, H, W, c, hot)
+    lib = _capi.load()
+    x = torch.from_numpy(feats).to(dev)
+    if bf16:
+        x = x.bfloat16()
+    plan = BevPoolPlan.from_coords(torch.from_numpy(coords).to(dev), B, D, H, W)
+    ref = oracle.bev_pool(x.float().cpu().numpy(), coords, B, D, H, W).transpose(0, 2, 3, 4, 1)
+    first = None
+    for v in FORWARD_VARIANTS:
+        out = torch.full((B, D, H, W, c), float("nan"), dtype=torch.float32, device=dev)
+        rc = lib.bevamd_bev_pool_forward_cells_tuned(_capi.ptr(x), int(bf16), _capi.ptr(plan.order), _capi.ptr(plan.cell_start),
+                                                    _capi.ptr(out), plan.n, c, B, D, H, W, v, _capi.stream_ptr(dev))
+        _capi.check(rc, f"variant {v}")
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), f"variant {v} left cells unwritten"
+        assert np.max(np.abs(got - ref)) <= ABS_TOL, v
+        if v in (1, 2) or v >= 14:     # one wave per cell: one fixed order (the cooperative flavours split a cell over waves)
+            if first is None:
+                first = got
+            assert np.array_equal(got, first), f"variant {v} differs from variant 1"
+    rc = lib.bevamd_bev_pool_forward_cells_tuned(_capi.ptr(x), int(bf16), _capi.ptr(plan.order), _capi.ptr(plan.cell_start),
+                                                _capi.ptr(out), plan.n, c, B, D, H, W, 99, _capi.stream_ptr(dev))
+    assert rc != 0 or c % (8 if bf16 else 4) != 0      # (the any-width scalar kernel has no variants)
+
+
 def test_bf16_features(dev):
     n, B, D, H, W, c = 30000, 2, 1, 20, 20, 80
     feats, coords = _case(3, n, B, D, H, W, c, 2000)
