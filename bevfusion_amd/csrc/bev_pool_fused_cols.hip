@@ -36,7 +36,9 @@ struct ColDims {
 };
 
 constexpr int COL_WB = 4;            // image columns per tile: one float4 of depth along w, 4*C*4 contiguous context bytes per row
+static_assert(COL_WB == 4, "the depth tile, the keep / end mask quads and the item map are written for 4 columns");
 constexpr int COL_THREADS = 320;     // 16 items of 20 lanes at C = 80
+constexpr int CTX_BATCH = 4;         // context float4 per thread and staging batch (2 and 8 measured: EXPERIMENTS C.8)
 constexpr int COL_DEP_PITCH = COL_WB * 4 + 4;   // floats per (d-group, h) row of the depth tile: +4 keeps b128 writes conflict-free
 
 // ---- plan ---------------------------------------------------------------------------------------------------------------
@@ -157,16 +159,39 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
   const int w0 = wb * COL_WB, d0 = dh * s.DH;
   const int tid = threadIdx.x;
 
+  // Run metadata of the tile's DH x 4 image columns -> LDS (round 5).  The item loop used to fetch end mask and first run of its
+  // four columns from global memory at the top of every pass and the run's output slot when the run closed: two dependent round
+  // trips per pass with nothing else to issue.  Here one thread per column asks for mask + first run BEFORE the context rows go
+  // out, for the slot of the column's first run between context and depth staging (its address has arrived by then), and the
+  // item loop reads all three from LDS; only columns with several runs (pitched / rolled rigs) look further slots up.
+  const int n_cols = s.DH * COL_WB;
+  // [n_cols] end masks, [n_cols] slot of the first run, [DH] first run of the bin's column w0 (the other three follow from the
+  // popcounts of the masks before them: run_first is the exclusive scan of the run counts in column order) — 2 160 bytes at
+  // DH = 60: with the context and depth tiles 81 520, two workgroups per CU (a third array of n_cols words was one too many:
+  // 164 480 bytes for two, ONE workgroup per CU, measured 8 % slower than before the change instead of faster)
+  uint32_t* s_meta = (uint32_t*)(s_dep + (size_t)(s.DH >> 2) * fH * COL_DEP_PITCH);
+  uint32_t m_end[2], m_rf[2];   // n_cols <= 2 * COL_THREADS (DH <= 128); clamped addresses, no branches: nothing waits here
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + u * COL_THREADS;
+    const int d = d0 + i / COL_WB;
+    const size_t col = ((size_t)bn * s.D + (d < s.D ? d : s.D - 1)) * s.fW + w0 + (i & (COL_WB - 1));
+    m_end[u] = endm[col];
+    m_rf[u] = run_first[col];
+  }
+
   // Staging: every global load of a batch is issued before the first LDS write (indices clamped instead of branched around, so
-  // that hipcc keeps the loads of a batch in flight together: branches made it wait for each load in turn).
+  // that hipcc keeps the loads of a batch in flight together: branches made it wait for each load in turn).  Batches of 4
+  // context vectors / one depth pair (8 loads) per thread — issuing the WHOLE tile's 28 loads per thread up front (one exposed
+  // round trip instead of four) was measured 27-46 us per 8 frames SLOWER (round 5, EXPERIMENTS C.8).
   // context rows: fH rows of 4 * C contiguous floats
   {
     const int per_row = COL_WB * lpr;                        // float4 per row
     const int nvec = fH * per_row;
-    for (int i0 = 0; i0 < nvec; i0 += 4 * COL_THREADS) {
-      float4 v[4];
+    for (int i0 = 0; i0 < nvec; i0 += CTX_BATCH * COL_THREADS) {
+      float4 v[CTX_BATCH];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < CTX_BATCH; ++u) {
         int i = i0 + u * COL_THREADS + tid;
         i = i < nvec ? i : nvec - 1;
         const int h = i / per_row, j = i - h * per_row;
@@ -181,13 +206,20 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
       }
       // (opaque uses: without them hipcc sinks each load into the guarded store below and waits for them one by one)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+      for (int u = 0; u < CTX_BATCH; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < CTX_BATCH; ++u) {
         const int i = i0 + u * COL_THREADS + tid;
         if (i < nvec) ((float4*)s_ctx)[i] = v[u];
       }
     }
+  }
+  uint32_t m_slot[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + u * COL_THREADS;
+    if (!(i < n_cols && d0 + i / COL_WB < s.D)) m_end[u] = 0u;     // past the tile / past the last depth bin: no runs
+    m_slot[u] = slot_of_run[m_end[u] ? m_rf[u] : 0u];             // (run 0 exists: the kernel is not launched without runs)
   }
   // depth tile with the range mask folded in: thread -> (d-group of 4 bins, h); 4 float4 loads along w, 4 float4 stores along d
   {
@@ -222,6 +254,15 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
       }
     }
   }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + u * COL_THREADS;
+    if (i < n_cols) {
+      s_meta[i] = m_end[u];
+      s_meta[n_cols + i] = m_slot[u];
+      if ((i & (COL_WB - 1)) == 0) s_meta[2 * n_cols + i / COL_WB] = m_rf[u];
+    }
+  }
   __syncthreads();
 
   // items: (column wl, d-group dg) x lpr lanes; a lane owns 4 channels of the 4 depth bins of its item
@@ -231,19 +272,18 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
   const int n_items = COL_WB * (s.DH >> 2);
   for (int item = item0; item < n_items; item += items_per_pass) {
     const int wl = item & (COL_WB - 1), dg = item >> 2;
-    uint32_t en[4], rf[4], eany = 0;
+    uint32_t en[4], rf[4], sl[4], eany = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int d = d0 + dg * 4 + j;
-      en[j] = 0; rf[j] = 0;
-      if (d < s.D) {
-        const size_t col = ((size_t)bn * s.D + d) * s.fW + w0 + wl;
-        en[j] = endm[col];
-        rf[j] = run_first[col];
-      }
+      const int dl = dg * 4 + j;                      // (bins past D hold zeros)
+      const CU4 em = ((const CU4*)s_meta)[dl];        // the end masks of the bin's four columns
+      en[j] = wl == 0 ? em.x : wl == 1 ? em.y : wl == 2 ? em.z : em.w;
+      rf[j] = s_meta[2 * n_cols + dl] + (wl > 0 ? __popc(em.x) : 0) + (wl > 1 ? __popc(em.y) : 0) + (wl > 2 ? __popc(em.z) : 0);
+      sl[j] = s_meta[n_cols + dl * COL_WB + wl];
       eany |= en[j];
     }
     if (!eany) continue;
+    uint32_t later = 0;      // bit j: bin j has closed a run already
     float4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -271,13 +311,25 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
         const float4 dv = dp[(size_t)h * (COL_DEP_PITCH / 4)];
         fma4(acc[0], dv.x, c); fma4(acc[1], dv.y, c); fma4(acc[2], dv.z, c); fma4(acc[3], dv.w, c);
       }
+      // the bins that close a run at row e.  A column's first run has its slot in LDS; a later one (pitched / rolled rigs) is
+      // looked up here.  All lookups first, then all stores: a lookup in front of each store made every store wait for the one
+      // before it, and a lookup left pending around the loop makes hipcc wait for ALL memory traffic at the top of every trip.
+      uint32_t slot[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        slot[j] = sl[j];
+        if (((en[j] >> e) & 1u) && ((later >> j) & 1u)) slot[j] = slot_of_run[rf[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(slot[j]));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if ((en[j] >> e) & 1u) {
-          const uint32_t slot = slot_of_run[rf[j]];
+          later |= 1u << j;
           ++rf[j];
-          float4* dst = (slot & RUN_DIRECT) ? (float4*)out + (size_t)(slot & ~RUN_DIRECT) * lpr : (float4*)partial + (size_t)slot * lpr;
-          dst[cv] = acc[j];   // alone in its cell: straight into the output row
+          float4* dst = (slot[j] & RUN_DIRECT) ? (float4*)out + (size_t)(slot[j] & ~RUN_DIRECT) * lpr
+                                               : (float4*)partial + (size_t)slot[j] * lpr;
+          dst[cv] = acc[j];   // (alone in its cell: straight into the output row)
           acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -286,9 +338,10 @@ __global__ __launch_bounds__(COL_THREADS) void bev_fused_cols_kernel(
 }
 
 // ---- pass 2 ---------------------------------------------------------------------------------------------------------------
-// lpr lanes per cell, rpi cells per wave instruction, TWO cell groups per wave in flight (two thirds of the cells are empty and the
-// rest hold one or two rows: the kernel is a chain of short dependent loads — CSR bounds, rows, store — so each lane keeps two
-// independent chains going); a cell's partial rows are consecutive and are added in a fixed order
+// lpr lanes per cell, rpi cells per wave instruction, G cell groups per wave in flight (two thirds of the cells are empty and the
+// rest hold one or two rows: the kernel is a chain of short dependent loads — CSR bounds, rows, store — so each lane keeps G
+// independent chains going: 1 -> 2 groups 138 -> 111 us in round 4; 4 groups measured in round 5: 90.5 vs 88.5 us, no gain, so
+// G = 2); a cell's partial rows are consecutive and are added in a fixed order
 __device__ __forceinline__ float4 reduce_rows(const float4* __restrict__ p, int len, int lpr) {
   // four interleaved partial sums (row r goes to sum r % 4), folded at the end: a fixed order, and a quarter of the rounding
   // growth of one long chain on the rare cells with hundreds of rows
@@ -310,6 +363,7 @@ __device__ __forceinline__ float4 reduce_rows(const float4* __restrict__ p, int 
   return acc;
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __restrict__ partial,
                                                                const uint32_t* __restrict__ prow_start, uint32_t ncells,
                                                                float* __restrict__ out, int lpr, int rpi, int B, int D, int H, int W,
@@ -318,41 +372,51 @@ __global__ __launch_bounds__(256) void bev_fused_reduce_kernel(const float4* __r
   const int slot = lane / lpr, cv = lane - slot * lpr;
   if (slot >= rpi) return;
   const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-  // frame-major cells: b * (D*H*W) + (x * W + y) * D + z; this wave owns 2 * rpi consecutive cells
-  const uint32_t c0 = wave * (uint32_t)(2 * rpi) + (uint32_t)slot, c1 = c0 + (uint32_t)rpi;
-  const bool ok0 = c0 < ncells, ok1 = c1 < ncells;
-  if (!ok0) return;
-  const uint32_t s0 = prow_start[c0], e0 = prow_start[c0 + 1];
-  const uint32_t s1 = ok1 ? prow_start[c1] : 0u, e1 = ok1 ? prow_start[c1 + 1] : 0u;
-  const int len0 = (int)(e0 - s0), len1 = (int)(e1 - s1);
-  float4 acc0, acc1;
-  if (len0 <= 2 && len1 <= 2) {   // the common case: both cells' rows requested together
+  // frame-major cells: b * (D*H*W) + (x * W + y) * D + z; this wave owns G * rpi consecutive cells, G per lane group
+  uint32_t cell[G], st[G];
+  int len[G];
+  bool ok[G], small = true;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    cell[g] = wave * (uint32_t)(G * rpi) + (uint32_t)(g * rpi + slot);
+    ok[g] = cell[g] < ncells;
+    const uint32_t cc = ok[g] ? cell[g] : 0u;
+    st[g] = prow_start[cc];
+    len[g] = ok[g] ? (int)(prow_start[cc + 1] - st[g]) : 0;
+    small = small && len[g] <= 2;
+  }
+  if (!ok[0]) return;
+  float4 acc[G];
+  if (small) {   // the common case: every cell's rows requested together
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* p0 = partial + (size_t)s0 * lpr + cv;
-    const float4* p1 = partial + (size_t)s1 * lpr + cv;
-    // (a one-run cell's row went straight to `out` in pass 1: its slot of `partial` was never written and is not read)
-    const float4 a = len0 > (direct ? 1 : 0) ? p0[0] : z, b = len0 > 1 ? p0[lpr] : z;
-    const float4 c = len1 > (direct ? 1 : 0) ? p1[0] : z, d = len1 > 1 ? p1[lpr] : z;
+    float4 a[G], b[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4* p = partial + (size_t)st[g] * lpr + cv;
+      // (a one-run cell's row went straight to `out` in pass 1: its slot of `partial` was never written and is not read)
+      a[g] = len[g] > (direct ? 1 : 0) ? p[0] : z;
+      b[g] = len[g] > 1 ? p[lpr] : z;
+    }
     // same association as reduce_rows for <= 2 rows: (a + b) + (0 + 0)
-    acc0 = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    acc1 = make_float4(c.x + d.x, c.y + d.y, c.z + d.z, c.w + d.w);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = make_float4(a[g].x + b[g].x, a[g].y + b[g].y, a[g].z + b[g].z, a[g].w + b[g].w);
   } else {
-    acc0 = reduce_rows(partial + (size_t)s0 * lpr + cv, len0, lpr);
-    acc1 = reduce_rows(partial + (size_t)s1 * lpr + cv, len1, lpr);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = reduce_rows(partial + (size_t)st[g] * lpr + cv, len[g], lpr);
   }
   const uint32_t per_frame = ncells / (uint32_t)B;
-  auto store = [&](uint32_t cell, const float4& acc) {
-    const uint32_t b = cell / per_frame;
-    uint32_t local = cell - b * per_frame;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    // a cell with exactly one run was stored by pass 1 (RUN_DIRECT): nothing to do here (direct == 0: plans built without the marks)
+    if (!ok[g] || (direct && len[g] == 1)) continue;
+    const uint32_t b = cell[g] / per_frame;
+    uint32_t local = cell[g] - b * per_frame;
     const uint32_t gz = local % (uint32_t)D; local /= (uint32_t)D;
     const uint32_t gy = local % (uint32_t)W;
     const uint32_t gx = local / (uint32_t)W;
     // out[b, z, x, y, :] (bev_pool_cuda.cu:33-35)
-    *((float4*)(out + ((((size_t)b * D + gz) * H + gx) * W + gy) * (size_t)C) + cv) = acc;
-  };
-  // a cell with exactly one run was stored by pass 1 (RUN_DIRECT): nothing to do here (direct == 0: plans built without the marks)
-  if (!(direct && len0 == 1)) store(c0, acc0);
-  if (ok1 && !(direct && len1 == 1)) store(c1, acc1);
+    *((float4*)(out + ((((size_t)b * D + gz) * H + gx) * W + gy) * (size_t)C) + cv) = acc[g];
+  }
 }
 
 // ---- backward by columns ---------------------------------------------------------------------------------------------------
@@ -541,7 +605,7 @@ static int cols_shape(int c, int depth_bins, int fh, int fw, ColDims& s, size_t&
   s.DH = dpad < dh_max ? dpad : dh_max;
   s.ndh = (depth_bins + s.DH - 1) / s.DH;
   s.nwb = fw / COL_WB;
-  lds_bytes = ((size_t)fh * COL_WB * c + (size_t)(s.DH / 4) * fh * COL_DEP_PITCH) * sizeof(float);
+  lds_bytes = ((size_t)fh * COL_WB * c + (size_t)(s.DH / 4) * fh * COL_DEP_PITCH + (size_t)(2 * COL_WB + 1) * s.DH) * sizeof(float);
   return lds_bytes <= 150 * 1024;
 }
 
@@ -697,10 +761,33 @@ int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, i
   }
   const int lpr = c / 4, rpi = 64 / lpr > 0 ? 64 / lpr : 0;
   BEVAMD_REQUIRE(rpi > 0, "bev_pool_fused_forward_columns: c=%d needs more than 64 lanes per row", c);
-  bev_fused_reduce_kernel<<<dim3(cdiv(cdiv(ncells, 2 * rpi), 4)), dim3(256), 0, stream>>>((const float4*)partial, prow_start, ncells, out,
-                                                                                     lpr, rpi, b, d, h, w, c, ncells < RUN_DIRECT ? 1 : 0);
+  bev_fused_reduce_kernel<2><<<dim3(cdiv(cdiv(ncells, 2 * rpi), 4)), dim3(256), 0, stream>>>((const float4*)partial, prow_start, ncells, out,
+                                                                                        lpr, rpi, b, d, h, w, c, ncells < RUN_DIRECT ? 1 : 0);
   BEVAMD_LAUNCH_CHECK("bev_fused_reduce");
   return BEVAMD_OK;
+}
+
+/* Introspection (tests, tuning): workgroups of pass 1 that fit one compute unit at this shape, from the runtime's occupancy
+ * calculator, or MINUS an error code — the tile of the flagship shape (81 520 bytes of LDS) is sized for TWO. */
+int bevamd_bev_pool_fused_columns_occupancy(int c, int depth_bins, int fh, int fw) {
+  ColDims s;
+  size_t lds_bytes = 0;
+  if (!cols_shape(c, depth_bins, fh, fw, s, lds_bytes)) {
+    set_error("bev_pool_fused_columns_occupancy: unsupported shape c=%d fh=%d fw=%d", c, fh, fw);
+    return -BEVAMD_ERR_UNSUPPORTED;
+  }
+  const void* k = (const void*)&bev_fused_cols_kernel<false>;
+  if (lds_bytes > 65536) {
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+  }
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, COL_THREADS, lds_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("bev_pool_fused_columns_occupancy: the occupancy query failed");
+    return -BEVAMD_ERR_HIP;
+  }
+  return n;
 }
 
 /* Backward of the fused pooling for fp32 context through the column masks (keep / end of bevamd_bev_pool_fused_columns_count):

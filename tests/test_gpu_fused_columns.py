@@ -192,6 +192,15 @@ def test_unsupported_shapes_fall_back_or_raise(dev):
     assert torch.allclose(out[0, 0, 0, 0], (depth.view(2, 3, 10, 1) * ctx.view(2, 1, 10, 8)).sum((0, 1, 2)), atol=1e-4)
 
 
+def test_flagship_tile_keeps_two_workgroups_per_compute_unit(dev):
+    """Pass 1's tile (context rows + depth tile + run metadata of 4 image columns x 60 depth bins) is sized so that TWO workgroups
+    share a compute unit's 160 KB of LDS; a third metadata array once pushed it to one (round 5) — the runtime's occupancy
+    calculator is the witness."""
+    lib = _capi.load()
+    assert lib.bevamd_bev_pool_fused_columns_occupancy(80, 118, 32, 88) >= 2
+    assert lib.bevamd_bev_pool_fused_columns_occupancy(80, 118, 33, 88) < 0       # unsupported shape: an error code
+
+
 def test_column_path_replays_from_a_graph(dev):
     B, n_cam, D, fh, fw, c = 1, 2, 24, 32, 44, 80
     cfg = synth.CL_CONFIG
