@@ -12,12 +12,23 @@
 //   * a block whose range exceeds CAP rows in some plane (rare: measured never on LiDAR frames) reads its operands straight
 //     from global memory with the same addressing — slower, same result.
 // Works for the strided 3x3x3 convolution as well: only the metadata differs (spconv_indice.hip: sp_slab_from_sorted_kernel).
+//
+// What bounds it (round 5, compile-time ablation with -DBEVAMD_SMALL_ABL, EXPERIMENTS C.10): the LDS PIPE.  16 -> 16 at 8 frames
+// (1.28 M rows): 53 us; without the reduction 21, without the MFMAs but with every operand read 52.  An operand fragment is read
+// for ONE 16-channel output tile (the wide layers reuse it for 4-8), so a layer moves rows x 27 x 32 B = 1.15 GB through
+// 128 B/clk/CU.  Neither a bank swizzle, nor all slots up front + operands two chunks ahead, nor slot entries baked into LDS rows
+// (one shift-add per fragment instead of six instructions), nor a software pipeline over the blocks moved the time.
 #pragma once
 #include <type_traits>
 #include "spconv_slab.h"
 
+#ifndef BEVAMD_SMALL_ABL
+#define BEVAMD_SMALL_ABL 0   // profiling builds only (wrong results by design): 1 no row DMA, 2 no slot DMA, 4 no reduction,
+#endif                       // 8 no epilogue, 16 no MFMA (operands still read), 32 no header load
+
 namespace bevamd {
 namespace slab {
+constexpr int SMALL_ABL = BEVAMD_SMALL_ABL;
 
 // NW waves form an (NW / CW) x CW grid: wave (r, c) owns 16*MT rows x (NT / CW) 16-channel output tiles (the 16->32 layer
 // splits its two output tiles over two waves: 56 filter registers per wave instead of 112, 4 waves per SIMD instead of 1).
@@ -95,7 +106,8 @@ __global__ __launch_bounds__(NW * 64) void spconv_slabs_kernel(SlabArgs sa) {
 
   for (; blk < bend; blk += gx) {
     __syncthreads();   // every wave is done with the previous block's rows and slots
-    const int2 hl = sa.hdr[(size_t)blk * PLANES + (lane < PLANES ? lane : 0)];
+    int2 hl = make_int2(blk * P::BM > 300 ? blk * P::BM - 300 : 0, 300);
+    if constexpr (!(SMALL_ABL & 32)) hl = sa.hdr[(size_t)blk * PLANES + (lane < PLANES ? lane : 0)];
     int lo[PLANES], cnt[PLANES];
 #pragma unroll
     for (int j = 0; j < PLANES; ++j) {
@@ -105,9 +117,10 @@ __global__ __launch_bounds__(NW * 64) void spconv_slabs_kernel(SlabArgs sa) {
     const bool big = cnt[0] > CAP || cnt[1] > CAP || cnt[2] > CAP;   // workgroup-uniform
     // slot table of the block -> LDS, by DMA as well (whole KiB pieces: the last one may run into the epilogue scratch, which
     // nobody uses before the stores at the end of the block; past the end of the buffer the descriptor returns zeros)
+    if constexpr (!(SMALL_ABL & 2))
     for (int i = w; i < P::SLOT_KIB; i += NW)
       dma16(rs_s, (unsigned)lane * 16u, (unsigned)blk * (unsigned)(27 * P::BM * 2) + (unsigned)i * 1024u, (char*)slot + i * 1024);
-    if (!big) {
+    if (!big && !(SMALL_ABL & 1)) {
 #pragma unroll
       for (int j = 0; j < PLANES; ++j) {
         const int np = (cnt[j] + P::RPI - 1) / P::RPI;
@@ -165,13 +178,19 @@ __global__ __launch_bounds__(NW * 64) void spconv_slabs_kernel(SlabArgs sa) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wt.acc[mt][nt] = mfma<DT>(wf[ch][nt], xa[ch & 1][mt], wt.acc[mt][nt]);
+          for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (SMALL_ABL & 16) asm volatile("" ::"v"(xa[ch & 1][mt]), "v"(wf[ch][nt]));
+            else wt.acc[mt][nt] = mfma<DT>(wf[ch][nt], xa[ch & 1][mt], wt.acc[mt][nt]);
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (big) reduce(std::true_type{});
-    else reduce(std::false_type{});
-    wt.store(aw);
+    if constexpr (!(SMALL_ABL & 4)) {
+      if (big) reduce(std::true_type{});
+      else reduce(std::false_type{});
+    }
+    if constexpr (!(SMALL_ABL & 8)) wt.store(aw);
+    else if (blk < 0) wt.store(aw);   // (keeps the accumulators alive)
   }
 }
 

@@ -26,6 +26,15 @@ def main():
     ind = vc.int().contiguous()
     stages = [(16, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (32, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 0))]
     tag = os.path.basename(os.environ.get("BEVAMD_LIB", "shipped"))
+    if 16 in want:   # level 1: the narrow-row kernels (variant 0 | 3000256 | 3000128)
+        rb = sops.build_rulebook(ind, frames, shape, 3, 1, 1, 1, True)
+        f = torch.randn(ind.shape[0], 16, device=dev).half()
+        w = (torch.randn(27, 16, 16, device=dev) / (27 * 16) ** 0.5).half()
+        img = sops.make_filter_image(w.view(27, 1, 1, 16, 16))
+        for v in want[16]:
+            meta = sops.slab_build(rb.nbr, rb.num_out, None, sops.slab_block_rows(16, v))
+            t = min(timeit(lambda: sops.sparse_conv_slab(f, img, meta, rb.num_out, 16, 16, variant=v))[0] for _ in range(3))
+            print(f"{tag:24s}  16->16  rows={rb.num_out:8d} variant {v}: {t:7.1f} us", flush=True)
     for cin, cout, ks, st, pd in stages:
         rbs = sops.build_rulebook(ind, frames, shape, list(ks), list(st), list(pd), 1, False)
         ind, shape = rbs.out_indices.contiguous(), rbs.out_spatial_shape
