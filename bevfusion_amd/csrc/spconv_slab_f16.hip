@@ -33,7 +33,11 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
   if (cin >= 1 && cin <= 16) {
     if (max_n > 0) codes[0] = slab::SMALL_BASE + 256;
     if (max_n > 1) codes[1] = slab::SMALL_BASE + 128;
-    return 2;
+    if (cin <= 8) return 2;
+    // 16 -> 32 only: both output tiles in one wave
+    if (max_n > 2) codes[2] = slab::SMALL_BASE + slab::SMALL_WHOLE + 256;
+    if (max_n > 3) codes[3] = slab::SMALL_BASE + slab::SMALL_WHOLE + 128;
+    return 4;
   }
   int n = 0, nr = 0;
   const slab::Shape* s = slab::shapes_of(cin, &n);

@@ -45,10 +45,14 @@ static inline long long persistent_cap(int wg_per_xcd) {
   return c < 1 ? 1 : c;
 }
 constexpr int SMALL_BASE = 3000000;   // variant codes of the narrow-row kernels: SMALL_BASE + rows per block
+constexpr int SMALL_WHOLE = 100000;   // + SMALL_WHOLE: 16 -> 32 with BOTH output tiles in one wave (each operand fragment read from
+                                      // LDS once instead of once per tile: the kernels are LDS-bound, EXPERIMENTS C.10)
 static inline int small_block_rows(int cinp, int variant) {
   if (cinp != 8 && cinp != 16) return 0;
   if (variant == 0 || variant == SMALL_BASE + 256) return 256;
   if (variant == SMALL_BASE + 128) return 128;
+  if (cinp == 16 && variant == SMALL_BASE + SMALL_WHOLE + 256) return 256;
+  if (cinp == 16 && variant == SMALL_BASE + SMALL_WHOLE + 128) return 128;
   return 0;
 }
 // resident workgroups per XCD of a persistent kernel on the current device (0 on error)
@@ -252,6 +256,10 @@ static int run_s(const SlabArgs& sa, hipStream_t stream) {
 template <int DT>
 int launch_s_impl(const SlabArgs& sa, int cinp, int nt, int variant, hipStream_t stream) {
   const int bm = small_block_rows(cinp, variant);
+  if (variant >= SMALL_BASE + SMALL_WHOLE && cinp == 16 && nt == 2) {
+    if (bm == 256) return run_s<DT, 16, 2, 4, 4, 1, 384>(sa, stream);
+    if (bm == 128) return run_s<DT, 16, 2, 2, 4, 1, 256>(sa, stream);
+  }
   if (bm == 256) {
     if (cinp == 8 && nt == 1) return run_s<DT, 8, 1, 4, 4, 1, 384>(sa, stream);
     if (cinp == 16 && nt == 1) return run_s<DT, 16, 1, 4, 4, 1, 384>(sa, stream);

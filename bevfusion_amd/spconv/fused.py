@@ -478,11 +478,12 @@ _BATCHED_VARIANTS = {(32, 32): 2213, (32, 64): 2211, (64, 64): 2221, (64, 128): 
 # frame: 26.7 / 30.8 us against 41 / 35.8 us, 128 channels 38.5-40 against 38.8 us (188 blocks on 256 CUs) -> those layers switch
 # over from 4 frames per step.  The persistent 32-channel kernel was only measured at 8 frames: smaller batches keep its one-block twin.
 # Narrow layers (cin padded to 8 | 16: csrc/spconv_slab_small.h) on a level in linear order — level 1 when the voxelizer wrote
-# its rows in key order: 3000256 = 256-row blocks (the SubM layers share one metadata set), 3000128 = 128-row blocks (the strided
-# 16 -> 32 convolution: its two output tiles go to two waves, 8-wave workgroups, so smaller blocks keep two of them per CU).
+# its rows in key order: 3000256 = 256-row blocks (the SubM layers share one metadata set); the strided 16 -> 32 convolution:
+# 3100128 = 128-row blocks, BOTH output tiles in one wave (round 5: these kernels are bound by the LDS pipe, and with the two tiles
+# on two waves — 3000128, 8-wave workgroups — every operand fragment was read from LDS twice: LiDAR branch alone 3.54 -> 3.45 ms).
 _CHECK = os.environ.get("BEVAMD_SPCONV_CHECK", "0") == "1"   # read the geometry status words back after every fused forward (one sync)
 _SLAB_NARROW_SUBM = 3000256
-_SLAB_NARROW_STRIDED = 3000128
+_SLAB_NARROW_STRIDED = 3100128
 _SORTED = os.environ.get("BEVAMD_SPCONV_SORTED", "1") != "0"          # sorted-key neighbour search on levels without a rank index
 _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and on those that have one (tuning)
 # 32 channels from 4 frames: the filter-stationary kernel (spconv_slab_fstat.h; 64-row blocks, baked slots): 159 us isolated against 190

@@ -1,7 +1,7 @@
 """Direct oracle parity of exactly what the driver's bench times ("next round" item 3).
 
   (i)   >= 4 frames per step — the regime in which `fused._slab_variant_for` picks the filter-stationary 32-channel kernel (4000112)
-        and the 128-channel slab kernel (1644220; 64 channels: 1644228, baked slot metadata), with level 1 in key order (narrow slab kernels 3000256 / 3000128): per level,
+        and the 128-channel slab kernel (1644220; 64 channels: 1644228, baked slot metadata), with level 1 in key order (narrow slab kernels 3000256 / 3100128): per level,
         the fp16 output of the first SubM layer and of the strided convolution leaving the level, each against
         `oracle.indice_conv` (float64) on the GPU's own stage input, <= 6e-4 * (1 + max|ref|) (2 x the observed error, profiles/r05_parity_observed.json);
   (ii)  the bench's exact shape — 8 full 10-sweep clouds at the 160 k cap (1.28 M level-1 rows): the fused key-ordered path
@@ -77,7 +77,7 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
         ws = torch.from_numpy((rng.standard_normal(tuple(ks) + (cw, cout)) / np.sqrt(cw * K / 4)).astype(np.float32)).to(dev).half()
         sconv = type("C", (), dict(subm=False, kernel_size=ks))()
         svar = fused._slab_variant_for(sconv, lvl, cw, cout)
-        assert (svar is not None) == (stage == 0) and (svar is None or svar == 3000128)
+        assert (svar is not None) == (stage == 0) and (svar is None or svar == 3100128)
         nxt, nbr = lvl.downsample(list(ks), list(st), list(pd), want_nbr=svar is None)
         m = int(nxt.n_dev.item())
         assert m == oi.shape[0] and np.array_equal(nxt.indices[:m].cpu().numpy(), oi)

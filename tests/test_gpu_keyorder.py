@@ -243,7 +243,7 @@ def test_narrow_subm_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, cin, cout
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("variant", [3000256, 3000128])
+@pytest.mark.parametrize("variant", [3000256, 3000128, 3100256, 3100128])   # 31xxxxx: both output tiles in one wave
 @pytest.mark.parametrize("batch,shape,n,pad", [(2, [24, 20, 9], 2500, (1, 1, 1)), (1, [16, 24, 41], 15000, (1, 1, 1)),
                                                 (1, [40, 40, 21], 9000, (1, 1, 0))])
 def test_narrow_strided_slab_is_the_gather_kernel_bit_for_bit(dev, dtype, variant, batch, shape, n, pad):
@@ -349,7 +349,7 @@ def test_encoder_key_ordered_path_is_bit_identical_to_first_appearance_path(dev,
     assert tuple(got.shape) == (B, 256, 180, 180)
     # level 1 ran on the narrow slab kernels: input layer, four 16 -> 16 layers, the strided 16 -> 32
     assert kinds[0][:4] == (5, 16, True, "slab") and all(k[3] == "slab" for k in kinds[1:5]) and kinds[5][:4] == (16, 32, False, "slab")
-    assert kinds[5][4] == 3000128 and kinds[1][4] == 3000256
+    assert kinds[5][4] == 3100128 and kinds[1][4] == 3000256
     assert torch.equal(again, ref), "un-profiled key-order pass"
     assert torch.equal(prepared, ref), "key-order pass over a prepared geometry"
     assert torch.equal(got, ref), "profiled key-order pass"

@@ -27,7 +27,8 @@ head -12 gpurun_out/r05_pmc_infer_per_kernel.txt | cut -c1-160
 python tools/spconv_layers_profile.py gpurun_out/prof_r05 gpurun_out/pmcb_infer gpurun_out/r05_bench_full.json gpurun_out/r05_spconv_layers.json > gpurun_out/r05_spconv_layers.txt 2>&1
 head -30 gpurun_out/r05_spconv_layers.txt | cut -c1-200
 python tools/update_bev_pool_traffic.py gpurun_out/pmcb_infer.json 5 > gpurun_out/r05_bev_pool_traffic.log 2>&1; cp profiles/bev_pool_traffic.json gpurun_out/r05_bev_pool_traffic.json; tail -4 gpurun_out/r05_bev_pool_traffic.log
-# training step: lines + kernel trace of the --amp step
+# training step: lines + kernel trace of the --amp step (SKIP_TRAIN=1: the training path did not change since the last visit)
+if [ -n "$SKIP_TRAIN" ]; then find gpurun_out -name "*.db" -delete; find gpurun_out/pmcb_infer -name "*.csv" -size +4M -delete; exit 0; fi
 for mode in "--amp" ""; do
   timeout 400 python bench.py --mode train-step --no-cpu-baseline $mode > gpurun_out/r05_train${mode}.log 2>&1
   grep "^{" gpurun_out/r05_train${mode}.log | tail -1 > gpurun_out/r05_bench_line_train_step${mode}.json
