@@ -4,8 +4,11 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+# health check first (round 5: a box whose GPU faulted in every process ate a whole visit): smoke() must pass, else stop at once
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05_health.log 2>&1 || { echo "== health check failed: stop"; tail -5 gpurun_out/r05_health.log; exit 3; }
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r05_tests.log 2>&1
-echo "== tests rc=$?"; grep -E "^E |FAILED|passed|failed" gpurun_out/r05_tests.log | tail -4 | cut -c1-300
+rc=$?; echo "== tests rc=$rc"; grep -E "^E |FAILED|passed|failed" gpurun_out/r05_tests.log | tail -4 | cut -c1-300
+if [ $rc -ge 124 ]; then echo "== the test run died (rc $rc): stop"; exit 3; fi
 timeout 900 python bench.py > gpurun_out/r05_bench.log 2>gpurun_out/r05_bench.err; cp gpurun_out/bench_last_full.json gpurun_out/r05_bench_full.json
 echo "== bench rc=$?"; grep "^{" gpurun_out/r05_bench.log | tail -1 > gpurun_out/r05_bench_line.json; cut -c1-300 gpurun_out/r05_bench_line.json
 # kernel-trace stats + timeline of the default step
