@@ -31,6 +31,7 @@ _SIGNATURES = {
     "bevamd_bev_pool_prepare_from_geom": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_forward_cells": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_forward_cells_tuned": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "bevamd_bev_pool_striped_line": (I, [I, I, I, I, P, I]),
     "bevamd_bev_pool_fused_forward": (I, [P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_fused_schedule_workspace_bytes": (Z, [I]),
     "bevamd_bev_pool_fused_schedule": (I, [P, P, I, I, I, I, I, I, I, I, P, P, P, Z, P]),

@@ -193,9 +193,10 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_intervals_scalar_kernel(
 // on XCD t % 8: the cells on either side of a run end — the same stripe one grid row on, or the neighbouring group of the
 // stripe — then meet in ONE L2.  A row's groups rarely divide by 8 * SW (360 cells = 90 groups): the stripes left over after
 // the last full round of 8 are dealt from a start that rotates with the line, so that every XCD gets the same number of
-// groups over 8 lines (dealt from XCD 0 every time, two XCDs would carry 12 groups a row against 11: measured +6 % time).
+// stripes over 8 lines (dealt from XCD 0 every time, two XCDs would carry 12 groups a row against 11).  The map is host-callable:
+// tests/test_bev_pool_striped_map.py checks it without a GPU (every group once, the XCD of a stripe, the balance, the rotation).
 template <int SW>
-__device__ __forceinline__ bool striped_group(uint32_t p, uint32_t line, uint32_t rb, uint32_t shift, uint32_t& j) {
+__host__ __device__ __forceinline__ bool striped_group(uint32_t p, uint32_t line, uint32_t rb, uint32_t shift, uint32_t& j) {
   constexpr uint32_t G = 8u * SW;
   const uint32_t stripes = (rb + SW - 1) / SW, full = stripes & ~7u, extra = stripes - full;
   const uint32_t c = p / G, q = p - c * G, m = q >> 3;               // chunk of 8 stripes, member of the stripe
@@ -869,6 +870,30 @@ int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint
     bev_pool_fwd_cells_scalar_kernel<false><<<grid, block, 0, stream>>>(x, order, cell_start, ncells, out, s);
   BEVAMD_LAUNCH_CHECK("bev_pool_fwd_cells_scalar");
   return BEVAMD_OK;
+}
+
+/* host-only (tests): the XCD-striped walk's map of one padded line of workgroups — groups[p] = the 4-cell group workgroup p of
+ * line `line` takes, or -1 for a padding slot; stripe_groups in {1, 2, 4}, rot_lines = lines per step of the rotating stripe map
+ * (0: fixed).  Returns the padded line length (a multiple of 8: workgroup p runs on XCD p % 8), negative on bad arguments. */
+int bevamd_bev_pool_striped_line(int row_groups, int stripe_groups, int line, int rot_lines, int* groups, int max_n) {
+  if (!(row_groups > 0 && line >= 0 && rot_lines >= 0 && (stripe_groups == 1 || stripe_groups == 2 || stripe_groups == 4))) {
+    set_error("bev_pool_striped_line: bad arguments");
+    return -BEVAMD_ERR_INVALID_ARG;
+  }
+  const uint32_t rb = (uint32_t)row_groups, sw = (uint32_t)stripe_groups;
+  const uint32_t pb = (uint32_t)cdiv(cdiv(rb, sw), 8) * 8u * sw;
+  if (!groups || max_n < 0 || (uint32_t)max_n < pb) {
+    set_error("bev_pool_striped_line: need room for %u entries", pb);
+    return -BEVAMD_ERR_INVALID_ARG;
+  }
+  const uint32_t shift = rot_lines ? (uint32_t)line / (uint32_t)rot_lines : 0u;
+  for (uint32_t p = 0; p < pb; ++p) {
+    uint32_t j = 0;
+    const bool live = sw == 1 ? striped_group<1>(p, (uint32_t)line, rb, shift, j)
+                    : sw == 2 ? striped_group<2>(p, (uint32_t)line, rb, shift, j) : striped_group<4>(p, (uint32_t)line, rb, shift, j);
+    groups[p] = live ? (int)j : -1;
+  }
+  return (int)pb;
 }
 
 int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* order, const uint32_t* cell_start,

@@ -1,0 +1,77 @@
+"""Host logic of the XCD-striped bev_pool walk (csrc/bev_pool.hip::striped_group, variants 16-19 of
+bevamd_bev_pool_forward_cells_tuned): the map from a padded line of workgroups to the 4-cell groups of a grid row, through
+the host-only hook bevamd_bev_pool_striped_line.  No GPU needed.
+
+What the kernel relies on: every group of the row is taken by exactly one workgroup of the line (else cells stay unwritten
+or are written twice), workgroup p runs on XCD p % 8 (lines are padded to a multiple of 8), the stripes of a line's full
+rounds sit on the same XCD in every line (that is the sharing), the leftover stripes are dealt from a rotating start (so no
+XCD carries more groups than another over 8 lines), and the optional rotation moves the whole map on by one XCD."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from bevfusion_amd import _capi
+
+
+def line(lib, rb, sw, ln, rot=0):
+    buf = (ctypes.c_int * 4096)()
+    n = lib.bevamd_bev_pool_striped_line(rb, sw, ln, rot, buf, 4096)
+    assert n > 0 and n % (8 * sw) == 0
+    return np.array(buf[:n])
+
+
+@pytest.mark.parametrize("sw", [1, 2, 4])
+@pytest.mark.parametrize("rb", list(range(1, 41)) + [90, 91, 96, 97, 128, 250])
+def test_every_group_once_and_the_xcds_carry_the_same_load(sw, rb):
+    lib = _capi.load()
+    stripes, groups = np.zeros(8, np.int64), np.zeros(8, np.int64)
+    for ln in range(16):
+        g = line(lib, rb, sw, ln)
+        live = g[g >= 0]
+        assert sorted(live.tolist()) == list(range(rb)), (sw, rb, ln)
+        assert len(g) < rb + 8 * sw                                 # less than one round of padding
+        p = np.nonzero(g >= 0)[0]
+        np.add.at(groups, p % 8, 1)
+        np.add.at(stripes, p[p % (8 * sw) < 8] % 8, 1)              # the first member of every stripe
+    assert stripes.max() == stripes.min(), stripes                  # over 8 (here 16) lines every XCD gets the same number of stripes
+    assert groups.max() - groups.min() <= 16 * (sw - 1), groups     # ... and of groups, up to the row's one partial stripe per line
+
+
+def test_full_rounds_stay_on_their_xcd_and_stripes_stay_together():
+    lib = _capi.load()
+    rb = 90                                                         # the flagship row: 360 cells
+    for sw in (1, 2, 4):
+        stripes = -(-rb // sw)
+        full = stripes // 8 * 8
+        first = line(lib, rb, sw, 0)
+        xcd_of = {int(j): p % 8 for p, j in enumerate(first) if j >= 0}
+        for j in range(full * sw):
+            assert xcd_of[j] == (j // sw) % 8                       # stripe t of a full round -> XCD t % 8
+        for ln in range(1, 9):
+            g = line(lib, rb, sw, ln)
+            for p, j in enumerate(g):
+                if 0 <= j < full * sw:
+                    assert p % 8 == xcd_of[int(j)], (sw, ln, j)     # the same XCD in every line: neighbouring rows share an L2
+                if j >= 0 and j % sw and j - 1 >= 0:
+                    assert (int(np.nonzero(g == j - 1)[0][0]) % 8) == p % 8   # the groups of a stripe share the XCD
+
+
+def test_rotation_moves_the_map_on_by_one_xcd_per_step():
+    lib = _capi.load()
+    rb, sw = 96, 1                                                  # no leftover stripes: the pure rotation
+    base = line(lib, rb, sw, 0, rot=2)
+    for ln in range(0, 12):
+        g = line(lib, rb, sw, ln, rot=2)
+        step = ln // 2
+        for p, j in enumerate(g):
+            assert int(np.nonzero(base == j)[0][0]) % 8 == (p - step) % 8
+
+
+def test_bad_arguments_are_refused():
+    lib = _capi.load()
+    buf = (ctypes.c_int * 8)()
+    assert lib.bevamd_bev_pool_striped_line(90, 3, 0, 0, buf, 8) < 0       # stripes of 1, 2 or 4 groups
+    assert lib.bevamd_bev_pool_striped_line(0, 1, 0, 0, buf, 8) < 0
+    assert lib.bevamd_bev_pool_striped_line(90, 1, 0, 0, buf, 8) < 0       # 96 entries do not fit 8
+    assert lib.bevamd_bev_pool_striped_line(90, 1, 0, 0, None, 0) < 0

@@ -113,6 +113,12 @@ def test_host_side_tables_of_the_slab_kernels():
         assert lib.bevamd_spconv_slab_block_rows(cin, 0) == lib.bevamd_spconv_slab_block_rows(cin, got[0])
         assert lib.bevamd_spconv_slab_block_rows(cin, 1999999) == 0            # not built
     assert lib.bevamd_spconv_slab_block_rows(48, 0) == 0
+    # the narrow-row kernels (cin <= 16): 256- | 128-row blocks; 31xxxxx = the 16 -> 32 layer with both output tiles in one wave
+    for cin in (5, 8, 16):
+        assert [lib.bevamd_spconv_slab_block_rows(cin, v) for v in (0, 3000256, 3000128, 3000064)] == [256, 256, 128, 0]
+        assert [lib.bevamd_spconv_slab_block_rows(cin, v) for v in (3100256, 3100128)] == ([256, 128] if cin > 8 else [0, 0])
+        n = lib.bevamd_spconv_slab_variants(cin, codes, 64)
+        assert [codes[i] for i in range(n)] == [3000256, 3000128] + ([3100256, 3100128] if cin > 8 else [])
     shape = (ctypes.c_int * 3)(720, 720, 21)
     assert lib.bevamd_spconv_slab_grid_ok(shape, 256) == 1                     # 256 + 722 * 21 + 2 rows fit 16-bit slots
     wide = (ctypes.c_int * 3)(720, 4000, 21)
