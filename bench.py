@@ -65,7 +65,7 @@ def parse():
                          "runs first with only the voxelizer beside it (second HIP stream), the rulebook chain "
                          "(SparseEncoder.prepare_geometry) starts when bev_pool has finished and runs beside the depth raster and the "
                          "fused pooling, the convolutions follow after the join and run alone (measured at the end of round 3: 5.51-5.52 against 5.55 ms — "
-                         "even the voxelizer alone costs bev_pool 24 %, 1.27 against 1.03 ms; not a gain); voxel: only the voxelizer (22 "
+                         "even the voxelizer alone costs bev_pool 24 %%, 1.27 against 1.03 ms; not a gain); voxel: only the voxelizer (22 "
                          "short dependent launches, 0.3 ms) runs on a second HIP stream beside the depth raster / fused pooling stages — it is "
                          "done long before bev_pool starts, whose roofline figure stays clean — and the encoder follows after the join (round 3: 5.34-5.38 "
                          "against 5.42-5.47 ms: the raster and the fused pooling pay 0.17 ms for the 0.3 ms hidden; round 4, with the column "

@@ -167,3 +167,9 @@ def test_dry_run_lines_stay_below_the_hard_limit():
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1 and len(lines[0]) < 8192, [len(ln) for ln in lines]
         assert CONTRACT_KEYS <= set(json.loads(lines[0]))
+
+
+def test_help_renders():
+    """argparse %-formats every help string: a bare per-cent sign in one of them breaks --help (round 5)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--overlap" in r.stdout, r.stderr[-500:]
