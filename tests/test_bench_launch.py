@@ -11,8 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_bench(*flags):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env,
-                       timeout=300, cwd=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *flags]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    if r.returncode != 0 and "ChildFailedError" in r.stderr and "Signal 6" in r.stderr:
+        # a rank aborted inside the gloo rendezvous / teardown (seen once in ~50 eight-rank launches on a busy 8-core container,
+        # never reproduced in isolation): one more try — a deterministic failure fails again
+        print("bench.py launch retried after:", r.stderr[-600:], file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
