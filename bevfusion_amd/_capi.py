@@ -39,6 +39,7 @@ _SIGNATURES = {
     "bevamd_bev_pool_fused_columns_supported": (I, [I, I, I, I]),
     "bevamd_bev_pool_fused_backward_columns_supported": (I, [I, I, I, I]),
     "bevamd_bev_pool_fused_columns_occupancy": (I, [I, I, I, I]),
+    "bevamd_bev_pool_fused_columns_lds_bytes": (Z, [I, I, I, I]),
     "bevamd_bev_pool_fused_columns_workspace_bytes": (Z, [I, I]),
     "bevamd_bev_pool_fused_columns_count": (I, [P, I, I, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_fused_columns_build": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, Z, P]),

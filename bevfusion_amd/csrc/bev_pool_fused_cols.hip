@@ -767,6 +767,14 @@ int bevamd_bev_pool_fused_forward_columns(const float* depth, const void* ctx, i
   return BEVAMD_OK;
 }
 
+/* host-only: dynamic LDS bytes of one pass-1 workgroup at this shape (context rows + depth tile + run metadata of 4 image columns
+ * x DH depth bins), 0 if the shape is not served.  Two workgroups must fit a compute unit's 160 KiB: <= 81 920 at the flagship. */
+size_t bevamd_bev_pool_fused_columns_lds_bytes(int c, int depth_bins, int fh, int fw) {
+  ColDims s;
+  size_t lds_bytes = 0;
+  return cols_shape(c, depth_bins, fh, fw, s, lds_bytes) ? lds_bytes : 0;
+}
+
 /* Introspection (tests, tuning): workgroups of pass 1 that fit one compute unit at this shape, from the runtime's occupancy
  * calculator, or MINUS an error code — the tile of the flagship shape (81 520 bytes of LDS) is sized for TWO. */
 int bevamd_bev_pool_fused_columns_occupancy(int c, int depth_bins, int fh, int fw) {

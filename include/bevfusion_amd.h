@@ -167,6 +167,8 @@ int bevamd_bev_pool_fused_backward_columns_supported(int c, int depth_bins, int 
 /* Introspection: workgroups of the column forward's pass 1 per compute unit at this shape (runtime occupancy calculator; needs a
  * device), or minus a BEVAMD_ERR_* code.  The flagship tile is sized for two. */
 int bevamd_bev_pool_fused_columns_occupancy(int c, int depth_bins, int fh, int fw);
+/* host-only: dynamic LDS bytes of one workgroup of that pass at this shape (0: shape not served) */
+size_t bevamd_bev_pool_fused_columns_lds_bytes(int c, int depth_bins, int fh, int fw);
 size_t bevamd_bev_pool_fused_columns_workspace_bytes(int ncols, int nruns);
 int bevamd_bev_pool_fused_columns_count(const uint32_t* cell_of_point, int n, int depth_bins, int fh, int fw, int b, int d, int h,
                                         int w, uint32_t* keep, uint32_t* end, uint32_t* run_first, uint32_t* total_runs,

@@ -151,3 +151,17 @@ def test_batch_entry_points_validate_their_host_arrays():
     ptrs = (ctypes.c_void_p * 1)(None)
     rc = lib.bevamd_voxelize_mean_batch(ptrs, one, 1, 2, vs, cr, 10, 100, 1, None, None, None, None, None, None, 0, None)
     assert rc != 0 and "num_features" in _capi.last_error()
+
+
+def test_column_pooling_tile_leaves_room_for_two_workgroups_per_compute_unit():
+    """Pass 1 of the fused column pooling sizes its dynamic LDS from the shape (context rows of 4 image columns + a depth tile of DH
+    bins + the run metadata of the tile).  Two workgroups share a compute unit's 160 KiB only if one takes at most 80 KiB: a third
+    metadata array once added 720 bytes too many and halved the occupancy (round 5, EXPERIMENTS C.8) — this is the guard that
+    needs no GPU (tests/test_gpu_fused_columns.py asks the runtime's occupancy calculator)."""
+    lib = _capi.load()
+    fh, c, dh = 32, 80, 60                                            # the flagship tile: 118 depth bins in two tiles of 60
+    want = (fh * 4 * c + (dh // 4) * fh * 20 + 9 * dh) * 4            # context + depth (pitch 20 floats) + 2 words per column + 1 per bin
+    got = lib.bevamd_bev_pool_fused_columns_lds_bytes(c, 118, fh, 88)
+    assert got == want == 81520 and 2 * got <= 160 * 1024
+    assert lib.bevamd_bev_pool_fused_columns_lds_bytes(c, 118, 33, 88) == 0      # unsupported: more rows than mask bits
+    assert lib.bevamd_bev_pool_fused_columns_lds_bytes(c, 8, 4, 8) == (4 * 4 * c + 2 * 4 * 20 + 9 * 8) * 4   # a tile shorter than DH
