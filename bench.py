@@ -278,7 +278,7 @@ def compact_line(res, side_file=None):
     rf = res.get("roofline")
     if rf:
         out["roofline"] = {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                  "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_in_step", "frac_in_step", "measured") if k in rf}
+                                                  "algorithmic_bytes_per_launch", "kernel_ms", "rocprof_kernel_us", "kernel_ms_in_step", "frac_in_step", "measured") if k in rf}
     else:
         out["roofline"] = None
     cb = res.get("cpu_baseline")
@@ -318,6 +318,9 @@ def compact_line(res, side_file=None):
     rs = res.get("roofline_spconv")
     if rs:
         out["roofline_spconv"] = {k: rs.get(k) for k in ("total_us", "total_gflop", "tflops", "frac_mfma_peak", "n_layers") if k in rs}
+    bx = res.get("box")
+    if bx:
+        out["box"] = {k: bx[k] for k in ("gpu_unique_id", "pci", "sclk", "mclk") if k in bx}
     if side_file:
         out["full_result"] = side_file
     out = _r(out)
@@ -345,6 +348,49 @@ def emit(res):
             except OSError:
                 pass
     print(compact_line(res, side), flush=True)
+
+
+def box_info(dev_index=0):
+    """Which box and which clocks a line was measured on (0.885 / 0.954 / 1.009 ms for one kernel on three
+    boxes could not be attributed): hostname, device name, the DPM levels sysfs marks current for the shader and memory clocks
+    (read right after the timed region, i.e. under load) and the device's compute-unit count.  Best effort: never raises."""
+    import glob
+    import socket
+
+    info = {"hostname": socket.gethostname()}
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        info.update(device=p.name, gcn_arch=getattr(p, "gcnArchName", None), compute_units=p.multi_processor_count,
+                    hbm_gb=round(p.total_memory / 2 ** 30, 1))
+    except Exception:
+        pass
+    # the sysfs node of THIS device (a node shows all its GPUs' cards; only one is visible to the process): by PCI address
+    node = None
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        if os.path.isdir(f"/sys/bus/pci/devices/{bdf}"):
+            node = f"/sys/bus/pci/devices/{bdf}"
+            info["pci"] = bdf
+    except Exception:
+        pass
+    nodes = [node] if node else [os.path.dirname(c) for c in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))]
+    for key, fname in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk")):
+        cur = []
+        for c in nodes:
+            try:
+                with open(os.path.join(c, fname)) as fh:
+                    cur += [ln.split(":")[1].strip().rstrip("*").strip() for ln in fh if ln.rstrip().endswith("*")]
+            except OSError:
+                pass
+        if cur:
+            info[key] = cur if len(set(cur)) > 1 else cur[0]
+    if node:
+        try:
+            info["gpu_unique_id"] = open(os.path.join(node, "unique_id")).read().strip()
+        except OSError:
+            pass
+    return info
 
 
 class quiet_gc:
@@ -1199,6 +1245,7 @@ def main():
     kern_ms = stage_ms[2]  # the bev_pool stage is exactly one kernel launch
     fused_ms = stage_ms[1]
 
+    box_sampled = box_info(dev.index or 0) if rank == 0 else None   # clocks right behind the timed region
     elapsed_local = elapsed
     elapsed = max_over_ranks(elapsed, device=dev)  # slowest rank defines the step time
     frames_per_step = int(sum_over_ranks(B, device=dev))
@@ -1452,6 +1499,14 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_frame") * B
             except Exception:
                 traffic = None
+        rocprof_us = rocprof_src = None
+        rpath = os.path.join(ROOT, "profiles", "roofline_rocprof.json")
+        if os.path.exists(rpath):
+            try:
+                rj = json.load(open(rpath))
+                rocprof_us, rocprof_src = rj.get("solo_avg_us"), f"profiles/roofline_rocprof.json (round {rj.get('round')}, stored: {rj.get('source')})"
+            except Exception:
+                pass
         res = {
             "metric": "frames/sec of the BEVFusion C+L hot path (6x256x704 cameras -> 360x360/180x180 BEV, ~310k LiDAR "
                       "points); bev_pool HBM GB/s in roofline",
@@ -1536,6 +1591,8 @@ def main():
                                   "passes of tools/pmc_bev_pool.sh, per frame x frames per launch) — not measured inside this run",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": roof_ms,
+                "rocprof_kernel_us": rocprof_us,
+                "rocprof_source": rocprof_src,
                 "kernel_ms_in_step": kern_ms,
                 "frac_in_step": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "measured": ("solo: HIP events around 20 back-to-back launches right after the timed region (inside the step the LiDAR "
@@ -1543,6 +1600,7 @@ def main():
                             "in the step: HIP events around the one launch of every timed step, nothing beside it",
             },
         }
+        res["box"] = box_sampled
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(inp, pts_np, cfg, B, D, H, W)
         else:

@@ -74,6 +74,18 @@ def main():
         print(f"{r[0][:78]:78s} {r[1]:6d} {r[2]:10.2f} {r[3]:10.2f} {r[4]:10.2f} {r[5]:10.3f} {100 * r[5] / tot:6.2f}")
     if dbs:
         sp = solo_split(dbs[0])
+        # round 6: the roofline kernel's kernel-trace figures as a small JSON that bench.py quotes in its line
+        # (roofline.rocprof_kernel_us) — python tools/rocprof_summary.py <dir> --roofline-json <out.json> <round>
+        if "--roofline-json" in sys.argv and sp:
+            import json
+
+            i = sys.argv.index("--roofline-json")
+            names = [r[0] for r in rows if "bev_pool_fwd_cells_vec_kernel" in r[0]]
+            json.dump({"kernel": names[0] if names else None, "round": int(sys.argv[i + 2]) if len(sys.argv) > i + 2 else None,
+                       "source": "rocprofv3 --kernel-trace --stats of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras` "
+                                 "(tools/gpu_round_artefacts.sh), split by tools/rocprof_summary.py::solo_split",
+                       "solo_launches": sp[0], "solo_avg_us": sp[1], "in_step_launches": sp[2], "in_step_avg_us": sp[3]},
+                      open(sys.argv[i + 1], "w"), indent=1)
         if sp and sp[0] and sp[2]:
             print(f"\n# bev_pool_fwd_cells_vec_kernel by setting: SOLO launches (nothing else on the GPU; what roofline.kernel_ms reports) "
                   f"n={sp[0]} avg {sp[1]:.2f} us; launches inside the step (LiDAR branch beside them; roofline.kernel_ms_in_step) "
