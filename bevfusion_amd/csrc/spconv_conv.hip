@@ -697,6 +697,8 @@ static int launch_fwd(const void* feat, const void* wt, const int* nbr, int nbr_
 
 }  // namespace bevamd
 
+#include "spconv_wgrad_slab.h"
+
 using namespace bevamd;
 
 extern "C" {
@@ -921,6 +923,67 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
   else if (dtype == DT_F16) spconv_wgrad_reduce_kernel<DT_F16><<<rgrid, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, cinp, coutp, (_Float16*)filter_grad);
   else spconv_wgrad_reduce_kernel<DT_BF16><<<rgrid, block, 0, stream>>>(part, nslabs, kernel_volume, cin, cout, cinp, coutp, (uint16_t*)filter_grad);
   BEVAMD_LAUNCH_CHECK("spconv_wgrad_reduce");
+  return BEVAMD_OK;
+}
+
+/* The filter gradient of a 3x3x3 SUBMANIFOLD convolution over rows in ascending linear index, from slab metadata (hdr / slots of
+ * bevamd_spconv_slab_build* with block_rows = 128, raw slots) instead of the neighbour table: the neighbour rows of a block are
+ * staged in LDS once and gathered by the transposing LDS reads (csrc/spconv_wgrad_slab.h).  Replaces the filter half of
+ * sparse_conv_ext.indice_conv_backward_half (spconv_ops.h:363-456).  16-bit features, cin == cout in {16, 32, 64, 128}; feature and
+ * out_grad pitches in elements (multiples of 8, rows 16-byte aligned).  Deterministic (fixed-order slab partials). */
+int bevamd_spconv_wgrad_slab_supported(int dtype, int cin, int cout) {
+  wgslab::Shape s;
+  return (dtype == DT_F16 || dtype == DT_BF16) && wgslab::shape_for(cin, cout, s) ? 1 : 0;
+}
+
+size_t bevamd_spconv_wgrad_slab_workspace_bytes(int cin, int cout) {
+  wgslab::Shape s;
+  if (!wgslab::shape_for(cin, cout, s)) return 0;
+  return align_up((size_t)wgslab::slabs_for(1 << 30, s) * 27 * cin * cout * sizeof(float), 256);
+}
+
+int bevamd_spconv_conv_wgrad_slab(const void* features, int feat_stride, int num_in, const void* out_grad, int og_stride,
+                                  int dtype, const void* hdr, const void* slots, int block_rows, int num_out, int cin, int cout,
+                                  void* filter_grad, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  wgslab::Shape sh;
+  BEVAMD_REQUIRE(dtype == DT_F16 || dtype == DT_BF16, "spconv_conv_wgrad_slab: dtype %d is not 16-bit", dtype);
+  BEVAMD_REQUIRE(wgslab::shape_for(cin, cout, sh), "spconv_conv_wgrad_slab: %d -> %d channels (cin == cout in 16 | 32 | 64 | 128)", cin, cout);
+  BEVAMD_REQUIRE(block_rows == wgslab::BM, "spconv_conv_wgrad_slab: metadata of %d-row blocks (raw slots of %d-row blocks wanted)", block_rows, wgslab::BM);
+  BEVAMD_REQUIRE(num_out >= 0 && num_in >= 0 && filter_grad, "spconv_conv_wgrad_slab: bad sizes / null filter_grad");
+  const size_t nw = (size_t)27 * cin * cout;
+  if (num_out == 0) {
+    BEVAMD_HIP_CHECK(hipMemsetAsync(filter_grad, 0, nw * 2, stream));
+    return BEVAMD_OK;
+  }
+  BEVAMD_REQUIRE(features && out_grad && hdr && slots, "spconv_conv_wgrad_slab: null buffer");
+  BEVAMD_REQUIRE(feat_stride >= cin && feat_stride % 8 == 0 && og_stride >= cout && og_stride % 8 == 0 &&
+                     (((uintptr_t)features | (uintptr_t)out_grad | (uintptr_t)slots) & 15) == 0,
+                 "spconv_conv_wgrad_slab: pitches %d / %d must be multiples of 8 covering the channels, buffers 16-byte aligned", feat_stride, og_stride);
+  BEVAMD_REQUIRE((unsigned long long)num_in * feat_stride * 2ull < 0x100000000ull && (unsigned long long)num_out * og_stride * 2ull < 0x100000000ull,
+                 "spconv_conv_wgrad_slab: tensors must be smaller than 4 GiB (buffer descriptors)");
+  if (!ws || ws_bytes < bevamd_spconv_wgrad_slab_workspace_bytes(cin, cout)) {
+    set_error("spconv_conv_wgrad_slab: workspace too small");
+    return BEVAMD_ERR_WORKSPACE;
+  }
+  wgslab::Args a;
+  a.feat = features; a.gout = out_grad; a.hdr = (const int2*)hdr; a.slots = (const uint16_t*)slots; a.part = (float*)ws;
+  a.feat_stride = feat_stride; a.gout_stride = og_stride; a.n_in = num_in; a.m = num_out;
+  a.nblk = (num_out + wgslab::BM - 1) / wgslab::BM;
+  int nslabs = wgslab::slabs_for(a.nblk, sh);
+  a.blocks_per_slab = (a.nblk + nslabs - 1) / nslabs;
+  a.nslabs = (a.nblk + a.blocks_per_slab - 1) / a.blocks_per_slab;
+  a.ncb = sh.nci * sh.nco; a.nco = sh.nco;
+  a.cinp_tot = cin; a.coutp_tot = cout;
+  const unsigned long long sb = (unsigned long long)a.nblk * wgslab::SLOT_BYTES;
+  BEVAMD_REQUIRE(sb < 0x100000000ull, "spconv_conv_wgrad_slab: slot table of 4 GiB or more");
+  a.slot_bytes = (unsigned)sb;
+  const int rc = dtype == DT_F16 ? wgslab::launch<true>(a, sh, stream) : wgslab::launch<false>(a, sh, stream);
+  if (rc != BEVAMD_OK) return rc;
+  const int n = (int)nw;   // 27 * cin * cout: a multiple of 64
+  if (dtype == DT_F16) wgslab::wgrad_slab_reduce_kernel<true><<<dim3((n / 4 + 15) / 16), dim3(256), 0, stream>>>(a.part, a.nslabs, n, (uint16_t*)filter_grad);
+  else wgslab::wgrad_slab_reduce_kernel<false><<<dim3((n / 4 + 15) / 16), dim3(256), 0, stream>>>(a.part, a.nslabs, n, (uint16_t*)filter_grad);
+  BEVAMD_LAUNCH_CHECK("wgrad_slab_reduce");
   return BEVAMD_OK;
 }
 

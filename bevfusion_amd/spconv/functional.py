@@ -37,7 +37,7 @@ class RulebookConvFunction(Function):
     def backward(ctx, grad_output):
         features, filters = ctx.saved_tensors
         nbr, nbr_t = ctx.rulebook.conv_tables()
-        in_grad, f_grad = ops.sparse_conv_backward(features, filters, grad_output, nbr, nbr_t, features.shape[0])
+        in_grad, f_grad = ops.sparse_conv_backward(features, filters, grad_output, nbr, nbr_t, features.shape[0], rulebook=ctx.rulebook)
         return in_grad, f_grad.to(filters.dtype), None
 
 

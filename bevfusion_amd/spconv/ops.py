@@ -81,6 +81,27 @@ class Rulebook:
         self._nbr_t = None
         self._pairs = None
         self._conv_tables = None
+        self._slab128 = None
+
+    def slab_meta128(self):
+        """Slab metadata (128-row blocks, raw 16-bit slots: csrc/spconv_slab_meta.h) of a symmetric 3x3x3 SubM rulebook whose rows
+        turn out to be in (near-)linear order — what the staged-rows filter gradient reads — or None.  Built from the neighbour
+        table on first use and shared by the convolutions of a level (they share the rulebook through `indice_key`).  Whether the
+        rows are ordered is MEASURED, not promised: the mean staged range of a block must stay below 4 blocks (a level in linear
+        order stages little more than its 128 rows per plane; first-appearance order stages thousands) and no range may overflow the 16-bit slots
+        — one small reduction and one host read-back per level."""
+        if self._slab128 is None:
+            meta = False
+            if (self.subm and self.symmetric and self.kernel_volume == 27 and self.num_out >= 128 and self.num_in == self.num_out
+                    and os.environ.get("BEVAMD_SPCONV_WGRAD_SLAB", "1") != "0"):
+                m = slab_build(self.nbr, self.num_out, None, 128)
+                nblk = (self.num_out + 127) // 128
+                cnt = m.hdr[:nblk * 24].view(torch.int32).view(nblk, 3, 2)[:, :, 1] & 0x3FFFFFFF
+                staged, flag = (int(v) for v in torch.stack((cnt.sum(dtype=torch.int64), m.status[0].to(torch.int64))).tolist())
+                if flag == 0 and staged <= 4 * 128 * 3 * nblk:
+                    meta = m
+            self._slab128 = meta
+        return self._slab128 or None
 
     @property
     def nbr_stride(self):
@@ -556,8 +577,25 @@ def sparse_conv(features, filters, nbr, num_out, bias=None, bn_scale=None, bn_sh
     return out
 
 
-def sparse_conv_backward(features, filters, out_grad, rulebook_nbr, nbr_t, num_in):
-    """(in_grad [num_in, Cin], filter_grad like filters) for out = sparse_conv(features, filters, nbr)."""
+def sparse_conv_wgrad_slab(features, out_grad, meta, cin, cout):
+    """filter_grad [27, cin, cout] of a 3x3x3 SubM convolution from slab metadata (bevamd_spconv_conv_wgrad_slab)."""
+    lib = _capi.load()
+    dev = features.device
+    fgrad = torch.empty((27, cin, cout), dtype=features.dtype, device=dev)
+    with torch.cuda.device(dev):
+        wsb = lib.bevamd_spconv_wgrad_slab_workspace_bytes(cin, cout)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        rc = lib.bevamd_spconv_conv_wgrad_slab(_capi.ptr(features), features.stride(0), features.shape[0], _capi.ptr(out_grad),
+                                               out_grad.stride(0), _dtype_code(features), _capi.ptr(meta.hdr), _capi.ptr(meta.slots),
+                                               int(meta.block_rows), out_grad.shape[0], int(cin), int(cout), _capi.ptr(fgrad),
+                                               _capi.ptr(ws), wsb, _capi.stream_ptr(dev))
+    _capi.check(rc, "spconv_conv_wgrad_slab")
+    return fgrad
+
+
+def sparse_conv_backward(features, filters, out_grad, rulebook_nbr, nbr_t, num_in, rulebook=None):
+    """(in_grad [num_in, Cin], filter_grad like filters) for out = sparse_conv(features, filters, nbr).  With the `rulebook`
+    the tables came from, a SubM layer over ordered rows takes the staged-rows filter gradient."""
     lib = _capi.load()
     features = features.contiguous()
     out_grad = out_grad.contiguous().to(features.dtype)
@@ -568,6 +606,12 @@ def sparse_conv_backward(features, filters, out_grad, rulebook_nbr, nbr_t, num_i
     # input gradient: the same fused kernel on (out_grad, W^T, input-stationary table)
     in_grad = sparse_conv(out_grad, filters, nbr_t, num_in, transpose_io=True)
     # filter gradient
+    if (rulebook is not None and features.dtype in (torch.float16, torch.bfloat16)
+            and lib.bevamd_spconv_wgrad_slab_supported(_dtype_code(features), cin, cout)
+            and features.stride(0) % 8 == 0 and out_grad.stride(0) % 8 == 0):
+        meta = rulebook.slab_meta128()
+        if meta is not None:
+            return in_grad, sparse_conv_wgrad_slab(features, out_grad, meta, cin, cout).view(filters.shape)
     fgrad = torch.empty_like(filters.contiguous())
     dt = _dtype_code(features)
     with torch.cuda.device(features.device):

@@ -595,6 +595,17 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
                              int nbr_stride, int num_out, int kernel_volume, int cin, int cout,
                              void* filter_grad, void* ws, size_t ws_bytes, void* stream);
 
+/* The same filter gradient (spconv_ops.h:363-456, the filter half of indice_conv_backward_half) for a 3x3x3 SUBMANIFOLD
+ * convolution over rows in ascending linear index, with the rulebook given as slab metadata (hdr / slots of
+ * bevamd_spconv_slab_build* with block_rows = 128: raw 16-bit slots) instead of the neighbour table: the neighbour rows of a block
+ * of output rows are contiguous ranges, staged in LDS once and gathered by the transposing LDS reads (csrc/spconv_wgrad_slab.h).
+ * 16-bit features; cin == cout in {16, 32, 64, 128}; pitches in elements, multiples of 8.  Deterministic. */
+int bevamd_spconv_wgrad_slab_supported(int dtype, int cin, int cout);
+size_t bevamd_spconv_wgrad_slab_workspace_bytes(int cin, int cout);
+int bevamd_spconv_conv_wgrad_slab(const void* features, int feat_stride, int num_in, const void* out_grad, int og_stride,
+                                  int dtype, const void* hdr, const void* slots, int block_rows, int num_out, int cin,
+                                  int cout, void* filter_grad, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * device primitives (exposed for tests; used by every precompute path)
  * ------------------------------------------------------------------------- */
