@@ -117,7 +117,9 @@ _SIGNATURES = {
     "bevamd_spconv_conv_forward_slab": (I, [P, I, I, I, P, P, P, I, I, P, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_wgrad_workspace_bytes": (Z, [I, I, I]),
     "bevamd_spconv_conv_wgrad": (I, [P, P, I, P, I, I, I, I, I, P, P, Z, P]),
+    "bevamd_spconv_wgrad_slab_set_profile_buffer": (None, [P]),
     "bevamd_spconv_wgrad_slab_supported": (I, [I, I, I]),
+    "bevamd_spconv_wgrad_slab_block_rows": (I, [I]),
     "bevamd_spconv_wgrad_slab_workspace_bytes": (Z, [I, I]),
     "bevamd_spconv_conv_wgrad_slab": (I, [P, I, I, P, I, I, P, P, I, I, I, I, P, P, Z, P]),
     # iou3d

@@ -931,9 +931,19 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
  * staged in LDS once and gathered by the transposing LDS reads (csrc/spconv_wgrad_slab.h).  Replaces the filter half of
  * sparse_conv_ext.indice_conv_backward_half (spconv_ops.h:363-456).  16-bit features, cin == cout in {16, 32, 64, 128}; feature and
  * out_grad pitches in elements (multiples of 8, rows 16-byte aligned).  Deterministic (fixed-order slab partials). */
+static unsigned long long* g_wgs_prof = nullptr;
+void bevamd_spconv_wgrad_slab_set_profile_buffer(void* buf) { g_wgs_prof = (unsigned long long*)buf; }  /* -DBEVAMD_WGS_PROF builds */
+
 int bevamd_spconv_wgrad_slab_supported(int dtype, int cin, int cout) {
   wgslab::Shape s;
   return (dtype == DT_F16 || dtype == DT_BF16) && wgslab::shape_for(cin, cout, s) ? 1 : 0;
+}
+
+/* the block_rows code (rows | slot format << 16) of the metadata the filter gradient of a cin -> cin layer reads; 0 = unsupported */
+int bevamd_spconv_wgrad_slab_block_rows(int cin) {
+  wgslab::Shape s;
+  if (!wgslab::shape_for(cin, cin, s)) return 0;
+  return wgslab::BM | ((s.cit == 2 ? slab::FMT_WG64 : slab::FMT_WG32) << slab::FMT_SHIFT);
 }
 
 size_t bevamd_spconv_wgrad_slab_workspace_bytes(int cin, int cout) {
@@ -949,7 +959,9 @@ int bevamd_spconv_conv_wgrad_slab(const void* features, int feat_stride, int num
   wgslab::Shape sh;
   BEVAMD_REQUIRE(dtype == DT_F16 || dtype == DT_BF16, "spconv_conv_wgrad_slab: dtype %d is not 16-bit", dtype);
   BEVAMD_REQUIRE(wgslab::shape_for(cin, cout, sh), "spconv_conv_wgrad_slab: %d -> %d channels (cin == cout in 16 | 32 | 64 | 128)", cin, cout);
-  BEVAMD_REQUIRE(block_rows == wgslab::BM, "spconv_conv_wgrad_slab: metadata of %d-row blocks (raw slots of %d-row blocks wanted)", block_rows, wgslab::BM);
+  BEVAMD_REQUIRE(block_rows == bevamd_spconv_wgrad_slab_block_rows(cin),
+                 "spconv_conv_wgrad_slab: metadata code %d, %d channels want %d (bevamd_spconv_wgrad_slab_block_rows)", block_rows, cin,
+                 bevamd_spconv_wgrad_slab_block_rows(cin));
   BEVAMD_REQUIRE(num_out >= 0 && num_in >= 0 && filter_grad, "spconv_conv_wgrad_slab: bad sizes / null filter_grad");
   const size_t nw = (size_t)27 * cin * cout;
   if (num_out == 0) {
@@ -978,6 +990,7 @@ int bevamd_spconv_conv_wgrad_slab(const void* features, int feat_stride, int num
   const unsigned long long sb = (unsigned long long)a.nblk * wgslab::SLOT_BYTES;
   BEVAMD_REQUIRE(sb < 0x100000000ull, "spconv_conv_wgrad_slab: slot table of 4 GiB or more");
   a.slot_bytes = (unsigned)sb;
+  a.prof = g_wgs_prof;
   const int rc = dtype == DT_F16 ? wgslab::launch<true>(a, sh, stream) : wgslab::launch<false>(a, sh, stream);
   if (rc != BEVAMD_OK) return rc;
   const int n = (int)nw;   // 27 * cin * cout: a multiple of 64

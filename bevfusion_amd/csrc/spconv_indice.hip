@@ -1420,7 +1420,7 @@ int bevamd_spconv_slab_build_from_index(const int* indices, int m_cap, const int
   const int fmt = slab::fmt_of_code(block_rows);   // upper half: slot format (spconv_slab_meta.h), 0 = raw / implied by 64-row blocks
   block_rows = slab::rows_of_code(block_rows);
   BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_index: block_rows %d (64 | 128 | 256)", block_rows);
-  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128, "spconv_slab_build_from_index: slot format %d", fmt);
+  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128 || (slab::fmt_is_wg(fmt) && block_rows == 128), "spconv_slab_build_from_index: slot format %d (the filter-gradient formats need 128-row blocks)", fmt);
   BEVAMD_REQUIRE(index_kind == INDEX_HASH || index_kind == INDEX_RANK, "spconv_slab_build_from_index: index_kind %d", index_kind);
   BEVAMD_REQUIRE(m_cap >= 0, "spconv_slab_build_from_index: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
@@ -1485,7 +1485,7 @@ int bevamd_spconv_slab_build_from_sorted(const int* out_indices, int m_cap, cons
   const int fmt = slab::fmt_of_code(block_rows);   // upper half: slot format (spconv_slab_meta.h), 0 = raw / implied by 64-row blocks
   block_rows = slab::rows_of_code(block_rows);
   BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build_from_sorted: block_rows %d (64 | 128 | 256)", block_rows);
-  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128, "spconv_slab_build_from_sorted: slot format %d", fmt);
+  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128 || (slab::fmt_is_wg(fmt) && block_rows == 128), "spconv_slab_build_from_sorted: slot format %d (the filter-gradient formats need 128-row blocks)", fmt);
   BEVAMD_REQUIRE(m_cap >= 0 && in_n_cap >= 0, "spconv_slab_build_from_sorted: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(out_indices && in_index && hdr && slots, "spconv_slab_build_from_sorted: null buffer");

@@ -85,7 +85,7 @@ int bevamd_spconv_slab_build(const int* nbr, int nbr_stride, int m_cap, const in
   const int fmt = slab::fmt_of_code(block_rows);   // upper half: slot format (spconv_slab_meta.h)
   block_rows = slab::rows_of_code(block_rows);
   BEVAMD_REQUIRE(block_rows == 64 || block_rows == 128 || block_rows == 256, "spconv_slab_build: block_rows %d (64 | 128 | 256)", block_rows);
-  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128, "spconv_slab_build: slot format %d", fmt);
+  BEVAMD_REQUIRE(fmt == 0 || fmt == slab::FMT_BAKED128 || (slab::fmt_is_wg(fmt) && block_rows == 128), "spconv_slab_build: slot format %d (the filter-gradient formats need 128-row blocks)", fmt);
   BEVAMD_REQUIRE(m_cap >= 0 && nbr_stride >= m_cap, "spconv_slab_build: bad sizes");
   if (m_cap == 0) return BEVAMD_OK;
   BEVAMD_REQUIRE(nbr && hdr && slots, "spconv_slab_build: null buffer");

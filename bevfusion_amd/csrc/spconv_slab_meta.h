@@ -34,6 +34,28 @@ __host__ __device__ __forceinline__ int rows_of_code(int code) { return code & 0
 __host__ __device__ __forceinline__ int fmt_of_code(int code) { return (code >> FMT_SHIFT) & 0xFF; }
 __host__ __device__ __forceinline__ unsigned baked128_entry(unsigned r) { return r * 128u | ((r & 7u) << 4); }
 
+// Round 6: the formats of the staged-rows FILTER GRADIENT (spconv_wgrad_slab.h; 128-row blocks only).  The reduction index of that
+// GEMM is the row, and a lane of its transposing LDS reads wants the staged rows of neighbours {32 q + 8 g + cc + 4 h} (q < 4, h < 2)
+// of an offset: the table of a block is stored TRANSPOSED — entry (offset k, row r) at ((k*4 + g)*4 + cc)*8 + q*2 + h with
+// r = 32 q + 8 g + 4 h + cc — so that those eight entries are one 16-byte read, and an entry is the LDS byte offset of the staged
+// row inside a stage of the kernel: plane * WG_CAP * row bytes + slot * row bytes (+ the half swap of 64-byte rows: bit 3 of the
+// slot -> bit 5), or WG_ZERO (the zero row behind the three planes) for a missing neighbour.  FMT_WG64: 64-byte staged rows
+// (32 input channels per workgroup: 32 channels and wider), 192 rows per plane; FMT_WG32: 32-byte rows (16 channels), 256 rows per
+// plane.  A plane whose range is longer keeps RAW slots — in the same transposed positions — and says so in its header (HDR_RAW):
+// the kernel converts those itself, piece by piece.
+constexpr int FMT_WG64 = 2, FMT_WG32 = 3;
+__host__ __device__ constexpr bool fmt_is_wg(int fmt) { return fmt == FMT_WG64 || fmt == FMT_WG32; }
+__host__ __device__ constexpr int wg_row_bytes(int fmt) { return fmt == FMT_WG64 ? 64 : 32; }
+__host__ __device__ constexpr int wg_cap(int fmt) { return fmt == FMT_WG64 ? 192 : 256; }
+__host__ __device__ constexpr unsigned wg_zero(int fmt) { return 3u * (unsigned)wg_cap(fmt) * (unsigned)wg_row_bytes(fmt); }
+__host__ __device__ __forceinline__ unsigned wg_entry(int fmt, int plane, unsigned slot) {
+  const unsigned rb = (unsigned)wg_row_bytes(fmt);
+  return (unsigned)plane * (unsigned)wg_cap(fmt) * rb + slot * rb + (fmt == FMT_WG64 ? ((slot >> 3) & 1u) << 5 : 0u);
+}
+__host__ __device__ __forceinline__ int wg_index(int k, int r) {   // position of (offset k, row r) inside a block's table
+  return ((k * 4 + ((r >> 3) & 3)) * 4 + (r & 3)) * 8 + (r >> 5) * 2 + ((r >> 2) & 1);
+}
+
 // One workgroup of BM threads per block; thread t holds the 27 neighbour rows v[] of output row blk*BM + t (-1 = none).
 template <int BM>
 __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, int2* __restrict__ hdr,
@@ -67,18 +89,19 @@ __device__ __forceinline__ void slab_emit(const int (&v)[27], int blk, int t, in
     if (hi < 0) lo = 0;
     if (cnt > 0xFFFE) { cnt = 0xFFFE; overflow = true; }   // cannot happen for rows in linear-index order on grids the host admits
     const bool wants128 = fmt == FMT_BAKED128;                 // wave-uniform (kernel argument)
-    const bool wants = wants128 || BM == BAKED_ROWS;
-    const bool baked = wants128 ? (cnt + 1) * 128 <= 0xFFFF : (BM == BAKED_ROWS && (cnt + 1) * BAKED_ROW_BYTES <= 0xFFFF);
+    const bool wg = BM == 128 && fmt_is_wg(fmt);
+    const bool wants = wants128 || wg || BM == BAKED_ROWS;
+    const bool baked = wg ? cnt <= wg_cap(fmt) : wants128 ? (cnt + 1) * 128 <= 0xFFFF : (BM == BAKED_ROWS && (cnt + 1) * BAKED_ROW_BYTES <= 0xFFFF);
     if (t == 0) hdr[(size_t)blk * PLANES + j] = make_int2(lo, wants && !baked ? (int)((unsigned)cnt | HDR_RAW) : cnt);
 #pragma unroll
     for (int d = 0; d < TAPS; ++d) {
       const int k = j * TAPS + d, x = v[k];
-      unsigned s = baked ? 0u : NO_SLOT;
+      unsigned s = !baked ? NO_SLOT : wg ? wg_zero(fmt) : 0u;
       if (x >= 0 && x - lo < cnt) {
         const unsigned r = (unsigned)(x - lo) + 1u;
-        s = !baked ? r - 1u : wants128 ? baked128_entry(r) : baked_entry(r);
+        s = !baked ? r - 1u : wg ? wg_entry(fmt, j, r - 1u) : wants128 ? baked128_entry(r) : baked_entry(r);
       }
-      slots[((size_t)blk * 27 + k) * BM + t] = (uint16_t)s;
+      slots[(size_t)blk * 27 * BM + (wg ? wg_index(k, t) : k * BM + t)] = (uint16_t)s;
     }
   }
   if (overflow && t == 0 && status) atomicOr(status, 1);

@@ -12,8 +12,9 @@
 // Here: on a level in linear order the inputs that a block of 128 output rows reads through one kernel plane kx are ONE
 // contiguous range of rows (hdr = (lo, cnt) per block and plane; slots = the neighbour table as 16-bit offsets into that range).
 // A workgroup copies the three ranges of its block global -> LDS with LDS-DMA (coalesced 1 KiB pieces, no registers), one block
-// ahead of the MFMAs, together with the block's out_grad rows; the slot table travels two blocks ahead and is turned into LDS
-// byte addresses ("baked") one block ahead.  The reduction index of this GEMM is the ROW:
+// ahead of the MFMAs, together with the block's out_grad rows and its neighbour table, which the rulebook producers write as LDS byte
+// addresses in the order the lanes read them (spconv_slab_meta.h, FMT_WG64 / FMT_WG32: converting raw slots inside the kernel was
+// 36-59 % of the wave cycles — every wave of the one workgroup a CU holds did it at the same time).  The reduction index of this GEMM is the ROW:
 // ds_read_b64_tr_b16 takes a per-lane address and transposes across its 16-lane group, so lane (c, g) hands in the address of
 // the STAGED ROW of neighbour 8g + (c >> 2) — the gather happens in the address of the transposing read.  No per-offset global
 // load, no ds_write, no wait in the inner loop: per (32-row chunk, offset) a wave issues 2 * CIT transposing reads and
@@ -46,7 +47,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int ABL = BEVAMD_WGS_ABL;   // 1 no prefetch DMA (first block only), 2 no bake after the first, 4 no MFMA, 8 no X fragment reads, 16 no out_grad fragment reads
 
-constexpr int BM = 128;          // output rows per block (the metadata's block size, raw 16-bit slots)
+constexpr int BM = 128;          // output rows per block (the metadata's block size)
 constexpr int NW = 8;            // waves per workgroup
 constexpr int KPW = 4;           // kernel offsets per wave (8 x 4 >= 27)
 constexpr int NQ = BM / 32;      // 32-row chunks (one MFMA reduction each) per block
@@ -78,9 +79,12 @@ struct Plan {
   static constexpr int OFF_X = 0;
   static constexpr int OFF_G = 2 * XS;
   static constexpr int OFF_S = OFF_G + 2 * GS;
-  static constexpr int OFF_B = OFF_S + 3 * SS;         // baked addresses [27][4 g][4 cc][NQ][2] u16, two tables
+  static constexpr int OFF_B = OFF_S + 2 * SS;         // addresses converted in the kernel (planes with raw slots, later pieces)
   static constexpr int BS = (SLOT_BYTES + 15) / 16 * 16;
-  static constexpr int BYTES = OFF_B + 2 * BS;
+  static constexpr int BYTES = OFF_B + BS;
+  static constexpr int FMT = CIT == 2 ? slab::FMT_WG64 : slab::FMT_WG32;
+  static_assert(CAP == slab::wg_cap(CIT == 2 ? slab::FMT_WG64 : slab::FMT_WG32) && RBX == slab::wg_row_bytes(CIT == 2 ? slab::FMT_WG64 : slab::FMT_WG32),
+                "the metadata format bakes this plan's stage geometry");
   static_assert(CAP % RPX == 0 && BM % RPG == 0, "whole DMA instructions");
   static_assert(ZERO_OFF + RBX <= 0xFFFF, "baked addresses are 16-bit");
   static_assert(XPLANE % 1024 == 0 && GS % 1024 == 0, "KiB-aligned stages");
@@ -97,6 +101,7 @@ struct Args {
   int nblk, blocks_per_slab, nslabs, ncb, nco;
   int cinp_tot, coutp_tot;
   unsigned slot_bytes;
+  unsigned long long* prof;   // -DBEVAMD_WGS_PROF builds: cycle sums over all waves [issue + bake, multiply, dma wait, barrier] + [4] = waves
 };
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, void* l) {
@@ -148,11 +153,14 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_wgrad_slab_kernel(Args a) {
     for (int j = 0; j < 3; ++j) r.h[j] = a.hdr[(size_t)blk * 3 + j];
     return r;
   };
-  auto use_hdr = [&](const Hdr& r, int (&lo)[3], int (&cnt)[3]) {
+  auto use_hdr = [&](const Hdr& r, int (&lo)[3], int (&cnt)[3], unsigned& rawmask) {   // rawmask bit j: plane j carries raw slots
+    rawmask = 0u;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       lo[j] = __builtin_amdgcn_readfirstlane(r.h[j].x);
-      cnt[j] = __builtin_amdgcn_readfirstlane((int)((unsigned)r.h[j].y & ~slab::HDR_RAW));
+      const unsigned c2 = (unsigned)__builtin_amdgcn_readfirstlane(r.h[j].y);
+      cnt[j] = (int)(c2 & ~slab::HDR_RAW);
+      rawmask |= (c2 & slab::HDR_RAW) ? 1u << j : 0u;
     }
   };
   // rows [pbase, pbase + CAP) of the planes' ranges -> X stage st (piece `pbase / CAP` of the block)
@@ -195,8 +203,8 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_wgrad_slab_kernel(Args a) {
       dma16(rs_g, r * grow + (unsigned)co0 * 2u + piece * 16u, 0u, dg + i * 1024);
     }
   };
-  auto stage_slots = [&](int blk, int sb) {      // sb: one of the three slot stages
-    char* ds = L + P::OFF_S + sb * P::SS;
+  auto stage_slots = [&](int blk, int st) {
+    char* ds = L + P::OFF_S + st * P::SS;
     const unsigned sbase = (unsigned)blk * SLOT_BYTES;
     for (int i = w; i < SLOT_PIECES; i += NW) {
       unsigned off = sbase + (unsigned)i * 1024u + (unsigned)lane * 16u;
@@ -204,65 +212,113 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_wgrad_slab_kernel(Args a) {
       dma16(rs_s, off, 0u, ds + i * 1024);
     }
   };
-  // raw slots of stage st -> baked LDS offsets of piece pbase: entry (k, r) = byte offset of the staged row inside an X stage (or the
-  // zero row), stored where lane (g, cc) finds its 8 rows {32 q + 8 g + cc + 4 h} of offset k in ONE 16-byte read
-  auto bake = [&](const int (&cnt)[3], int pbase, int sb, int bt) {     // slot stage sb -> baked table bt
-    const uint16_t* raw = (const uint16_t*)(L + P::OFF_S + sb * P::SS);
-    uint16_t* const baked = (uint16_t*)(L + P::OFF_B + bt * P::BS);
+  // The table of a block arrives as LDS byte offsets (spconv_slab_meta.h, FMT_WG*), except for planes whose range is longer than
+  // the stage: those carry raw slots in the same positions and are converted here, piece by piece, into the one `baked` buffer
+  // (planes in `mask`; a plane without rows in this piece gets the zero row everywhere).
+  uint16_t* const baked = (uint16_t*)(L + P::OFF_B);
+  auto bake = [&](const int (&cnt)[3], unsigned rawmask, unsigned mask, int pbase, int st) {
+    const uint16_t* tab = (const uint16_t*)(L + P::OFF_S + st * P::SS);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {            // plane by plane: its row count stays in a scalar register
+    for (int j = 0; j < 3; ++j) {
+      if (!((mask >> j) & 1u)) continue;       // wave-uniform
       const int left = cnt[j] - pbase;
-      const unsigned lim = (unsigned)(left < 0 ? 0 : left < CAP ? left : CAP);
-      for (int e = tid; e < 9 * BM; e += NW * 64) {
-        const int k = j * 9 + e / BM, r = e % BM;
-        const unsigned s = (unsigned)raw[j * 9 * BM + e] - (unsigned)pbase;         // NO_SLOT stays above every limit
-        const unsigned off = s < lim ? (unsigned)(j * P::XPLANE) + s * P::RBX + (CIT == 2 ? ((s >> 3) & 1u) << 5 : 0u) : (unsigned)P::ZERO_OFF;
-        const int q = r >> 5, gg = (r >> 3) & 3, h = (r >> 2) & 1, c2 = r & 3;
-        baked[((k * 4 + gg) * 4 + c2) * (NQ * 2) + q * 2 + h] = (uint16_t)off;
+      const unsigned lim = ((rawmask >> j) & 1u) ? (unsigned)(left < 0 ? 0 : left < CAP ? left : CAP) : 0u;
+      for (int e = j * 9 * BM + tid; e < (j + 1) * 9 * BM; e += NW * 64) {
+        const unsigned s = (unsigned)tab[e] - (unsigned)pbase;         // NO_SLOT stays above every limit
+        baked[e] = (uint16_t)(s < lim ? slab::wg_entry(P::FMT, j, s) : (unsigned)P::ZERO_OFF);
       }
     }
   };
-  auto tr = [&](const char* p) -> s16x4 {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  // The requests of the NEXT block as nine per-wave tasks (6 row pieces, 2 out_grad pieces, 1 table piece), issued one after each of
+  // the first nine (chunk, offset) units of this block: asked for in one burst at the top of a block, the ~48 KiB of a block queue
+  // up in front of the texture path (64 bytes per clock and CU) and the waves sat in the issue of those requests for 23-38 % of their
+  // cycles (phase timers of -DBEVAMD_WGS_PROF builds) with nothing to multiply beside them.
+  struct Next { bool on; int lo[3], cnt[3], blk, st; } nx{false, {0, 0, 0}, {0, 0, 0}, 0, 0};
+  auto dma_task = [&](int t) __attribute__((always_inline)) {
+    if (!nx.on) return;                              // wave-uniform
+    if (t < 6) {
+      const int j = t >> 1, i = w + (t & 1) * NW;
+      const int cj = j == 0 ? nx.cnt[0] : j == 1 ? nx.cnt[1] : nx.cnt[2], lj = j == 0 ? nx.lo[0] : j == 1 ? nx.lo[1] : nx.lo[2];
+      const unsigned rows = (unsigned)(cj < CAP ? cj : CAP);
+      if ((unsigned)i * P::RPX >= rows) return;
+      unsigned r = (unsigned)i * P::RPX + xlr;
+      r = r < rows ? r : rows - 1u;
+      dma16(rs_x, r * xrow + xsp * 16u, (unsigned)lj * xrow + (unsigned)ci0 * 2u, L + P::OFF_X + nx.st * P::XS + j * P::XPLANE + i * 1024);
+    } else if (t < 8) {
+      const int i = w + (t - 6) * NW;
+      if (i >= BM / P::RPG) return;
+      unsigned r = (unsigned)nx.blk * BM + (unsigned)i * P::RPG + glr;
+      const unsigned last = (unsigned)a.m - 1u;
+      r = r < last ? r : last;
+      const unsigned piece = COT == 4 ? gsp ^ (((unsigned)i & 1u) << 2) : gsp;
+      dma16(rs_g, r * grow + (unsigned)co0 * 2u + piece * 16u, 0u, L + P::OFF_G + nx.st * P::GS + i * 1024);
+    } else {
+      if (w >= SLOT_PIECES) return;
+      unsigned off = (unsigned)nx.blk * SLOT_BYTES + (unsigned)w * 1024u + (unsigned)lane * 16u;
+      off = off + 16u <= a.slot_bytes ? off : a.slot_bytes - 16u;
+      dma16(rs_s, off, 0u, L + P::OFF_S + nx.st * P::SS + w * 1024);
+    }
   };
-  // the MFMAs of one staged piece of a block
+  constexpr int NTASK = 9;
+  // Transposing reads as INLINE ASSEMBLY with counted waits of our own.  Through the builtin, hipcc cannot tell the staged buffers
+  // apart and puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA request in program order (SIInsertWaitcnts:
+  // "LDS DMA store may alias"): the next block's rows were fully waited for BEFORE the first MFMA of this block — no overlap at all.
+  // A read it does not see cannot be made to wait; the price is that the waits for the reads' results are ours too: LDS operations of
+  // a wave return in order, so "the fragments of unit u have arrived" = at most as many operations outstanding as were issued
+  // after them (lgkmcnt(n), n a compile-time count; scalar loads in flight only make the wait longer, never shorter).
+  auto lds_addr = [&](const char* p) -> unsigned { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; };
+  auto tr_at = [&](unsigned addr) -> s16x4 {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+  };
+  auto tr_off = [&](unsigned addr, auto off_) -> s16x4 {      // ... with a compile-time byte offset in the instruction
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(off_)::value));
+    return v;
+  };
   // The (chunk, offset) units of a block form one flat list; the fragments of unit u + 1 (2 * CIT gathered transposing reads, and
-  // the 2 * COT out_grad reads when it opens a chunk) are requested BEFORE the CIT * COT MFMAs of unit u are issued — two register
-  // sets, sched_barrier keeps hipcc from re-serialising them behind one s_waitcnt (left to itself it waits for every read of an
-  // offset before its first MFMA and requests the next offset's after the last: a wave's LDS round trip per offset was exposed).
-  // Every wave runs its first three offsets in one unrolled body; waves 0-2 then run their fourth (offsets 24-26) in a second, short
-  // one (two whole bodies for 3 and 4 offsets behind one branch made hipcc rename every accumulator: 206 registers instead of 122).
-  auto compute_n = [&](int st, auto k0_, auto nt_) __attribute__((always_inline)) {
+  // the 2 * COT out_grad reads when it opens a chunk) are requested BEFORE the CIT * COT MFMAs of unit u are issued (two register
+  // sets).  Every wave runs its first three offsets in one unrolled body; waves 0-2 then run their fourth (offsets 24-26) in a
+  // second, short one (two whole bodies for 3 and 4 offsets behind one branch made hipcc rename every accumulator: 206 registers
+  // instead of 122).  One request of the next block's data follows each of the first nine units (dma_task).
+  auto compute_n = [&](int st, const u32x4 (&ad4)[KPW], auto k0_, auto nt_) __attribute__((always_inline)) {
     constexpr int KK0 = decltype(k0_)::value, NT = decltype(nt_)::value, U = NQ * NT;
-    const uint16_t* const baked = (const uint16_t*)(L + P::OFF_B + st * P::BS);
-    const char* X = L + P::OFF_X + st * P::XS + (c & 3) * 8;
-    const char* G = L + P::OFF_G + st * P::GS + (8 * g + cc) * P::RBG + (c & 3) * 8;
-    unsigned gto[COT];   // byte offset of out_grad tile t inside this lane's rows
-#pragma unroll
-    for (int t = 0; t < COT; ++t) gto[t] = ((unsigned)t ^ g_tile_swz) << 5;
-    u32x4 ad[NT];
-#pragma unroll
-    for (int kk = 0; kk < NT; ++kk) ad[kk] = *(const u32x4*)(baked + (((w + (KK0 + kk) * NW) * 4 + g) * 4 + cc) * (NQ * 2));
-    auto load_b = [&](int q, s16x8 (&b)[COT]) {
+    const unsigned X = lds_addr(L + P::OFF_X + st * P::XS + (c & 3) * 8);
+    // out_grad: this lane's rows of chunk 0, tile swizzle in bits 5-6 (rows are whole 32-byte tiles, so "+" is "|" there and tile t is
+    // one xor away); the chunk and the +4 rows go into the instruction's offset field
+    const unsigned Gs = lds_addr(L + P::OFF_G + st * P::GS + (8 * g + cc) * P::RBG + (c & 3) * 8) | (g_tile_swz << 5);
+    auto load_b = [&](auto q_, s16x8 (&b)[COT]) {
+      constexpr int Q = decltype(q_)::value;
 #pragma unroll
       for (int t = 0; t < COT; ++t) {
-        if constexpr (ABL & 16) { b[t] = s16x8{(short)(q + t), 1, 2, 3, 4, 5, 6, (short)lane}; continue; }
-        const s16x4 lo = tr(G + q * 32 * P::RBG + gto[t]);
-        const s16x4 hi = tr(G + (q * 32 + 4) * P::RBG + gto[t]);
+        if constexpr (ABL & 16) { b[t] = s16x8{(short)(Q + t), 1, 2, 3, 4, 5, 6, (short)lane}; continue; }
+        const unsigned gt = Gs ^ (unsigned)(t << 5);
+        const s16x4 lo = tr_off(gt, std::integral_constant<int, Q * 32 * P::RBG>{});
+        const s16x4 hi = tr_off(gt, std::integral_constant<int, (Q * 32 + 4) * P::RBG>{});
         b[t] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     };
     auto load_x = [&](int u, s16x8 (&x)[CIT]) {
-      const unsigned pair = ad[u % NT][u / NT];
+      const unsigned pair = ad4[KK0 + u % NT][u / NT];
       const unsigned o_lo = pair & 0xFFFFu, o_hi = pair >> 16;
 #pragma unroll
       for (int t = 0; t < CIT; ++t) {
         if constexpr (ABL & 8) { x[t] = s16x8{(short)o_lo, (short)o_hi, 2, 3, 4, 5, (short)t, (short)lane}; continue; }
-        const s16x4 lo = tr(X + (o_lo ^ (unsigned)(t * 32)));   // xor: the baked offset carries the half swap in bit 5
-        const s16x4 hi = tr(X + (o_hi ^ (unsigned)(t * 32)));
+        const s16x4 lo = tr_at(X + (o_lo ^ (unsigned)(t * 32)));   // xor: the baked offset carries the half swap in bit 5
+        const s16x4 hi = tr_at(X + (o_hi ^ (unsigned)(t * 32)));
         x[t] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
     };
+    // at most N LDS operations of this wave outstanding; the fragments named are results of earlier reads: tying them to the wait keeps
+    // hipcc from issuing their MFMAs in front of it
+    auto wait_frags = [&](auto n_, s16x8 (&x)[CIT], s16x8 (&b)[COT]) {
+      constexpr int N = decltype(n_)::value;
+      if constexpr (CIT == 1 && COT == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(b[0]) : "n"(N));
+      else if constexpr (CIT == 2 && COT == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+      else asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(x[0]), "+v"(x[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+    };
+    static_assert((CIT == 1 && COT == 1) || (CIT == 2 && (COT == 2 || COT == 4)), "wait_frags lists the fragments of these shapes");
     auto mma = [&](int kk, const s16x8 (&x)[CIT], const s16x8 (&b)[COT]) {
 #pragma unroll
       for (int ta = 0; ta < CIT; ++ta)
@@ -272,71 +328,122 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_wgrad_slab_kernel(Args a) {
           else acc[kk][ta][tb] = mfma<F16>(x[ta], b[tb], acc[kk][ta][tb]);
         }
     };
+    constexpr int RX = (ABL & 8) ? 0 : 2 * CIT, RB = (ABL & 16) ? 0 : 2 * COT;    // LDS reads of one unit's rows / one chunk's out_grad
     s16x8 b0[COT], b1[COT], x0[CIT], x1[CIT];
-    load_b(0, b0);
+    load_b(std::integral_constant<int, 0>{}, b0);
     load_x(0, x0);
+    auto load_b_rt = [&](int q1) {      // q1 is a constant after unrolling; the offset field wants it as a template argument
+      if (q1 == 1) load_b(std::integral_constant<int, 1>{}, b1);
+      else if (q1 == 2) load_b(std::integral_constant<int, 2>{}, b0);
+      else if (q1 == 3) load_b(std::integral_constant<int, 3>{}, b1);
+    };
+    static_assert(NQ == 4, "load_b_rt lists the chunks");
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = u / NT, kk = u % NT;
+      constexpr int dummy = 0;
+      (void)dummy;
+      const bool nextb = u + 1 < U && (u + 1) % NT == 0;
       if (u + 1 < U) {
         const int q1 = (u + 1) / NT;
-        if ((u + 1) % NT == 0) { if (q1 & 1) load_b(q1, b1); else load_b(q1, b0); }
+        if (nextb) load_b_rt(q1);
         if ((u + 1) & 1) load_x(u + 1, x1); else load_x(u + 1, x0);
       }
+      // outstanding behind unit u's fragments: what was just requested for unit u + 1
+      auto wait_u = [&](s16x8 (&x)[CIT], s16x8 (&b)[COT]) {
+        if (u + 1 >= U) wait_frags(std::integral_constant<int, 0>{}, x, b);
+        else if (nextb) wait_frags(std::integral_constant<int, RX + RB>{}, x, b);
+        else wait_frags(std::integral_constant<int, RX>{}, x, b);
+      };
+      if (u & 1) { if (q & 1) { wait_u(x1, b1); mma(KK0 + kk, x1, b1); } else { wait_u(x1, b0); mma(KK0 + kk, x1, b0); } }
+      else { if (q & 1) { wait_u(x0, b1); mma(KK0 + kk, x0, b1); } else { wait_u(x0, b0); mma(KK0 + kk, x0, b0); } }
       __builtin_amdgcn_sched_barrier(0);
-      if (u & 1) { if (q & 1) mma(KK0 + kk, x1, b1); else mma(KK0 + kk, x1, b0); }
-      else { if (q & 1) mma(KK0 + kk, x0, b1); else mma(KK0 + kk, x0, b0); }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (KK0 == 0) {
+        static_assert(KK0 != 0 || U >= NTASK, "every task of the next block needs a unit to follow");
+        if (u < NTASK) dma_task(u);
+      }
     }
   };
-  auto compute = [&](int st) __attribute__((always_inline)) {
-    compute_n(st, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-    if (w + 3 * NW < 27) compute_n(st, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+  auto compute = [&](int st, unsigned bmask) __attribute__((always_inline)) {
+    // the address quads of all four offsets, read (by ordinary loads the compiler sees) BEFORE the first request of the next block
+    const uint16_t* const tab = (const uint16_t*)(L + P::OFF_S + st * P::SS);
+    u32x4 ad4[KPW];
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+      const int k0 = w + kk * NW, k = k0 < 27 ? k0 : 26;
+      const uint16_t* t = (bmask >> (k / 9)) & 1u ? baked : tab;      // wave-uniform: this offset's plane was converted in the kernel
+      ad4[kk] = *(const u32x4*)(t + ((k * 4 + g) * 4 + cc) * (NQ * 2));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    compute_n(st, ad4, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+    if (w + 3 * NW < 27) compute_n(st, ad4, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
   };
 
   if (blk_beg < blk_end) {
-    // Pipeline: while block n multiplies, the rows and out_grad of block n + 1 and the slot table of block n + 2 are in flight,
-    // and the slot table of block n + 1 (landed one block ago) is baked into the other address table — one barrier per block.
+    // Pipeline: while block n multiplies, the rows, out_grad and address table of block n + 1 are in flight (its header came a
+    // block earlier) — one barrier per block, no work between a block's last MFMA and the next block's first but that barrier.
     int lo[3], cnt[3], lo_n[3], cnt_n[3];
+    unsigned rawm = 0u, rawm_n = 0u;
     Hdr raw = load_hdr_raw(blk_beg);
-    use_hdr(raw, lo, cnt);
-    if (blk_beg + 1 < blk_end) { raw = load_hdr_raw(blk_beg + 1); use_hdr(raw, lo_n, cnt_n); }
+    use_hdr(raw, lo, cnt, rawm);
+    if (blk_beg + 1 < blk_end) { raw = load_hdr_raw(blk_beg + 1); use_hdr(raw, lo_n, cnt_n, rawm_n); }
     stage_x(lo, cnt, 0, 0);
     stage_g(blk_beg, 0);
     stage_slots(blk_beg, 0);
-    if (blk_beg + 1 < blk_end) stage_slots(blk_beg + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    bake(cnt, 0, 0, 0);
-    __syncthreads();
-    int st = 0, sb = 0;                             // X / out_grad / baked stage, slot stage of the current block
-    for (int blk = blk_beg; blk < blk_end; ++blk, st ^= 1, sb = sb == 2 ? 0 : sb + 1) {
+#ifdef BEVAMD_WGS_PROF
+    unsigned long long t_issue = 0, t_mul = 0, t_wait = 0, t_bar = 0, t0 = __builtin_readcyclecounter(), t1;
+#define WGS_TICK(acc_) do { t1 = __builtin_readcyclecounter(); acc_ += t1 - t0; t0 = t1; } while (0)
+#else
+#define WGS_TICK(acc_) do { } while (0)
+#endif
+    int st = 0;
+    for (int blk = blk_beg; blk < blk_end; ++blk, st ^= 1) {
       const bool more = blk + 1 < blk_end;
-      const int sb1 = sb == 2 ? 0 : sb + 1, sb2 = sb1 == 2 ? 0 : sb1 + 1;
       if (blk + 2 < blk_end) raw = load_hdr_raw(blk + 2);
-      if (more && !(ABL & 1)) {
-        stage_x(lo_n, cnt_n, 0, st ^ 1);
-        stage_g(blk + 1, st ^ 1);
-        if (blk + 2 < blk_end) stage_slots(blk + 2, sb2);
-        if (!(ABL & 2)) bake(cnt_n, 0, sb1, st ^ 1);
+      nx.on = more && !(ABL & 1);
+      nx.blk = blk + 1;
+      nx.st = st ^ 1;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { nx.lo[j] = lo_n[j]; nx.cnt[j] = cnt_n[j]; }
+      if (rawm) {                                   // rare: a plane with raw slots — converted before the block multiplies
+        bake(cnt, rawm, rawm, 0, st);
+        __syncthreads();
       }
-      compute(ABL & 1 ? 0 : st);
-      int longest = cnt[0] > cnt[1] ? cnt[0] : cnt[1];
-      longest = longest > cnt[2] ? longest : cnt[2];
-      for (int pbase = CAP; pbase < longest; pbase += CAP) {   // rare: a range longer than the stage — its next CAP rows, synchronously
-        __syncthreads();
-        stage_x(lo, cnt, pbase, st);
-        bake(cnt, pbase, sb, st);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        compute(st);
+      WGS_TICK(t_issue);
+      compute(ABL & 1 ? 0 : st, rawm);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WGS_TICK(t_mul);
+      if (rawm) {
+        int longest = cnt[0] > cnt[1] ? cnt[0] : cnt[1];
+        longest = longest > cnt[2] ? longest : cnt[2];
+        for (int pbase = CAP; pbase < longest; pbase += CAP) {   // ... and its further pieces of CAP rows, synchronously
+          __syncthreads();
+          stage_x(lo, cnt, pbase, st);
+          bake(cnt, rawm, 7u, pbase, st);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          nx.on = false;
+          compute(st, 7u);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                              // the next block has landed and is baked; everybody is done with this one
+      WGS_TICK(t_wait);
+      __syncthreads();                              // the next block has landed; everybody is done with this one
+      WGS_TICK(t_bar);
 #pragma unroll
       for (int j = 0; j < 3; ++j) { lo[j] = lo_n[j]; cnt[j] = cnt_n[j]; }
-      if (blk + 2 < blk_end) use_hdr(raw, lo_n, cnt_n);
+      rawm = rawm_n;
+      if (blk + 2 < blk_end) use_hdr(raw, lo_n, cnt_n, rawm_n);
     }
+#ifdef BEVAMD_WGS_PROF
+    if (a.prof && lane == 0) {
+      atomicAdd(a.prof + 0, t_issue); atomicAdd(a.prof + 1, t_mul); atomicAdd(a.prof + 2, t_wait); atomicAdd(a.prof + 3, t_bar);
+      atomicAdd(a.prof + 4, 1ull);
+    }
+#endif
+#undef WGS_TICK
   }
   // D[i = ci][j = co]: lane holds column co = c, rows ci = 4 g + e of a tile
 #pragma unroll

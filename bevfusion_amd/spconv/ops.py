@@ -83,25 +83,29 @@ class Rulebook:
         self._conv_tables = None
         self._slab128 = None
 
-    def slab_meta128(self):
-        """Slab metadata (128-row blocks, raw 16-bit slots: csrc/spconv_slab_meta.h) of a symmetric 3x3x3 SubM rulebook whose rows
-        turn out to be in (near-)linear order — what the staged-rows filter gradient reads — or None.  Built from the neighbour
-        table on first use and shared by the convolutions of a level (they share the rulebook through `indice_key`).  Whether the
-        rows are ordered is MEASURED, not promised: the mean staged range of a block must stay below 4 blocks (a level in linear
-        order stages little more than its 128 rows per plane; first-appearance order stages thousands) and no range may overflow the 16-bit slots
-        — one small reduction and one host read-back per level."""
+    def slab_meta_wgrad(self, cin):
+        """Slab metadata (128-row blocks, the filter gradient's address format for `cin` channels: csrc/spconv_slab_meta.h FMT_WG64 /
+        FMT_WG32) of a symmetric 3x3x3 SubM rulebook whose rows turn out to be in (near-)linear order — what the staged-rows filter
+        gradient reads — or None.  Built from the neighbour table on first use and shared by the convolutions of a level (they share
+        the rulebook through `indice_key`).  Whether the rows are ordered is MEASURED, not promised: the mean staged range of a block
+        must stay below 4 blocks (a level in linear order stages little more than its 128 rows per plane; first-appearance order
+        stages thousands) and no range may overflow the 16-bit slots — one small reduction and one host read-back per level."""
+        code = int(_capi.load().bevamd_spconv_wgrad_slab_block_rows(int(cin)))
+        if code == 0:
+            return None
         if self._slab128 is None:
-            meta = False
+            self._slab128 = {}
+        if code not in self._slab128:
+            meta = None
             if (self.subm and self.symmetric and self.kernel_volume == 27 and self.num_out >= 128 and self.num_in == self.num_out
-                    and os.environ.get("BEVAMD_SPCONV_WGRAD_SLAB", "1") != "0"):
-                m = slab_build(self.nbr, self.num_out, None, 128)
+                    and os.environ.get("BEVAMD_SPCONV_WGRAD_SLAB", "1") != "0" and False not in self._slab128.values()):
+                m = slab_build(self.nbr, self.num_out, None, code)
                 nblk = (self.num_out + 127) // 128
                 cnt = m.hdr[:nblk * 24].view(torch.int32).view(nblk, 3, 2)[:, :, 1] & 0x3FFFFFFF
                 staged, flag = (int(v) for v in torch.stack((cnt.sum(dtype=torch.int64), m.status[0].to(torch.int64))).tolist())
-                if flag == 0 and staged <= 4 * 128 * 3 * nblk:
-                    meta = m
-            self._slab128 = meta
-        return self._slab128 or None
+                meta = m if flag == 0 and staged <= 4 * 128 * 3 * nblk else False
+            self._slab128[code] = meta if meta is not None else False
+        return self._slab128[code] or None
 
     @property
     def nbr_stride(self):
@@ -609,7 +613,7 @@ def sparse_conv_backward(features, filters, out_grad, rulebook_nbr, nbr_t, num_i
     if (rulebook is not None and features.dtype in (torch.float16, torch.bfloat16)
             and lib.bevamd_spconv_wgrad_slab_supported(_dtype_code(features), cin, cout)
             and features.stride(0) % 8 == 0 and out_grad.stride(0) % 8 == 0):
-        meta = rulebook.slab_meta128()
+        meta = rulebook.slab_meta_wgrad(cin)
         if meta is not None:
             return in_grad, sparse_conv_wgrad_slab(features, out_grad, meta, cin, cout).view(filters.shape)
     fgrad = torch.empty_like(filters.contiguous())

@@ -597,10 +597,13 @@ int bevamd_spconv_conv_wgrad(const void* features, const void* out_grad, int dty
 
 /* The same filter gradient (spconv_ops.h:363-456, the filter half of indice_conv_backward_half) for a 3x3x3 SUBMANIFOLD
  * convolution over rows in ascending linear index, with the rulebook given as slab metadata (hdr / slots of
- * bevamd_spconv_slab_build* with block_rows = 128: raw 16-bit slots) instead of the neighbour table: the neighbour rows of a block
+ * bevamd_spconv_slab_build* with block_rows = bevamd_spconv_wgrad_slab_block_rows(cin): the table as LDS byte addresses in the
+ * order the lanes of the transposing reads want them, csrc/spconv_slab_meta.h FMT_WG64 / FMT_WG32) instead of the neighbour table: the neighbour rows of a block
  * of output rows are contiguous ranges, staged in LDS once and gathered by the transposing LDS reads (csrc/spconv_wgrad_slab.h).
  * 16-bit features; cin == cout in {16, 32, 64, 128}; pitches in elements, multiples of 8.  Deterministic. */
+void bevamd_spconv_wgrad_slab_set_profile_buffer(void* buf);   /* only meaningful in -DBEVAMD_WGS_PROF experiment builds */
 int bevamd_spconv_wgrad_slab_supported(int dtype, int cin, int cout);
+int bevamd_spconv_wgrad_slab_block_rows(int cin);   /* block_rows code (128 | format << 16) of the metadata a cin -> cin layer reads */
 size_t bevamd_spconv_wgrad_slab_workspace_bytes(int cin, int cout);
 int bevamd_spconv_conv_wgrad_slab(const void* features, int feat_stride, int num_in, const void* out_grad, int og_stride,
                                   int dtype, const void* hdr, const void* slots, int block_rows, int num_out, int cin,

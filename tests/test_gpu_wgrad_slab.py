@@ -3,7 +3,7 @@ oracle restating indiceConvBackward (spconv_ops.h:363-456) and against the gathe
 
 Bars: 16-bit features, fp32 accumulation, one rounding of the result: <= 2e-3 * (1 + max|ref|) of the float64 oracle on the rounded
 inputs (the bar of test_gpu_spconv.py::test_filter_gradient_mfma_any_width_deterministic), bit-identical run to run; rows that are
-NOT in linear order must not take this path at all (the range test of Rulebook.slab_meta128 is measured, not promised)."""
+NOT in linear order must not take this path at all (the range test of Rulebook.slab_meta_wgrad is measured, not promised)."""
 import numpy as np
 import pytest
 import torch
@@ -43,7 +43,7 @@ def test_slab_filter_gradient_vs_oracle_and_gather_kernel(dev, c, dtype):
     B, shape = 2, (40, 24, 9)
     indices = _sorted_indices(rng, B, shape, 2500)           # 5000 rows: 40 blocks, a partial last block, several slabs
     x, g, rb, ref = _case(rng, indices, B, shape, c, dtype, dev)
-    meta = rb.slab_meta128()
+    meta = rb.slab_meta_wgrad(c)
     assert meta is not None, "rows in linear order must qualify for the staged-rows path"
     outs = [sops.sparse_conv_wgrad_slab(x, g, meta, c, c) for _ in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])          # no atomics, fixed-order partials
@@ -67,7 +67,7 @@ def test_ranges_longer_than_the_stage_are_walked_in_pieces(dev):
     indices = _sorted_indices(rng, B, shape, 6900)            # 90 % occupancy, 96 cells per (x, y) line: ranges of ~300 rows
     for c, dtype in ((32, torch.float16), (16, torch.float16), (64, torch.bfloat16)):
         x, g, rb, ref = _case(rng, indices, B, shape, c, dtype, dev)
-        meta = rb.slab_meta128()
+        meta = rb.slab_meta_wgrad(c)
         assert meta is not None
         nblk = (indices.shape[0] + 127) // 128
         cnt = (meta.hdr[:nblk * 24].view(torch.int32).view(nblk, 3, 2)[:, :, 1] & 0x3FFFFFFF).cpu().numpy()
@@ -83,7 +83,7 @@ def test_unordered_rows_keep_the_gather_kernel(dev):
     indices = _sorted_indices(rng, B, shape, 2500)
     rng.shuffle(indices, axis=0)
     x, g, rb, ref = _case(rng, indices, B, shape, 32, torch.float16, dev)
-    assert rb.slab_meta128() is None
+    assert rb.slab_meta_wgrad(32) is None
     wt = torch.zeros((3, 3, 3, 32, 32), dtype=torch.float16, device=dev)
     got = sops.sparse_conv_backward(x, wt, g, *rb.conv_tables(), x.shape[0], rulebook=rb)[1].float().cpu().numpy().reshape(27, 32, 32)
     assert float(np.max(np.abs(got - ref))) / (1 + np.abs(ref).max()) <= 2e-3
@@ -102,7 +102,7 @@ def test_autograd_takes_the_staged_rows_path_on_ordered_rows(dev):
     gy = torch.randn_like(out.features)
     out.features.backward(gy)
     rb = out.indice_dict["s"].rulebook
-    meta = rb.slab_meta128()
+    meta = rb.slab_meta_wgrad(32)
     assert meta is not None
     direct = sops.sparse_conv_wgrad_slab(feats.half(), gy.half(), meta, 32, 32).view(3, 3, 3, 32, 32)
     assert torch.equal(conv.weight.grad, direct.to(conv.weight.grad.dtype))

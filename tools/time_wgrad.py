@@ -48,13 +48,23 @@ def main():
         t_old = min(timeit(old)[0] for _ in range(3))
         os.environ["BEVAMD_SPCONV_WGRAD_SLAB"] = "1"
         rb._slab128 = None
-        meta = rb.slab_meta128()
+        meta = rb.slab_meta_wgrad(c)
         if meta is None:
             print(f"{c:3d}->{c:<3d} rows={rb.num_out:8d} gather {t_old:7.1f} us   staged rows: not eligible (rows not in linear order)", flush=True)
             total_old += 4 * t_old
             total_new += 4 * t_old
             continue
         t_new = min(timeit(lambda: sops.sparse_conv_wgrad_slab(x, g, meta, c, c))[0] for _ in range(3))
+        if os.environ.get("WGS_PROF"):   # BEVAMD_LIB = a -DBEVAMD_WGS_PROF build: cycle sums of the phases over all waves
+            prof = torch.zeros(8, dtype=torch.int64, device=dev)
+            lib.bevamd_spconv_wgrad_slab_set_profile_buffer(sops._capi.ptr(prof))
+            sops.sparse_conv_wgrad_slab(x, g, meta, c, c)
+            torch.cuda.synchronize()
+            lib.bevamd_spconv_wgrad_slab_set_profile_buffer(None)
+            pv = prof.tolist()
+            tot = sum(pv[:4]) or 1
+            print(f"    phases (share of wave cycles, {pv[4]} waves, {tot / max(pv[4], 1):.0f} cycles per wave): issue+bake {pv[0] / tot:.2f}  multiply {pv[1] / tot:.2f}  "
+                  f"dma wait {pv[2] / tot:.2f}  barrier {pv[3] / tot:.2f}", flush=True)
         new = sops.sparse_conv_wgrad_slab(x, g, meta, c, c).float()
         old()
         err = float((new.view(-1) - fg.float().view(-1)).abs().max() / (1 + fg.float().abs().max()))
