@@ -732,7 +732,8 @@ def train_step(args, rank, world, frame_ids, dev):
         mark(3)
         outf.backward(gout)
         mark(4)
-        vf, vc, _ = voxelize_batch(pts, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][0])
+        vf, vc, _ = voxelize_batch(pts, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][0],
+                                   order=args.voxel_order)
         mark(5)
         if scaler is not None:
             with torch.autocast("cuda", dtype=torch.float16):

@@ -31,7 +31,6 @@ _SIGNATURES = {
     "bevamd_bev_pool_prepare_from_geom": (I, [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, Z, P]),
     "bevamd_bev_pool_forward_cells": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_forward_cells_tuned": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
-    "bevamd_bev_pool_striped_line": (I, [I, I, I, I, P, I]),
     "bevamd_bev_pool_fused_forward": (I, [P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bevamd_bev_pool_fused_schedule_workspace_bytes": (Z, [I]),
     "bevamd_bev_pool_fused_schedule": (I, [P, P, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
@@ -142,6 +141,11 @@ _SIGNATURES = {
 
 
 # libbevfusion_amd_ext.so (include/bevfusion_amd_ext.h): exports of the reference's pybind modules outside the hot path
+# exported by -DBEVAMD_PROFILING builds only (rejected experiments kept for sweeps): bound when present
+_PROFILING_SIGNATURES = {
+    "bevamd_bev_pool_striped_line": (I, [I, I, I, I, P, I]),
+}
+
 _EXT_SIGNATURES = {
     "bevamd_dynamic_scatter_workspace_bytes": (Z, [I]),
     "bevamd_dynamic_scatter_index": (I, [P, I, I, P, P, P, P, P, P, P, P, Z, P]),
@@ -185,6 +189,11 @@ def _bind(path, signatures, mode=ctypes.DEFAULT_MODE):
             raise NativeLibraryMissing(f"symbol {name} missing from {path}: rebuild the library") from e
         fn.restype = res
         fn.argtypes = args
+    if signatures is _SIGNATURES:
+        for name, (res, args) in _PROFILING_SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
     return lib
 
 

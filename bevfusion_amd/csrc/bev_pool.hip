@@ -694,18 +694,26 @@ static int launch_cells_vec(const void* x, const uint32_t* order, const uint32_t
                  xv, order, cell_start, ncells, out, lpr, rpi, s); break;
     case 15: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 8, 0, true><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
                  xv, order, cell_start, ncells, out, lpr, rpi, s); break;
+#ifdef BEVAMD_PROFILING   // measured slower than the plain walk and rejected (EXPERIMENTS C.7): kept for sweeps, not shipped
     case 16: BEVAMD_STRIPED(4, 2, true); break;
     case 17: BEVAMD_STRIPED(8, 2, true); break;
     case 18: BEVAMD_STRIPED(4, 1, true); break;
     case 19: BEVAMD_STRIPED(8, 1, true); break;
+#endif
 #define BEVAMD_TILED(U, TX)                                                                                           \
   {                                                                                                                   \
     const uint32_t rb = cdiv((uint32_t)s.W * (uint32_t)s.D, 4u), lp = cdiv((uint32_t)s.H, TX);                        \
     bev_pool_fwd_cells_vec_kernel<VecT, VEC, U, 0, true, TX>                                                          \
         <<<dim3(rb * lp * (uint32_t)s.B), dim3(256 * TX), 0, stream>>>(xv, order, cell_start, ncells, out, lpr, rpi, s); \
   }
+#ifdef BEVAMD_PROFILING
     case 23: BEVAMD_TILED(8, 2); break;
     case 25: BEVAMD_TILED(4, 2); break;
+#else
+    case 16: case 17: case 18: case 19: case 23: case 25:
+      set_error("bev_pool_forward_cells: variant %d (XCD-striped / tiled walk) is compiled into -DBEVAMD_PROFILING builds only", variant);
+      return BEVAMD_ERR_UNSUPPORTED;
+#endif
 #undef BEVAMD_TILED
 #undef BEVAMD_STRIPED
     case 3: BEVAMD_COOP(4, 4); break;
@@ -872,7 +880,8 @@ int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint
   return BEVAMD_OK;
 }
 
-/* host-only (tests): the XCD-striped walk's map of one padded line of workgroups — groups[p] = the 4-cell group workgroup p of
+#ifdef BEVAMD_PROFILING
+/* host-only (tests of profiling builds): the XCD-striped walk's map of one padded line of workgroups — groups[p] = the 4-cell group workgroup p of
  * line `line` takes, or -1 for a padding slot; stripe_groups in {1, 2, 4}, rot_lines = lines per step of the rotating stripe map
  * (0: fixed).  Returns the padded line length (a multiple of 8: workgroup p runs on XCD p % 8), negative on bad arguments. */
 int bevamd_bev_pool_striped_line(int row_groups, int stripe_groups, int line, int rot_lines, int* groups, int max_n) {
@@ -895,6 +904,7 @@ int bevamd_bev_pool_striped_line(int row_groups, int stripe_groups, int line, in
   }
   return (int)pb;
 }
+#endif
 
 int bevamd_bev_pool_forward_cells(const void* x, int x_is_bf16, const uint32_t* order, const uint32_t* cell_start,
                                   float* out, int n, int c, int b, int d, int h, int w, void* stream_) {

@@ -38,6 +38,8 @@ def _workspace(dev, c):
     # BatchNorm calls running concurrently on different streams of one device (two models, an eager call beside a graph replay)
     key = (dev.index, int(c), int(torch.cuda.current_stream(dev).cuda_stream))
     if key not in _WS:
+        while len(_WS) >= 64:            # bounded: the oldest (device, width, stream) entry goes
+            _WS.pop(next(iter(_WS)))
         nbytes = int(_capi.load().bevamd_sparse_bn_workspace_bytes(c))
         _WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)   # zeroed once: the ticket word; every launch leaves it zero
     return _WS[key]

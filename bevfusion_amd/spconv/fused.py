@@ -513,7 +513,11 @@ def _frames_hint(enc, batch_size, n_rows, num_voxels):
         elif torch.cuda.is_current_stream_capturing():
             return None
         else:
-            hints[batch_size] = min(int(num_voxels.reshape(-1)[0]), n_rows) / float(_ROWS_PER_FLAGSHIP_FRAME)
+            live = int(num_voxels.reshape(-1)[0])
+            if live < 0:   # the voxelizer's single-pass kernels flag a stalled look-back word as total = -1 (csrc/voxelize.hip): flagged, never silent
+                raise RuntimeError("SparseEncoder: the voxelizer reported a failed pass (num_voxels < 0: a single-pass look-back word "
+                                   "stalled); rerun with BEVAMD_SINGLE_PASS=0")
+            hints[batch_size] = min(live, n_rows) / float(_ROWS_PER_FLAGSHIP_FRAME)
     return hints[batch_size]
 
 
@@ -546,6 +550,8 @@ def _narrow_variant_for(conv, lvl, cin, cout):
         rows = ops.slab_block_rows(cin, variant)
         return variant if rows and ops.slab_grid_ok(lvl.shape, rows) else None
     variant = overrides.get(-16, _SLAB_NARROW_STRIDED)
+    if not ops.slab_block_rows(cin, variant) and -16 not in overrides:
+        variant = 3000128          # cin <= 8 -> 16: the both-tiles-in-one-wave shape (3100128) is built for 16 -> 32 only
     return variant if ops.slab_block_rows(cin, variant) else None
 
 

@@ -558,8 +558,15 @@ def sparse_conv(features, filters, nbr, num_out, bias=None, bn_scale=None, bn_sh
             residual = residual.to(features.dtype)
         return sparse_conv_tiled(feats, image, nbr, num_out, K, cin, cout, bias=bias, bn_scale=bn_scale,
                                  bn_shift=bn_shift, residual=residual, relu=relu)
+    # fp32 on the bf16 matrix cores by three-way operand splitting (csrc/spconv_tile_f32x3.hip): NOT the exact fp32 chain — three of
+    # the nine piece products are dropped (<= 1.2e-6 of float64 relative to 1 + max|ref|), an Inf input becomes NaN (hi = Inf,
+    # remainder = Inf - Inf) and bf16-range denormals of a piece may flush.  Its preconditions (16-byte aligned rows, a feature matrix
+    # below 2 GiB) are checked here, so that a tensor it cannot serve takes the exact-chain kernel below instead of raising.
     if (prepared is None and features.dtype == torch.float32 and _F32X3 != "0" and f32x3_supported(cin, cout)
-            and (_F32X3 == "1" or num_out >= _F32X3_MIN_ROWS)):
+            and (_F32X3 == "1" or num_out >= _F32X3_MIN_ROWS)
+            and features.data_ptr() % 16 == 0 and (features.stride(0) * 4) % 16 == 0
+            and features.shape[0] * features.stride(0) * 4 < 2 ** 31
+            and (residual is None or (residual.data_ptr() % 16 == 0 and (residual.stride(0) * 4) % 16 == 0))):
         return sparse_conv_f32x3(features, make_filter_image3(filters, transpose_io), nbr, num_out, K, cin, cout, bias=bias,
                                  bn_scale=bn_scale, bn_shift=bn_shift, residual=residual, relu=relu)
     if prepared is None:

@@ -37,7 +37,8 @@ def gen_dx_bx(xbound, ybound, zbound):
     return dx, bx, nx
 
 
-_RASTER_MAPS = {}   # (device, bytes) -> the persistent zeroed map of _depth_raster_native
+_RASTER_MAPS = {}          # (device, bytes, stream) -> zeroed map; insertion-ordered, at most _RASTER_MAPS_MAX entries
+_RASTER_MAPS_MAX = 8
 
 class FactoredCamFeats:
     """`get_cam_feats` result kept factored: depth [B, N, D, fH, fW] (softmax) and context [B, N, C, fH, fW].  Equivalent
@@ -391,6 +392,8 @@ class BaseDepthTransform(BaseTransform):
             key = (dev.index, int(wsb), int(torch.cuda.current_stream(dev).cuda_stream))
             ws = _RASTER_MAPS.get(key)
             if ws is None and not torch.cuda.is_current_stream_capturing():
+                while len(_RASTER_MAPS) >= _RASTER_MAPS_MAX:      # bounded (69 MB per map at 8 frames, one per stream ever used):
+                    _RASTER_MAPS.pop(next(iter(_RASTER_MAPS)))    # the oldest goes; a stream that comes back takes a fresh, zeroed map
                 ws = _RASTER_MAPS[key] = torch.zeros(wsb, dtype=torch.uint8, device=dev)
             if ws is not None:
                 rc = lib.bevamd_depth_raster_batch_zero_ws(ptrs, counts, B, nfeat, _capi.ptr(inv_rot), _capi.ptr(trans), 3,

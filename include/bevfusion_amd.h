@@ -206,9 +206,11 @@ int bevamd_bev_pool_forward_cells_tuned(const void* x, int x_is_bf16, const uint
                                         const uint32_t* cell_start, float* out, int n, int c, int b,
                                         int d, int h, int w, int variant, void* stream);
 
+#ifdef BEVAMD_PROFILING   /* profiling builds only: the rejected XCD-striped walk (variants 16-19) and its host-side map */
 /* host-only (tests of the striped variants 16..19 above): groups[p] = the 4-cell group that workgroup p of the padded line `line`
  * takes (-1: padding); returns the padded line length — a multiple of 8, workgroup p runs on XCD p % 8 — or a negative error code. */
 int bevamd_bev_pool_striped_line(int row_groups, int stripe_groups, int line, int rot_lines, int* groups, int max_n);
+#endif
 
 /* The same gradient written in POINT order (x_grad[i] = out_grad[cell of point i], zeros for dropped points): consecutive
  * 16-byte pieces of x_grad by consecutive threads — a streaming write — with the scattered side on the cached out_grad reads.

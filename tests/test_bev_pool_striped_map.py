@@ -13,6 +13,11 @@ import pytest
 
 from bevfusion_amd import _capi
 
+# round 6: the striped walk lost to the plain one and left the shipped library; its kernels and this hook are
+# compiled into -DBEVAMD_PROFILING builds only (python -m bevfusion_amd.build --profiling), where these tests still run
+if not hasattr(_capi.load()._main, "bevamd_bev_pool_striped_line"):
+    pytest.skip("rejected experiment: exported by profiling builds only", allow_module_level=True)
+
 
 def line(lib, rb, sw, ln, rot=0):
     buf = (ctypes.c_int * 4096)()

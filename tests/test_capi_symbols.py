@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header="bevfusion_amd.h"):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#ifdef BEVAMD_PROFILING.*?#endif", "", txt, flags=re.S)   # hooks of rejected experiments: profiling builds only
     return set(re.findall(r"\b(bevamd_\w+)\s*\(", txt))
 
 

@@ -147,6 +147,7 @@ def test_full_op_matches_oracle(dev, n, B, D, H, W, c, hot):
 # wave per cell (1, 2), cooperative (3-7), batched tails (14, 15 = the defaults), XCD-striped (16-19; + 100 * lines per step of
 # the rotating stripe map), 2 x 4 cell tiles (23, 25)
 FORWARD_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 14, 15, 16, 17, 18, 19, 23, 25, 118, 219, 316, 817)
+PROFILING_ONLY = {16, 17, 18, 19, 23, 25}     # rejected walks (EXPERIMENTS C.7): in -DBEVAMD_PROFILING builds only since round 6
 
 
 @pytest.mark.parametrize("n,B,D,H,W,c,hot", [
@@ -172,6 +173,8 @@ def test_every_forward_variant_matches_oracle_and_variant_1(dev, n, B, D, H, W, 
         out = torch.full((B, D, H, W, c), float("nan"), dtype=torch.float32, device=dev)
         rc = lib.bevamd_bev_pool_forward_cells_tuned(_capi.ptr(x), int(bf16), _capi.ptr(plan.order), _capi.ptr(plan.cell_start),
                                                     _capi.ptr(out), plan.n, c, B, D, H, W, v, _capi.stream_ptr(dev))
+        if rc == 4 and v % 100 in PROFILING_ONLY:      # BEVAMD_ERR_UNSUPPORTED: not in the shipped library
+            continue
         _capi.check(rc, f"variant {v}")
         got = out.cpu().numpy()
         assert np.isfinite(got).all(), f"variant {v} left cells unwritten"
