@@ -92,6 +92,11 @@ def parse():
                     help="infer (default): the inference hot path of BASELINE configs[3]; train-step: forward + backward + optimizer "
                          "step of the same path in fp32 (BASELINE configs[4]: 4 frames per GPU unless --batch / --global-batch says "
                          "otherwise, gradients all-reduced over RCCL when --gpus > 1)")
+    ap.add_argument("--train-inputs", choices=["augmented", "static"], default="augmented",
+                    help="--mode train-step: augmented (default) = what a training step of the reference pays — per-sample image augmentation "
+                         "(resize 0.38-0.55, rotate +-5.4 deg, flip) and LiDAR augmentation (rotate +-45 deg, scale 0.9-1.1, translate 0.5 m) drawn "
+                         "per step, frustum geometry + pooling plan + column plan rebuilt INSIDE the timed step, point clouds rotating through a "
+                         "pool; static = round 5's protocol (one test-time calibration, plan built once outside the timed loop, the same clouds)")
     ap.add_argument("--no-extras", action="store_true",
                     help="infer mode, one rank: skip the secondary measurements of `extra` (bev_pool on bf16 features = BASELINE "
                          "configs[1], the single-frame step, the product step without the double-counted API kernel, 5 steps of "
@@ -272,7 +277,7 @@ def compact_line(res, side_file=None):
     per_rank = cfg.get("per_rank") or []
     ms = [r["ms_per_step"] for r in per_rank if isinstance(r, dict) and "ms_per_step" in r]
     out["config"] = {k: cfg[k] for k in ("workload", "frames_per_step", "frames_per_step_per_gpu", "rccl_ranks", "stage_ms", "overlap",
-                                         "inputs", "hip_graph", "gradient_allreduce") if k in cfg}
+                                         "inputs", "hip_graph", "gradient_allreduce", "plan_ms", "runs_per_column", "fused_kernel") if k in cfg}
     if ms:
         out["config"]["per_rank_ms_per_step"] = {"min": min(ms), "max": max(ms)}
     rf = res.get("roofline")
@@ -308,6 +313,9 @@ def compact_line(res, side_file=None):
         e["train_amp_ms"] = g("train_step_amp", "ms_per_step")
         e["train_amp_frames"] = g("train_step_amp", "frames")
         e["train_amp_bev_pool_bwd_frac"] = g("train_step_amp", "bev_pool_bwd_frac")
+        e["train_amp_plan_ms"] = g("train_step_amp", "plan_ms")
+        e["train_amp_runs_per_column"] = g("train_step_amp", "runs_per_column")
+        e["train_amp_fused_kernel"] = g("train_step_amp", "fused_kernel")
         e["fused_pool_alone_ms"] = g("fused_pool", "alone_ms")
         e["fused_pool_rigged_ms"] = g("fused_pool", "rigged_ms")
         e["kernel_nodes"] = (ex.get("lidar_graph") or {}).get("kernel_nodes")
@@ -699,12 +707,12 @@ def train_step(args, rank, world, frame_ids, dev):
 
     cfg = synth.CL_CONFIG
     B = len(frame_ids)
+    augmented = getattr(args, "train_inputs", "augmented") == "augmented"
     inp = synth.bev_pool_inputs(cfg, batch=1, seed=rank, with_feats=False)     # one calibration, tiled over the frames on the device
     H, W, D = (int(v) for v in inp["nx"])
     C = inp["channels"]
     geom = torch.from_numpy(inp["geom"]).to(dev).repeat(B, 1)
-    plan = BevPoolPlan.from_geometry(geom, B, inp["origin"], inp["dx"], inp["nx"], want_intervals=True)
-    n_kept = plan.n_kept()
+    plan0 = BevPoolPlan.from_geometry(geom, B, inp["origin"], inp["dx"], inp["nx"], want_intervals=True)
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
     feats = torch.randn((geom.shape[0], C), generator=gen, device=dev).requires_grad_(True)
     fh, fw = cfg["feature_size"]
@@ -713,48 +721,94 @@ def train_step(args, rank, world, frame_ids, dev):
     depth = torch.softmax(torch.randn((B * n_cam, dbins, fh, fw), generator=gen, device=dev), 1).requires_grad_(True)
     ctx = torch.randn((B * n_cam * fh * fw, C), generator=gen, device=dev).requires_grad_(True)
     gout = torch.randn((B, D, H, W, C), generator=gen, device=dev)
-    pts = [torch.from_numpy(synth.lidar_points(seed=f)).to(dev) for f in frame_ids]
+    # ---- the inputs of a step.  augmented (VERDICT r5 missing #3): the reference augments per sample per step
+    # (configs/nuscenes/default.yaml:13-15, 20-23; datasets/pipelines/transforms_3d.py:85-165, 196-230), so get_geometry
+    # (vtransforms/base.py:92-135), the rank / sort / CSR plan (base.py:141-176, bev_pool.py:83-97) and the column plan of the fused
+    # pooling are on the critical path of EVERY training step: they are rebuilt inside the timed step from that step's matrices
+    # (drawn beforehand: sampling is the data loader's work), and the point clouds rotate through a pool with that step's LiDAR
+    # augmentation applied.
+    from bevfusion_amd.vtransforms import DepthLSSTransform
+
+    vt = DepthLSSTransform(256, C, cfg["image_size"], cfg["feature_size"], cfg["xbound"], cfg["ybound"], cfg["zbound"], cfg["dbound"],
+                           downsample=2).to(dev).eval()
+    rig = synth.camera_rig(n_cam)
+    t_c2l_r = torch.from_numpy(np.tile(rig["camera2lidar_rots"], (B, 1, 1, 1))).to(dev)
+    t_c2l_t = torch.from_numpy(np.tile(rig["camera2lidar_trans"], (B, 1, 1))).to(dev)
+    t_K = torch.from_numpy(np.tile(rig["intrins"], (B, 1, 1, 1))).to(dev)
+    n_pool = max(8, 2 * B) if augmented else B
+    pool = [torch.from_numpy(synth.lidar_points(seed=1000 * rank + f)).to(dev) for f in (range(n_pool) if augmented else frame_ids)]
+    rng = np.random.default_rng(4242 + rank)
+    n_aug = (max(1, args.warmup) + args.steps) if augmented else 0
+    augs = []
+    for _ in range(n_aug):
+        a = synth.training_augmentation(rng, B, n_cam, cfg)
+        augs.append({k: torch.from_numpy(v).to(dev) for k, v in a.items()})
+    origin, dx_l, nx_l = inp["origin"], inp["dx"], inp["nx"]
+    state = {"i": 0, "plan": plan0, "runs": [], "kernel": [], "kept": []}
     enc = make_encoder(cfg, dev, torch.float32).train()
     model = wrap_for_gradient_allreduce(enc, world, dev)
     opt = torch.optim.AdamW(enc.parameters(), lr=2e-4, weight_decay=0.01)
     scaler = torch.amp.GradScaler("cuda", growth_interval=2000) if args.amp else None
-    names = ["bev_pool_fwd", "bev_pool_bwd", "fused_pool_fwd", "fused_pool_bwd", "voxelize", "encoder_fwd", "encoder_bwd+allreduce",
+    names = ["geometry+plan", "bev_pool_fwd", "bev_pool_bwd", "fused_pool_fwd", "fused_pool_bwd", "voxelize", "encoder_fwd", "encoder_bwd+allreduce",
              "clip+adamw"]
 
     def step(ev=None):
         mark = (lambda i: ev[i].record()) if ev else (lambda i: None)
+        i = state["i"]
+        state["i"] += 1
         mark(0)
-        out = plan.forward(feats)
+        if augmented:
+            a = augs[i % n_aug]
+            with torch.no_grad():
+                gm = vt.get_geometry(t_c2l_r, t_c2l_t, t_K, a["post_rots"], a["post_trans"], extra_rots=a["extra_rots"],
+                                     extra_trans=a["extra_trans"])
+            plan = BevPoolPlan.from_geometry(gm.view(-1, 3), B, origin, dx_l, nx_l)
+            plan.prepare_fused(dbins, fh, fw, C)             # the column plan (one 4-byte read-back sizes its buffers)
+            state["plan"] = plan
+            pts = []
+            for j in range(B):
+                p = pool[(i * B + j) % n_pool]
+                xyz = p[:, :3] @ a["extra_rots"][j].t() + a["extra_trans"][j]       # the step's LiDAR augmentation on the device
+                pts.append(torch.cat((xyz, p[:, 3:]), 1))
+        else:
+            plan, pts = plan0, pool
         mark(1)
-        out.backward(gout)
+        out = plan.forward(feats)
         mark(2)
-        outf = plan.fused(depth, ctx, dbins, fh, fw)
+        out.backward(gout)
         mark(3)
-        outf.backward(gout)
+        outf = plan.fused(depth, ctx, dbins, fh, fw)
         mark(4)
+        outf.backward(gout)
+        mark(5)
         vf, vc, _ = voxelize_batch(pts, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][0],
                                    order=args.voxel_order)
-        mark(5)
+        mark(6)
         if scaler is not None:
             with torch.autocast("cuda", dtype=torch.float16):
                 y = model(vf, vc, B)
-            mark(6)
-            scaler.scale(y.float().square().mean()).backward()
             mark(7)
+            scaler.scale(y.float().square().mean()).backward()
+            mark(8)
             scaler.unscale_(opt)
             torch.nn.utils.clip_grad_norm_(enc.parameters(), 35.0)
             scaler.step(opt)
             scaler.update()
         else:
             y = model(vf, vc, B)
-            mark(6)
-            y.square().mean().backward()
             mark(7)
+            y.square().mean().backward()
+            mark(8)
             torch.nn.utils.clip_grad_norm_(enc.parameters(), 35.0)
             opt.step()
         opt.zero_grad(set_to_none=True)
         feats.grad = depth.grad = ctx.grad = None
-        mark(8)
+        mark(9)
+        if augmented and ev is None:        # warm-up steps only (untimed): which fused kernel the step's plan selects, runs per image column
+            cols = plan.fused_columns(dbins, fh, fw, C, build=False)
+            state["kernel"].append("columns" if cols is not None else "cells")
+            if cols is not None:
+                state["runs"].append(cols.nruns / max(1, B * n_cam * dbins * fw))
 
     for _ in range(max(1, args.warmup)):
         step()
@@ -773,7 +827,9 @@ def train_step(args, rank, world, frame_ids, dev):
     frames_per_step = int(sum_over_ranks(B, device=dev))
     stage = {n: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i, n in enumerate(names)}
     per_step_ms = [round(float(e[0].elapsed_time(e[len(names)])), 3) for e in evs]            # GPU time of every timed step
-    fwd_step_ms = [round(float(e[5].elapsed_time(e[6])), 3) for e in evs]                     # ... and of its encoder forward
+    fwd_step_ms = [round(float(e[6].elapsed_time(e[7])), 3) for e in evs]                     # ... and of its encoder forward
+    plan = state["plan"]
+    n_kept = plan.n_kept()
     # the dominant streaming kernel of the step, timed on its own (the stage above also holds autograd's copy of the incoming gradient)
     for _ in range(3):
         plan.launch_backward(gout, C)
@@ -799,8 +855,16 @@ def train_step(args, rank, world, frame_ids, dev):
             "data": "synthetic",
             "config": {"workload": f"training step of the hot path, {B} frame(s)/GPU (BASELINE configs[4]: 4 per GPU): bev_pool "
                                    f"N'={geom.shape[0]} ({n_kept} kept) x C={C} fwd+bwd, fused depth x context pooling fwd+bwd, hard "
-                                   f"voxelize {sum(p.shape[0] for p in pts)} points (cap {cfg['max_voxels'][0]}), SparseEncoder fp32 "
+                                   f"voxelize ~{sum(p.shape[0] for p in pool[:B])} points (cap {cfg['max_voxels'][0]}), SparseEncoder fp32 "
                                    f"train mode ({nparam} parameters) fwd+bwd, clip_grad_norm 35, AdamW",
+                       "inputs": ("augmented per step like the reference's training pipeline: per-camera image augmentation (resize 0.38-0.55, "
+                                  "rotate +-5.4 deg, flip), per-sample LiDAR augmentation (rotate +-45 deg, scale 0.9-1.1, translate N(0, 0.5 m)); "
+                                  "get_geometry + pooling plan + column plan rebuilt INSIDE every timed step (stage geometry+plan); point clouds "
+                                  f"rotate through a pool of {n_pool}") if augmented else
+                                 "static (round 5 protocol): one test-time calibration, plan built once outside the timed loop, the same clouds every step",
+                       "plan_ms": stage.get("geometry+plan"),
+                       "runs_per_column": (float(np.mean(state["runs"])) if state["runs"] else None),
+                       "fused_kernel": (max(set(state["kernel"]), key=state["kernel"].count) if state["kernel"] else "columns (static plan)"),
                        "frames_per_step_per_gpu": B, "frames_per_step": frames_per_step, "stage_ms": stage,
                        "per_step_ms": per_step_ms, "encoder_fwd_per_step_ms": fwd_step_ms,
                        "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention; see quiet_gc)",
@@ -1470,6 +1534,8 @@ def main():
             tr = train_step(a2, 0, 1, list(range(4)), dev)
             extra["train_step_amp"] = dict(ms_per_step=tr["ms_per_step"], frames_per_s=tr["value"], frames=4, steps=5,
                                            stage_ms=tr["config"]["stage_ms"], bev_pool_bwd_frac=tr["roofline"]["frac"],
+                                           plan_ms=tr["config"].get("plan_ms"), runs_per_column=tr["config"].get("runs_per_column"),
+                                           fused_kernel=tr["config"].get("fused_kernel"), inputs=tr["config"].get("inputs"),
                                            bev_pool_bwd_kernel_ms=tr["roofline"]["kernel_ms"],
                                            note="--mode train-step --amp (fp16 conv operands, fp32 accumulate / master weights): fwd + "
                                                 "bwd + clip + AdamW of bev_pool, fused pooling, voxelize, SparseEncoder at 4 frames")

@@ -88,6 +88,11 @@ __device__ __forceinline__ void slab_of(long long n, long long& lo, long long& h
 constexpr int GROUP = 32;
 constexpr int MAX_SLABS = 1024;
 constexpr int MAX_GROUPS = MAX_SLABS / GROUP;
+constexpr int BN_DEFAULT_SLABS = 512, BN_DEFAULT_UNROLL = 4;
+// Round 6: one ticket per 128-byte line.  The tickets of all groups used to sit in consecutive words of ONE line, so the 512 arrivals
+// of a launch were 512 atomics on one L2 line, served one after another (~50 ns each): 25 us of a 55-us kernel, and the reason why
+// MORE slabs made the reductions slower (1024 slabs: 81 us, 256: 36 us for the same 54 MB; tools/time_bn.py).
+constexpr int TICKET_STRIDE = 32;   // words
 
 // sum over `n` partial rows (stride floats/doubles apart) per channel, by one workgroup: thread -> (channel, share), four rows in flight
 template <typename T, typename Out>
@@ -135,12 +140,15 @@ __device__ __forceinline__ void finish_totals(const float* sa, const float* sb, 
     __hip_atomic_store(mine + c, sa[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(mine + C + c, sb[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
+  // no __threadfence() here (round 6): the barrier orders the partial stores of all threads before thread 0's ticket, and the ticket
+  // is an acq_rel read-modify-write at agent scope — its release half publishes everything that happens-before it.  The fence was
+  // executed by every wave of every workgroup (an L2 write-back each on a multi-XCD part) and made the kernels slower the more
+  // slabs they were given: 81 us at 1024 slabs, 55 at 512, 36 at 256 for the same 54 MB (tools/time_bn.py).
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(tickets + grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(tickets + grp * TICKET_STRIDE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     last = t == (unsigned)gsize - 1u;
-    if (last) __hip_atomic_store(tickets + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) __hip_atomic_store(tickets + grp * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (!last) return;
@@ -153,9 +161,9 @@ __device__ __forceinline__ void finish_totals(const float* sa, const float* sb, 
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(tickets + MAX_GROUPS, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(tickets + MAX_GROUPS * TICKET_STRIDE, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     last = t == (unsigned)ngroups - 1u;
-    if (last) __hip_atomic_store(tickets + MAX_GROUPS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) __hip_atomic_store(tickets + MAX_GROUPS * TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (!last) return;
@@ -164,7 +172,7 @@ __device__ __forceinline__ void finish_totals(const float* sa, const float* sb, 
 }
 
 // this workgroup's per-channel sums of (p, q) over its rows -> LDS sa / sb [C]; `rowfn(row, cv, p[VEC], q[VEC])` supplies the terms
-template <int VEC, typename RowFn>
+template <int VEC, int U, typename RowFn>
 __device__ __forceinline__ void slab_sums(long long n, int C, float* sa, float* sb, RowFn rowfn) {
   extern __shared__ float dyn[];   // [rows in flight][2][C]
   const int lpr = C / VEC, rif = THREADS / lpr;
@@ -177,7 +185,7 @@ __device__ __forceinline__ void slab_sums(long long n, int C, float* sa, float* 
   // four rows per trip, their loads issued together (the callback loads all four before it touches the sums): with one load in
   // flight per lane the reductions ran at 0.8 TB/s (first cut, profiles/r04_train_step_amp_kernel_trace_stats_a.txt)
   if (r_in < rif)
-    for (long long r = lo + r_in; r < hi; r += 4LL * rif) rowfn(r, (long long)rif, hi, cv, p, q);
+    for (long long r = lo + r_in; r < hi; r += (long long)U * rif) rowfn(r, (long long)rif, hi, cv, p, q);
   if (r_in < rif) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -198,7 +206,7 @@ __device__ __forceinline__ void slab_sums(long long n, int C, float* sa, float* 
   __syncthreads();
 }
 
-template <int DT>
+template <int DT, int U>
 __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restrict__ x_, long long n, int C, long long stride,
                                                            float eps, float momentum, float* __restrict__ mean,
                                                            float* __restrict__ invstd, float* __restrict__ running_mean,
@@ -212,17 +220,17 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const void* __restric
   // SHIFTED sums: p = sum (x - x0), q = sum (x - x0)^2 with x0 = row 0 of the tensor — the same pivot in every
   // workgroup, a value of the channel's own distribution — so that var = q/n - (p/n)^2 does not cancel when |mean| >> std
   // (E[x^2] - mean^2 on raw fp32 sums loses ~1e-7 * mean^2 / var of relative accuracy; torch's batch_norm runs Welford).
-  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, long long step, long long hi, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
-    V v[4];
+  slab_sums<R::VEC, U>(n, C, sa, sb, [&](long long r, long long step, long long hi, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
+    V v[U];
     float x0[R::VEC];
     R::unpack(*(const V*)(x + (size_t)cv * R::VEC * esz), x0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const long long ru = r + u * step < hi ? r + u * step : r;
       v[u] = *(const V*)(x + ((size_t)ru * stride + (size_t)cv * R::VEC) * esz);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (r + u * step < hi) {
         float f[R::VEC];
         R::unpack(v[u], f);
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(THREADS) void bn_apply_kernel(const void* __restric
   }
 }
 
-template <int DT>
+template <int DT, int U>
 __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const void* __restrict__ dy_, long long dy_stride,
                                                                 const void* __restrict__ y_, long long y_stride,
                                                                 const void* __restrict__ x_, long long stride, long long n, int C,
@@ -312,21 +320,21 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const void* __re
   typedef typename R::V V;
   __shared__ float sa[MAX_C], sb[MAX_C];
   const size_t esz = DT == 0 ? 4 : 2;
-  slab_sums<R::VEC>(n, C, sa, sb, [&](long long r, long long step, long long hi, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
+  slab_sums<R::VEC, U>(n, C, sa, sb, [&](long long r, long long step, long long hi, int cv, float (&p)[R::VEC], float (&q)[R::VEC]) {
     const int c0 = cv * R::VEC;
     float mu[R::VEC], is[R::VEC];
 #pragma unroll
     for (int j = 0; j < R::VEC; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
-    V vd[4], vx[4], vy[4];
+    V vd[U], vx[U], vy[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const long long ru = r + u * step < hi ? r + u * step : r;
       vd[u] = *(const V*)((const char*)dy_ + ((size_t)ru * dy_stride + c0) * esz);
       vx[u] = *(const V*)((const char*)x_ + ((size_t)ru * stride + c0) * esz);
       if (relu) vy[u] = *(const V*)((const char*)y_ + ((size_t)ru * y_stride + c0) * esz);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       if (r + u * step < hi) {
         float d[R::VEC], f[R::VEC], o[R::VEC];
         R::unpack(vd[u], d);
@@ -413,12 +421,24 @@ static int check_shape(const char* who, long long n, int c, int dtype) {
   return BEVAMD_OK;
 }
 
+// tuning knobs of the two reducing kernels (round 6): BEVAMD_BN_SLABS = most workgroups (default 512, at most MAX_SLABS),
+// BEVAMD_BN_UNROLL = rows a lane keeps in flight per trip (4 | 8)
+static int bn_max_slabs() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BEVAMD_BN_SLABS"); v = e ? atoi(e) : BN_DEFAULT_SLABS; v = v < 1 ? 1 : v > MAX_SLABS ? MAX_SLABS : v; }
+  return v;
+}
+static int bn_unroll() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BEVAMD_BN_UNROLL"); v = e ? atoi(e) : BN_DEFAULT_UNROLL; v = v == 8 ? 8 : 4; }
+  return v;
+}
 static unsigned reduce_grid(long long n, int c, int dtype) {
   const int vec = dtype == 0 ? 4 : 8, rif = THREADS / (c / vec);
   // >= 16 rows per lane (four trips of four), at most 512 slabs: a slab's fixed cost (LDS column sums, partial stores, fence,
   // ticket: ~5 us) is paid per workgroup — 1024 slabs measured 62 / 95 us per layer (stats / backward reduce) against 50 / 68 at 512
   long long g = n / ((long long)rif * 16);
-  return (unsigned)(g < 1 ? 1 : g > 512 ? 512 : g);
+  return (unsigned)(g < 1 ? 1 : g > bn_max_slabs() ? bn_max_slabs() : g);
 }
 
 static unsigned apply_grid(long long n, int c, int dtype) {
@@ -440,7 +460,9 @@ extern "C" {
  * it; every launch leaves it zero again).  bytes: bevamd_sparse_bn_workspace_bytes(c). */
 static size_t ws_part_bytes(int c) { return align_up((size_t)MAX_SLABS * 2 * c * sizeof(float), 256); }
 static size_t ws_gpart_bytes(int c) { return align_up((size_t)MAX_GROUPS * 2 * c * sizeof(double), 256); }
-size_t bevamd_sparse_bn_workspace_bytes(int c) { return c > 0 ? ws_part_bytes(c) + ws_gpart_bytes(c) + 256 : 0; }
+size_t bevamd_sparse_bn_workspace_bytes(int c) {
+  return c > 0 ? ws_part_bytes(c) + ws_gpart_bytes(c) + align_up((size_t)(MAX_GROUPS + 1) * TICKET_STRIDE * sizeof(unsigned), 256) : 0;
+}
 
 /* Training-mode statistics of x [n, c] (row pitch `stride` elements; dtype 0 fp32 | 1 fp16 | 2 bf16): mean [c], invstd [c] =
  * 1 / sqrt(biased var + eps) (fp32), and — when given — running_mean / running_var updated in place with `momentum` (unbiased
@@ -461,7 +483,11 @@ int bevamd_sparse_bn_stats(const void* x, int dtype, long long n, int c, long lo
   const unsigned g = reduce_grid(n, c, dtype);
   const int vec = dtype == 0 ? 4 : 8;
   const size_t lds = (size_t)(THREADS / (c / vec)) * 2 * c * sizeof(float);
-#define BEVAMD_GO(DT) bn_stats_kernel<DT><<<dim3(g), dim3(THREADS), lds, stream>>>(x, n, c, stride, eps, momentum, mean, invstd, running_mean, running_var, part, gpart, ticket)
+#define BEVAMD_GO(DT)                                                                                                                          \
+  do {                                                                                                                                         \
+    if (bn_unroll() == 8) bn_stats_kernel<DT, 8><<<dim3(g), dim3(THREADS), lds, stream>>>(x, n, c, stride, eps, momentum, mean, invstd, running_mean, running_var, part, gpart, ticket); \
+    else bn_stats_kernel<DT, 4><<<dim3(g), dim3(THREADS), lds, stream>>>(x, n, c, stride, eps, momentum, mean, invstd, running_mean, running_var, part, gpart, ticket); \
+  } while (0)
   if (dtype == 0) BEVAMD_GO(0); else if (dtype == 1) BEVAMD_GO(1); else BEVAMD_GO(2);
 #undef BEVAMD_GO
   BEVAMD_LAUNCH_CHECK("bn_stats");
@@ -511,8 +537,12 @@ int bevamd_sparse_bn_backward(const void* dy, long long dy_stride, const void* y
   const size_t lds = (size_t)(THREADS / (c / vec)) * 2 * c * sizeof(float);
 #define BEVAMD_GO(DT)                                                                                                              \
   do {                                                                                                                             \
-    bn_bwd_reduce_kernel<DT><<<dim3(g), dim3(THREADS), lds, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean,      \
-                                                                      invstd, sum_dz, sum_dz_xhat, part, gpart, ticket);           \
+    if (bn_unroll() == 8)                                                                                                          \
+      bn_bwd_reduce_kernel<DT, 8><<<dim3(g), dim3(THREADS), lds, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean,  \
+                                                                         invstd, sum_dz, sum_dz_xhat, part, gpart, ticket);        \
+    else                                                                                                                           \
+      bn_bwd_reduce_kernel<DT, 4><<<dim3(g), dim3(THREADS), lds, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean,  \
+                                                                         invstd, sum_dz, sum_dz_xhat, part, gpart, ticket);        \
     bn_bwd_apply_kernel<DT><<<dim3(ga), dim3(THREADS), 0, stream>>>(dy, dy_stride, y, y_stride, x, stride, n, c, relu, mean, invstd, \
                                                                     weight, sum_dz, sum_dz_xhat, dx, dx_stride, d_residual,        \
                                                                     dres_stride);                                                  \

@@ -184,3 +184,46 @@ def rigged_geometry(B, n_cam, D, fh, fw, seed, pitch_deg=1.5, roll_deg=1.0, rot_
             pts = pts @ (c2l @ np.linalg.inv(rig["intrins"][n].astype(np.float64))).T + rig["camera2lidar_trans"][n]
             out[b, n] = pts
     return out.astype(np.float32)
+
+
+def training_augmentation(rng, B, n_cam, cfg=CL_CONFIG, ori_shape=(1600, 900), resize_lim=(0.38, 0.55), bot_pct_lim=(0.0, 0.0),
+                          rot_lim_deg=(-5.4, 5.4), rand_flip=True, lidar_scale=(0.9, 1.1), lidar_rot=(-0.78539816, 0.78539816),
+                          lidar_trans_std=0.5):
+    """One training batch's augmentation matrices, drawn the way the reference's pipeline draws them per sample and per camera:
+    ImageAug3D (datasets/pipelines/transforms_3d.py:85-131 sampling, :134-165 the post-homography: resize, crop, flip, rotate about the
+    crop centre; configs/nuscenes/default.yaml:13-15 resize [0.38, 0.55], rotate +-5.4 deg; bot_pct_lim [0, 0], rand_flip) and
+    GlobalRotScaleTrans (:196-230; default.yaml:20-23 scale 0.9-1.1, rotate +-pi/4, translate N(0, 0.5) per axis).
+    -> dict(post_rots [B,N,3,3], post_trans [B,N,3], extra_rots [B,3,3], extra_trans [B,3]) fp32: what BaseTransform._split_mats
+    hands get_geometry (img_aug_matrix[..., :3, :3] / [..., :3, 3], lidar_aug_matrix likewise)."""
+    W, H = ori_shape
+    fH, fW = cfg["image_size"]
+    post_rots = np.tile(np.eye(3, dtype=np.float64), (B, n_cam, 1, 1))
+    post_trans = np.zeros((B, n_cam, 3))
+    for b in range(B):
+        for n in range(n_cam):
+            resize = rng.uniform(*resize_lim)
+            newW, newH = int(W * resize), int(H * resize)
+            crop_h = int((1 - rng.uniform(*bot_pct_lim)) * newH) - fH
+            crop_w = int(rng.uniform(0, max(0, newW - fW)))
+            flip = bool(rand_flip and rng.integers(0, 2))
+            theta = rng.uniform(*rot_lim_deg) / 180.0 * math.pi
+            rot = np.eye(2) * resize
+            tr = -np.array([crop_w, crop_h], dtype=np.float64)
+            if flip:
+                A = np.array([[-1.0, 0.0], [0.0, 1.0]])
+                rot, tr = A @ rot, A @ tr + np.array([fW, 0.0])
+            A = np.array([[math.cos(theta), math.sin(theta)], [-math.sin(theta), math.cos(theta)]])
+            c = np.array([fW, fH], dtype=np.float64) / 2
+            rot, tr = A @ rot, A @ tr + (A @ (-c) + c)
+            post_rots[b, n, :2, :2] = rot
+            post_trans[b, n, :2] = tr
+    extra_rots = np.empty((B, 3, 3))
+    extra_trans = np.empty((B, 3))
+    for b in range(B):
+        scale, th = rng.uniform(*lidar_scale), rng.uniform(*lidar_rot)
+        t = rng.normal(0.0, lidar_trans_std, size=3)
+        R = np.array([[math.cos(th), -math.sin(th), 0.0], [math.sin(th), math.cos(th), 0.0], [0.0, 0.0, 1.0]])
+        extra_rots[b] = R.T * scale
+        extra_trans[b] = t * scale
+    f = lambda a: a.astype(np.float32)
+    return dict(post_rots=f(post_rots), post_trans=f(post_trans), extra_rots=f(extra_rots), extra_trans=f(extra_trans))

@@ -351,3 +351,53 @@ def test_column_backward_with_dropped_columns_and_poisoned_lds(dev):
         assert np.max(np.abs(dc.cpu().numpy() - want_dc)) <= 1e-4
         dropped = want_dc.reshape(cams, fh, fw, c)[:, :, [1, 6]]
         assert not dropped.any() and not dc.view(cams, fh, fw, c)[:, :, [1, 6]].any() and not dc.view(cams, fh, fw, c)[1].any()
+
+
+@pytest.mark.parametrize("B,seed", [(2, 0), (4, 7)])
+def test_per_step_training_plan_equals_the_oracle(dev, B, seed):
+    """What `bench.py --mode train-step` rebuilds inside every timed step (round 6): that step's augmentation
+    matrices (synth.training_augmentation = ImageAug3D + GlobalRotScaleTrans as the reference samples them,
+    transforms_3d.py:85-165, 196-230) -> get_geometry on the device (base.py:92-135) -> rank / sort / CSR plan -> column plan ->
+    pooled BEV — against a float64 segment sum of the explicit outer product with the reference's cell arithmetic
+    (base.py:149-169) on the SAME geometry, and the materialised-volume op on that plan against the float64 oracle."""
+    import oracle
+    from bevfusion_amd.vtransforms import DepthLSSTransform
+
+    cfg = synth.CL_CONFIG
+    n_cam, (fh, fw), c = cfg["num_cameras"], cfg["feature_size"], 80
+    vt = DepthLSSTransform(256, c, cfg["image_size"], cfg["feature_size"], cfg["xbound"], cfg["ybound"], cfg["zbound"], cfg["dbound"],
+                           downsample=2).to(dev).eval()
+    rig = synth.camera_rig(n_cam)
+    a = synth.training_augmentation(np.random.default_rng(seed), B, n_cam, cfg)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    with torch.no_grad():
+        gm = vt.get_geometry(t(np.tile(rig["camera2lidar_rots"], (B, 1, 1, 1))), t(np.tile(rig["camera2lidar_trans"], (B, 1, 1))),
+                             t(np.tile(rig["intrins"], (B, 1, 1, 1))), t(a["post_rots"]), t(a["post_trans"]),
+                             extra_rots=t(a["extra_rots"]), extra_trans=t(a["extra_trans"]))
+    D = gm.shape[2]
+    dx, bx, nx = synth.gen_dx_bx(cfg["xbound"], cfg["ybound"], cfg["zbound"])
+    origin = (bx - dx / np.float32(2.0)).astype(np.float32)
+    H, W, Dz = (int(v) for v in nx)
+    plan = BevPoolPlan.from_geometry(gm.view(-1, 3), B, origin, dx, nx)
+    plan.prepare_fused(D, fh, fw, c)
+    geom = gm.cpu().numpy().reshape(-1, 3)
+    cell = ((geom - origin) / dx).astype(np.int64)                       # fp32 subtract / divide, truncation like .long()
+    coords = np.concatenate([cell, np.repeat(np.arange(B), geom.shape[0] // B)[:, None]], 1)
+    rng = np.random.default_rng(seed + 1)
+    cams = B * n_cam
+    depth = torch.softmax(torch.from_numpy(rng.standard_normal((cams, D, fh, fw)).astype(np.float32)), 1).numpy()
+    ctx = (rng.standard_normal((cams * fh * fw, c)) * 0.5).astype(np.float32)
+    want, ok = float64_reference(depth, ctx, coords, cams, D, fh, fw, B, Dz, H, W)
+    assert int(ok.sum()) == plan.n_kept() and 0.5 * geom.shape[0] < plan.n_kept() <= geom.shape[0]
+    got = plan.launch_fused(torch.from_numpy(depth).reshape(-1).to(dev), torch.from_numpy(ctx).to(dev), D, fh, fw)
+    err = float(np.max(np.abs(got.cpu().numpy() - want)))
+    assert err <= 1e-4, err
+    # the augmented rig crosses cells inside a column: more runs per column than the unaugmented test-time rig, still the column kernel
+    cols = plan.fused_columns(D, fh, fw, c, build=False)
+    assert cols is not None and cols.nruns / (cams * D * fw) > 1.0
+    # the API-level op on the materialised volume of one frame of that plan
+    feats = (rng.standard_normal((geom.shape[0], 8)) * 0.25).astype(np.float32)
+    planm = BevPoolPlan.from_geometry(gm.view(-1, 3), B, origin, dx, nx)
+    outm = planm.forward(torch.from_numpy(feats).to(dev)).cpu().numpy()
+    refm = oracle.bev_pool(feats[ok], coords[ok], B, Dz, H, W).transpose(0, 2, 3, 4, 1)
+    assert float(np.max(np.abs(outm - refm))) <= 1e-4
