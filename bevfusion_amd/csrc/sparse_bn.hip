@@ -88,7 +88,7 @@ __device__ __forceinline__ void slab_of(long long n, long long& lo, long long& h
 constexpr int GROUP = 32;
 constexpr int MAX_SLABS = 1024;
 constexpr int MAX_GROUPS = MAX_SLABS / GROUP;
-constexpr int BN_DEFAULT_SLABS = 512, BN_DEFAULT_UNROLL = 4;
+constexpr int BN_DEFAULT_SLABS = 256, BN_DEFAULT_UNROLL = 4;   // tools/time_bn.py, 20 layers at 4 frames: 192 slabs 0.42 / 1.21 ms (stats / backward), 256: 0.42 / 1.17, 512: 0.47 / 1.32
 // Round 6: one ticket per 128-byte line.  The tickets of all groups used to sit in consecutive words of ONE line, so the 512 arrivals
 // of a launch were 512 atomics on one L2 line, served one after another (~50 ns each): 25 us of a 55-us kernel, and the reason why
 // MORE slabs made the reductions slower (1024 slabs: 81 us, 256: 36 us for the same 54 MB; tools/time_bn.py).
@@ -421,7 +421,7 @@ static int check_shape(const char* who, long long n, int c, int dtype) {
   return BEVAMD_OK;
 }
 
-// tuning knobs of the two reducing kernels (round 6): BEVAMD_BN_SLABS = most workgroups (default 512, at most MAX_SLABS),
+// tuning knobs of the two reducing kernels (round 6): BEVAMD_BN_SLABS = most workgroups (default 256, at most MAX_SLABS),
 // BEVAMD_BN_UNROLL = rows a lane keeps in flight per trip (4 | 8)
 static int bn_max_slabs() {
   static int v = -1;
