@@ -277,7 +277,7 @@ def compact_line(res, side_file=None):
     per_rank = cfg.get("per_rank") or []
     ms = [r["ms_per_step"] for r in per_rank if isinstance(r, dict) and "ms_per_step" in r]
     out["config"] = {k: cfg[k] for k in ("workload", "frames_per_step", "frames_per_step_per_gpu", "rccl_ranks", "stage_ms", "overlap",
-                                         "inputs", "hip_graph", "gradient_allreduce", "plan_ms", "runs_per_column", "fused_kernel") if k in cfg}
+                                         "inputs", "hip_graph", "gradient_allreduce", "plan_ms", "runs_per_column", "fused_kernel", "encoder_path") if k in cfg}
     if ms:
         out["config"]["per_rank_ms_per_step"] = {"min": min(ms), "max": max(ms)}
     rf = res.get("roofline")
@@ -749,6 +749,9 @@ def train_step(args, rank, world, frame_ids, dev):
     model = wrap_for_gradient_allreduce(enc, world, dev)
     opt = torch.optim.AdamW(enc.parameters(), lr=2e-4, weight_decay=0.01)
     scaler = torch.amp.GradScaler("cuda", growth_interval=2000) if args.amp else None
+    # rows in key order (the voxelizer's default here) are in ascending linear index: the encoder trains on the inference kernels
+    # (spconv/fused_train.py; --voxel-order first or BEVAMD_SPCONV_FUSED_TRAIN=0: the module-by-module path)
+    coors_order = "linear" if args.voxel_order == "key" else None
     names = ["geometry+plan", "bev_pool_fwd", "bev_pool_bwd", "fused_pool_fwd", "fused_pool_bwd", "voxelize", "encoder_fwd", "encoder_bwd+allreduce",
              "clip+adamw"]
 
@@ -786,7 +789,7 @@ def train_step(args, rank, world, frame_ids, dev):
         mark(6)
         if scaler is not None:
             with torch.autocast("cuda", dtype=torch.float16):
-                y = model(vf, vc, B)
+                y = model(vf, vc, B, coors_order=coors_order)
             mark(7)
             scaler.scale(y.float().square().mean()).backward()
             mark(8)
@@ -795,7 +798,7 @@ def train_step(args, rank, world, frame_ids, dev):
             scaler.step(opt)
             scaler.update()
         else:
-            y = model(vf, vc, B)
+            y = model(vf, vc, B, coors_order=coors_order)
             mark(7)
             y.square().mean().backward()
             mark(8)
@@ -862,6 +865,7 @@ def train_step(args, rank, world, frame_ids, dev):
                                   "get_geometry + pooling plan + column plan rebuilt INSIDE every timed step (stage geometry+plan); point clouds "
                                   f"rotate through a pool of {n_pool}") if augmented else
                                  "static (round 5 protocol): one test-time calibration, plan built once outside the timed loop, the same clouds every step",
+                       "encoder_path": f"{enc.last_path}" + (f" ({enc.last_path_reason})" if enc.last_path_reason else ""),
                        "plan_ms": stage.get("geometry+plan"),
                        "runs_per_column": (float(np.mean(state["runs"])) if state["runs"] else None),
                        "fused_kernel": (max(set(state["kernel"]), key=state["kernel"].count) if state["kernel"] else "columns (static plan)"),

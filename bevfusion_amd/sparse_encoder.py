@@ -19,6 +19,7 @@ from . import spconv
 from .registry import register_everywhere
 from .sparse_block import SparseBasicBlock, make_sparse_convmodule
 from .spconv import fused as _fused
+from .spconv import fused_train as _fused_train
 
 _BLOCK_TYPES = ("conv_module", "basicblock")
 
@@ -45,7 +46,9 @@ class SparseEncoder(nn.Module):
         # eval-mode 16-bit forward runs on the sync-free fused path (spconv/fused.py); set False (or
         # BEVAMD_SPCONV_FUSED=0) to force the module-by-module path that mirrors the reference call for call
         self.fused_inference = os.environ.get("BEVAMD_SPCONV_FUSED", "1") != "0"
-        # which path the last forward() took: "fused" | "modules" (+ why, in `last_path_reason`); the module path makes one
+        # training-mode forward with 16-bit compute and rows in linear order runs on the same kernels (spconv/fused_train.py)
+        self.fused_training = os.environ.get("BEVAMD_SPCONV_FUSED_TRAIN", "1") != "0"
+        # which path the last forward() took: "fused" | "fused-train" | "modules" (+ why, in `last_path_reason`); the module path makes one
         # host sync per strided convolution and cannot be captured into a HIP graph, so a silent demotion is a perf cliff
         self.last_path = None
         self.last_path_reason = None
@@ -72,7 +75,21 @@ class SparseEncoder(nn.Module):
         coors_order = kwargs.get("coors_order")
         geometry = kwargs.get("geometry")      # fused.prepare_geometry(...) of these coordinates, built ahead of time
         reason = "fused_inference is off"
-        if self.fused_inference:
+        if self.training and torch.is_grad_enabled() and self.fused_training:
+            # training on the inference kernels (spconv/fused_train.py): 16-bit compute, rows promised in linear order
+            reason = _fused_train.unsupported_reason(self, voxel_features, coors_order, num_voxels)
+            if reason is None:
+                try:
+                    out = _fused_train.run_encoder(self, voxel_features, coors, int(batch_size), coors_order=coors_order)
+                    self.last_path, self.last_path_reason = "fused-train", None
+                    return out
+                except _fused.NotThisCall as e:
+                    reason = f"this call only: {e}"
+                except _fused.Unfusable as e:
+                    self.fused_training = False
+                    reason = f"encoder not fusable for training, fused training path disabled for this module: {e}"
+                    self._warn_once(reason)
+        elif self.fused_inference:
             reason = _fused.unsupported_reason(self, voxel_features)
             if reason is None:
                 try:
