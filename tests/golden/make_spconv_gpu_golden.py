@@ -11,7 +11,12 @@ Cases: the inputs of the five CPU goldens (spconv_ref_*.npz; everything stored) 
 one synthetic LiDAR sweep on 1440 x 1440 x 41: SubM 3x3x3 16->16 and the strided 3x3x3 / 2 / pad 1 16->32 convolution that leaves
 level 1.  The order of the pairs inside one kernel offset comes from atomicAdd slots in the reference (indice_cuda.cu): pairs are
 stored SORTED per offset (small cases) or as a SHA-256 of the sorted arrays (flagship); output rows of the flagship layers are
-stored for a seeded sample of rows plus a SHA-256 of the whole tensor."""
+stored for a seeded sample of rows plus a SHA-256 of the whole tensor.
+
+Round 6: three more flagship-grid cases, `flag_subm32 / 64 / 128` — SubM 3x3x3 C -> C over the
+SAME voxels with their rows in ascending linear index (b, x, y, z), the order the staged-rows (slab) kernels and the fused training
+path need — so that the kernels the time is spent in are pinned to `indice_conv_half` / `indice_conv_backward_half` on the GPU, not
+only to float64 and the reference's CPU functors.  A SubM output row IS its input row, so no row order is involved."""
 import hashlib
 import os
 import sys
@@ -68,7 +73,14 @@ def main(out_dir):
     ext = ref_build.load_ref("sparse_conv_ext")
     dev = torch.device("cuda:0")
     out = {}
+    # round 6: the fixture's existing entries are carried over untouched (`--regenerate` rebuilds them); only missing cases are run
+    have = os.path.join(GOLDEN, "spconv_gpu_ref.npz")
+    if os.path.exists(have) and "--regenerate" not in sys.argv:
+        with np.load(have) as z0:
+            out = {k: z0[k] for k in z0.files}
     for name in SMALL:
+        if f"{name}.out_indices" in out:
+            continue
         z = np.load(os.path.join(GOLDEN, f"spconv_ref_{name}.npz"))
         rng = np.random.default_rng(100)
         og = lambda m, z=z: (z["out_grad"] if z["out_grad"].shape[0] == m else None)
@@ -96,6 +108,9 @@ def main(out_dir):
     rng = np.random.default_rng(7)
     for tag, ks, st, pd, subm, cin, cout in (("flag_subm", (3, 3, 3), (1, 1, 1), (1, 1, 1), 1, 16, 16),
                                              ("flag_conv", (3, 3, 3), (2, 2, 2), (1, 1, 1), 0, 16, 32)):
+        if f"{tag}.out_indices" in out:
+            rng.standard_normal((indices.shape[0], cin)); rng.standard_normal(ks + (cin, cout))     # keep the stream where it was
+            continue
         feats = rng.standard_normal((indices.shape[0], cin)).astype(np.float16).astype(np.float32)     # fp16-representable
         w = (rng.standard_normal(ks + (cin, cout)) * 0.1).astype(np.float16).astype(np.float32)
         ogs = {}
@@ -119,10 +134,43 @@ def main(out_dir):
         out[f"{tag}.filter_grad_half"] = r["filter_grad_half"]
         print(tag, "N", indices.shape[0], "M", m, "pairs", int(r["indice_num"].sum()),
               "half vs fp32 max", float(np.abs(r["out_half"].astype(np.float32) - r["out_fp32"]).max()))
+    # ---- round 6: wide SubM layers over the same voxels in linear order
+    # (a full multi-sweep cloud at the inference cap: ~19 of 27 neighbours per row, like the bench's frames; the single sweep above
+    # has 3.5)
+    shape = cfg["sparse_shape"]
+    _, c2, _ = oracle.hard_voxelize(synth.lidar_points(seed=1), cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
+                                    cfg["max_voxels"][1])
+    xyz2 = c2 if c2[:, 0].max() >= 41 else c2[:, ::-1]
+    ind2 = np.concatenate([np.zeros((c2.shape[0], 1), np.int32), xyz2.astype(np.int32)], 1)
+    key = (ind2[:, 1].astype(np.int64) * shape[1] + ind2[:, 2]) * shape[2] + ind2[:, 3]
+    lin = np.ascontiguousarray(ind2[np.argsort(key, kind="stable")])
+    out["flaglin.num_voxels"] = np.int64(lin.shape[0])
+    out["flaglin.indices_sha256"] = sha(lin)
+    for C in (32, 64, 128):
+        tag = f"flag_subm{C}"
+        if f"{tag}.rows" in out:
+            continue
+        rng = np.random.default_rng(700 + C)
+        feats = (rng.standard_normal((lin.shape[0], C)) * 0.5).astype(np.float16).astype(np.float32)
+        w = (rng.standard_normal((3, 3, 3, C, C)) * (0.6 / np.sqrt(27 * C))).astype(np.float16).astype(np.float32)
+        ogv = (np.random.default_rng(900 + C).standard_normal((lin.shape[0], C)) * 0.5).astype(np.float16).astype(np.float32)
+        r = run_case(ext, dev, lin, 1, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1, feats, w, lambda m, ogv=ogv: ogv)
+        assert np.array_equal(r["out_indices"], lin)
+        rows = np.sort(np.random.default_rng(3).choice(lin.shape[0], size=512, replace=False))
+        out[f"{tag}.features_sha256"], out[f"{tag}.filters_sha256"], out[f"{tag}.out_grad_sha256"] = sha(feats), sha(w), sha(ogv)
+        out[f"{tag}.indice_num"] = r["indice_num"]
+        out[f"{tag}.rows"] = rows
+        out[f"{tag}.out_fp32_rows"], out[f"{tag}.out_half_rows"] = r["out_fp32"][rows], r["out_half"][rows]
+        out[f"{tag}.out_half_sha256"] = sha(r["out_half"])
+        out[f"{tag}.in_grad_half_rows"] = r["in_grad_half"][rows]
+        out[f"{tag}.filter_grad_half"] = r["filter_grad_half"]
+        print(tag, "N", lin.shape[0], "pairs", int(r["indice_num"].sum()), "half vs fp32 max",
+              float(np.abs(r["out_half"].astype(np.float32) - r["out_fp32"]).max()), "|out| max", float(np.abs(r["out_fp32"]).max()),
+              "|wgrad| max", float(np.abs(r["filter_grad_half"].astype(np.float32)).max()))
     path = os.path.join(out_dir, "spconv_gpu_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/golden")
+    main(sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "gpurun_out/golden")

@@ -1,2 +1,7 @@
-timeout 900 python -m pytest tests/test_gpu_fused_train.py -x -q 2>&1 | tail -30
-timeout 400 python bench.py --mode train-step --amp --no-cpu-baseline --train-inputs static > gpurun_out/v2_train_static.log 2>&1; grep "^{" gpurun_out/v2_train_static.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['encoder_path'], d['config']['stage_ms'])" || tail -20 gpurun_out/v2_train_static.log
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf gpurun_out/prof_v3
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_v3 -o b -- python $R/bench.py --mode train-step --amp --steps 5 --warmup 2 --no-cpu-baseline --train-inputs static > $R/gpurun_out/prof_v3_run.log 2>&1)
+python tools/rocprof_summary.py gpurun_out/prof_v3 > gpurun_out/v3_train_trace.txt 2>&1
+head -70 gpurun_out/v3_train_trace.txt | cut -c1-150
+find gpurun_out -name "*.db" -size +30M -delete
