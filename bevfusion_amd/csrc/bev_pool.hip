@@ -670,6 +670,14 @@ static int prepare_tail(PrepBuffers& pb, int n, BevDims s, uint32_t ncells, uint
 //          16 / 17 = XCD-striped walk, stripes of 2 groups, U4 / U8, batched tail;  18 / 19 = stripes of 1 group;
 //          + 100 * R on 16-19: the stripe -> XCD map moves on every R lines;  23 / 25 = 2 x 4 cell tiles, U8 / U4.
 //          (the striped and tiled walks cut the L2 -> fabric fetch counter by 3-7 % and are SLOWER: EXPERIMENTS C.7)
+// BEVAMD_BEV_POOL_LDS_PAD = bytes of (unused) dynamic LDS per 4-wave workgroup of the default kernel: an occupancy cap (160 KB per
+// CU / pad workgroups) for schedules in which the kernel shares the machine (round 6 experiment; 0 = none)
+static size_t lds_pad_bytes() {
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("BEVAMD_BEV_POOL_LDS_PAD"); v = e ? atol(e) : 0; v = v < 0 ? 0 : v > 160 * 1024 ? 160 * 1024 : v; }
+  return (size_t)v;
+}
+
 template <typename VecT, int VEC>
 static int launch_cells_vec(const void* x, const uint32_t* order, const uint32_t* cell_start, uint32_t ncells,
                             float* out, int lpr, int rpi, BevDims s, int variant, hipStream_t stream) {
@@ -692,7 +700,7 @@ static int launch_cells_vec(const void* x, const uint32_t* order, const uint32_t
   }
     case 14: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 4, 0, true><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
                  xv, order, cell_start, ncells, out, lpr, rpi, s); break;
-    case 15: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 8, 0, true><<<dim3(cdiv(ncells, 4)), dim3(256), 0, stream>>>(
+    case 15: bev_pool_fwd_cells_vec_kernel<VecT, VEC, 8, 0, true><<<dim3(cdiv(ncells, 4)), dim3(256), lds_pad_bytes(), stream>>>(
                  xv, order, cell_start, ncells, out, lpr, rpi, s); break;
 #ifdef BEVAMD_PROFILING   // measured slower than the plain walk and rejected (EXPERIMENTS C.7): kept for sweeps, not shipped
     case 16: BEVAMD_STRIPED(4, 2, true); break;
