@@ -94,6 +94,7 @@ _SIGNATURES = {
     "bevamd_spconv_tiled_supported": (I, [I, I, I]),
     "bevamd_spconv_filter_image_elems": (Z, [I, I, I, I]),
     "bevamd_spconv_make_filter_image": (I, [P, I, I, I, I, I, P, P]),
+    "bevamd_spconv_make_filter_images": (I, [I, P, P, P, P, P, P, I, P]),
     "bevamd_spconv_conv_forward_tiled": (I, [P, I, I, I, P, P, I, I, P, I, I, I, P, I, P, P, P, P, I, I, I, P]),
     "bevamd_spconv_f32x3_supported": (I, [I, I]),
     "bevamd_spconv_filter_image3_elems": (Z, [I, I, I, I]),

@@ -25,11 +25,83 @@ __global__ __launch_bounds__(256) void sp_pad_cast_rows_kernel(const float* __re
     dst[i] = tile::Num<DT>::from_f32(col < c ? src[row * c + col] : 0.f);
   }
 }
+
+// ---- filter images of MANY layers in one launch (round 6: the training path prepares the forward and the input-gradient image of
+// every convolution of a step from the fp32 master weights — 21 casts + 37 image launches + 16 flips before) -------------------
+// flags: 1 = transpose_io (input-gradient pass), 2 = mirror the kernel offsets (k -> K - 1 - k: the input gradient of a symmetric
+// SubM rulebook walks the SAME table with the mirrored transposed filter), 4 = the source is fp32 (else the image's 16-bit type)
+struct ImgDesc {
+  const void* w;
+  void* img;
+  int K, cin, cout, cinp, nt, nchunks, flags;
+};
+constexpr int IMG_BATCH = 48;
+struct ImgBatch {
+  ImgDesc d[IMG_BATCH];
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void sp_filter_images_batch_kernel(ImgBatch b) {
+  typedef typename tile::Num<DT>::T T;
+  const ImgDesc& d = b.d[blockIdx.y];
+  const size_t total = (size_t)d.nchunks * d.nt * 64 * 8;
+  const bool tr = d.flags & 1, mirror = d.flags & 2, f32 = d.flags & 4;
+  const int rows = tr ? d.cin : d.cout, cols = tr ? d.cout : d.cin;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const size_t t = i >> 9;
+    const int nt = (int)(t % d.nt);
+    const long long j = (long long)(t / d.nt);
+    const int c = lane & 15, g = lane >> 4;
+    const long long flat = j * 32 + g * 8 + e;
+    const int k = (int)(flat / d.cinp), ci = (int)(flat % d.cinp);
+    const int co = nt * 16 + c;
+    T v = tile::Num<DT>::from_f32(0.f);
+    if (k < d.K && ci < cols && co < rows) {
+      const int wi = tr ? co : ci, wo = tr ? ci : co;
+      const size_t at = ((size_t)(mirror ? d.K - 1 - k : k) * d.cin + wi) * d.cout + wo;
+      v = f32 ? tile::Num<DT>::from_f32(((const float*)d.w)[at]) : ((const T*)d.w)[at];
+    }
+    ((T*)d.img)[i] = v;
+  }
+}
 }  // namespace bevamd
 
 using namespace bevamd;
 
 extern "C" {
+
+/* Filter images (bevamd_spconv_make_filter_image's layout) of n <= 48 convolutions in ONE launch.  Per layer: filters[i]
+ * [K, cin, cout] (fp32 when flags[i] & 4, else `dtype`), image[i] of bevamd_spconv_filter_image_elems(K, cin, cout, flags & 1)
+ * elements of `dtype` (1 fp16 | 2 bf16); flags[i] & 1 = transpose_io, & 2 = kernel offsets mirrored (k -> K - 1 - k).
+ * No reference counterpart: the reference hands torch::mm the filter as it is (spconv_ops.h:322-334). */
+int bevamd_spconv_make_filter_images(int n, const void* const* filters, void* const* images, const int* kernel_volume, const int* cin,
+                                     const int* cout, const int* flags, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BEVAMD_REQUIRE(dtype == tile::T_F16 || dtype == tile::T_BF16, "spconv_make_filter_images: dtype %d is not 16-bit", dtype);
+  BEVAMD_REQUIRE(n >= 0 && n <= IMG_BATCH, "spconv_make_filter_images: %d layers (at most %d a call)", n, IMG_BATCH);
+  if (n == 0) return BEVAMD_OK;
+  BEVAMD_REQUIRE(filters && images && kernel_volume && cin && cout && flags, "spconv_make_filter_images: null array");
+  ImgBatch b;
+  size_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const int tr = flags[i] & 1;
+    const int rows = tr ? cin[i] : cout[i], cols = tr ? cout[i] : cin[i];
+    BEVAMD_REQUIRE(kernel_volume[i] > 0 && cin[i] > 0 && cout[i] > 0 && filters[i] && images[i], "spconv_make_filter_images: layer %d: bad sizes / null buffer", i);
+    const int cinp = tile::pad_cin(cols), nt = tile::pad_nt(rows);
+    BEVAMD_REQUIRE(cinp && nt, "spconv_make_filter_images: layer %d: channels %d -> %d exceed 128", i, cols, rows);
+    b.d[i].w = filters[i]; b.d[i].img = images[i];
+    b.d[i].K = kernel_volume[i]; b.d[i].cin = cin[i]; b.d[i].cout = cout[i];
+    b.d[i].cinp = cinp; b.d[i].nt = nt; b.d[i].nchunks = tile::image_chunks(kernel_volume[i], cinp); b.d[i].flags = flags[i];
+    const size_t total = tile::image_elems(kernel_volume[i], cinp, nt);
+    most = total > most ? total : most;
+  }
+  const unsigned gx = (unsigned)((most + 2047) / 2048 < 64 ? (most + 2047) / 2048 : 64);
+  if (dtype == tile::T_F16) sp_filter_images_batch_kernel<tile::T_F16><<<dim3(gx ? gx : 1, n), dim3(256), 0, stream>>>(b);
+  else sp_filter_images_batch_kernel<tile::T_BF16><<<dim3(gx ? gx : 1, n), dim3(256), 0, stream>>>(b);
+  BEVAMD_LAUNCH_CHECK("sp_filter_images_batch");
+  return BEVAMD_OK;
+}
 
 /* 1 if (dtype, cin -> cout) is served by the tiled kernels (16-bit features, channels <= 128) */
 int bevamd_spconv_tiled_supported(int dtype, int cin, int cout) {

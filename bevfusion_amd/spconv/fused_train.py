@@ -44,36 +44,105 @@ class _Lv:
 
 
 class _Plan:
-    """One forward pass: the levels, their products, the read-back."""
+    """One forward pass: the levels, their products, the read-back.
 
-    def __init__(self, enc, lv1, dtype):
+    Issue order (round 6, from the step timeline: level 1 of a training step is bound by the HOST's launch rate — the rulebook
+    launches cost ~40 us of Python each — so what the host issues first decides when the GPU starts):
+      1. level 1's forward products (sorted-key index, one metadata set) and the step's filter images;
+      2. the level-1 layers on the main stream — the GPU computes them while the host
+      3. issues the rest of the forward's chain (every downsample, table and metadata set of levels 2..5), when the walker reaches
+         the first strided layer;
+      4. the read-back (the chain has finished on the GPU by the time the host has issued it), then levels 2..5, GPU-bound;
+      5. what only the backward reads (filter-gradient metadata, the stem's level-1 table), behind the whole forward.
+    Products are allocated from the main stream's pool and written on the geometry stream without a fork in between
+    (fused.Level._fork): the top-of-pass fork orders the geometry stream behind every block freed BEFORE the pass, and the pass
+    itself frees nothing — every tensor it makes is saved for the backward.  (Allocating them under the geometry stream instead,
+    as fused._Chain does for inference, was measured: that pool sees new sizes every step when the row counts change, and the
+    allocator falls through to hipMalloc — encoder forward 3.9 -> 26 ms on augmented inputs.)"""
+
+    def __init__(self, enc, lv1, dtype, mods=()):
         self.enc = enc
         self.lv1 = lv1
         self.dtype = dtype
         self.pending = []      # _Lv whose count is still on the device
         self.gstream = lv1.level.gstream
+        self.mods = list(mods)
+        self.pos = {id(m): i for i, m in enumerate(self.mods)}
+        self.layers = []       # the _Layer of mods[:len(layers)], in execution order
+        self.cur = lv1         # level the next layer reads
+        self.images = {}       # id(conv) -> [forward image, input-gradient image | None]
+        self.late_issued = False
+
+    def _on_geometry_stream(self):
+        import contextlib
+
+        return torch.cuda.stream(self.gstream) if self.gstream is not None else contextlib.nullcontext()
+
+    def advance(self, upto):
+        """Create the layers mods[len(layers) .. upto] and issue what their forward reads."""
+        if len(self.layers) > upto:
+            return
+        old = fused._PREFETCHING[0]
+        fused._PREFETCHING[0] = True
+        try:
+            while len(self.layers) <= upto and len(self.layers) < len(self.mods):
+                m = self.mods[len(self.layers)]
+                if m.subm:
+                    L = _Layer(m, self, self.cur, self.cur)
+                    L.issue()
+                else:
+                    L = _Layer(m, self, self.cur, None)
+                    L.issue()
+                    nxt = _Lv(self.cur.level.downsample(m.kernel_size, m.stride, m.padding, wait=False, want_nbr=True)[0])
+                    self.pending.append(nxt)
+                    L.lv_out = nxt
+                    self.cur = nxt
+                L.image, L.image_t = self.images.get(id(m), (None, None))
+                self.layers.append(L)
+        finally:
+            fused._PREFETCHING[0] = old
+
+    def layer(self, conv):
+        i = self.pos[id(conv)]
+        if i >= len(self.layers):
+            self.advance(len(self.mods) - 1)      # the walker left level 1: everything else goes out now, in front of the read-back
+        return self.layers[i]
 
     def resolve(self):
-        """The step's ONE host sync: the row counts of every level a strided convolution produced, read on the geometry stream (the
-        whole chain was issued there up front; the main stream keeps computing level 1 meanwhile)."""
+        """The step's ONE host sync: the row counts of every level a strided convolution produced, read on the geometry stream."""
         if not self.pending:
             return
-        g = self.gstream
-        if g is not None:
-            with torch.cuda.stream(g):
-                host = torch.cat([lv.level.n_dev.reshape(1) for lv in self.pending]).cpu()
-        else:
+        with self._on_geometry_stream():
             host = torch.cat([lv.level.n_dev.reshape(1) for lv in self.pending]).cpu()
         for lv, v in zip(self.pending, host.tolist()):
             lv.n = int(v)
         self.pending = []
+
+    def issue_backward_products(self):
+        """What only the backward pass reads (filter-gradient metadata, the level-1 table of the stem's filter gradient)."""
+        if self.late_issued:
+            return
+        self.late_issued = True
+        old = fused._PREFETCHING[0]
+        fused._PREFETCHING[0] = True
+        try:
+            for L in self.layers:
+                L.issue(forward=False)
+        finally:
+            fused._PREFETCHING[0] = old
 
 
 class _Layer:
     """What one convolution of the pass reads: its module, the levels either side, the plan."""
 
     def __init__(self, conv, plan, lv_in, lv_out):
-        self.conv, self.plan, self.lv_in, self.lv_out = conv, plan, lv_in, lv_out
+        # no strong reference back to the plan (plan.layers holds this object): a plan <-> layer cycle would keep a whole step's
+        # activations and rulebooks alive until the cyclic collector runs — with the collector paused (bench.py's timed region) a
+        # 30-step run ended in allocator retries: forward 3.9 ms for 28 steps, then 18 and 62 ms
+        import weakref
+
+        self.conv, self._plan, self.lv_in, self.lv_out = conv, weakref.ref(plan), lv_in, lv_out
+        self.dtype = plan.dtype
         self.cin, self.cout = conv.in_channels, conv.out_channels
         self.K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
         lvl = lv_in.level
@@ -84,18 +153,24 @@ class _Layer:
             if lib.bevamd_spconv_wgrad_slab_supported(ops._DT[plan.dtype], self.cin, self.cout) and ops.slab_grid_ok(lvl.shape, 128):
                 self.wg_code = int(lib.bevamd_spconv_wgrad_slab_block_rows(self.cin))
         self.nbr_t = None
+        self.image = self.image_t = None     # forward / input-gradient filter images of this step (one batched launch: run_encoder)
 
     # ---- products (built on the geometry stream by issue(); these calls find them cached and wait for their events) ----
-    def issue(self):
+    def issue(self, forward=True):
+        """forward=True: what the forward pass reads (and the level below needs); False: what only the backward pass reads."""
         conv, lvl = self.conv, self.lv_in.level
         if conv.subm:
-            if self.variant is not None:
-                lvl.subm_slab(ops.slab_block_rows(self.cin, self.variant), wait=False)
-            if self.wg_code:
-                lvl.subm_slab(self.wg_code, wait=False)
-            if self.variant is None or not self.wg_code:
-                lvl.subm_neighbors(conv.kernel_size, wait=False)
-        else:
+            if forward:
+                if self.variant is not None:
+                    lvl.subm_slab(ops.slab_block_rows(self.cin, self.variant), wait=False)
+                else:
+                    lvl.subm_neighbors(conv.kernel_size, wait=False)
+            else:
+                if self.wg_code:
+                    lvl.subm_slab(self.wg_code, wait=False)
+                else:
+                    lvl.subm_neighbors(conv.kernel_size, wait=False)
+        elif forward:
             lvl.downsample(conv.kernel_size, conv.stride, conv.padding, wait=False, want_nbr=True)
 
     def table(self):
@@ -118,6 +193,23 @@ class _Layer:
         return self.nbr_t
 
 
+def prepare_images(plan, dev, stem_needs_grad=False):
+    """Forward and input-gradient filter images of every convolution of the pass (plan.mods, execution order; the first one is the
+    stem, whose input gradient nobody asks for unless `stem_needs_grad`) from their master weights, in one launch."""
+    specs, slots = [], []
+    for i, m in enumerate(plan.mods):
+        plan.images[id(m)] = [None, None]
+        specs.append((m.weight, False, False))
+        slots.append((id(m), 0))
+        if i > 0 or stem_needs_grad:
+            specs.append((m.weight, True, bool(m.subm)))
+            slots.append((id(m), 1))
+    for (key, j), img in zip(slots, ops.make_filter_images(specs, plan.dtype, dev)):
+        plan.images[key][j] = img
+    for L in plan.layers:
+        L.image, L.image_t = plan.images[id(L.conv)]
+
+
 def _rows_buffer(m, c, dtype, dev):
     full = torch.empty(((max(m, 1) + _PAD_ROWS - 1) // _PAD_ROWS * _PAD_ROWS, c), dtype=dtype, device=dev)
     return full[:m]
@@ -129,10 +221,9 @@ class _LevelConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, L):
-        conv, plan = L.conv, L.plan
+        conv, plan = L.conv, L._plan()
         lvl_in, lvl_out = L.lv_in.level, L.lv_out.level
-        w16 = weight.detach().to(plan.dtype)
-        image = ops.make_filter_image(w16)
+        image = L.image
         # the launch is bounded by the level's capacity and guarded by its device-side count, like the inference path; the buffer
         # holds the exact rows once they are known (a strided layer learns them right behind its own launch)
         if conv.subm:
@@ -152,14 +243,14 @@ class _LevelConv(torch.autograd.Function):
             ops.sparse_conv_tiled(x, image, nbr, m, L.K, L.cin, L.cout, out=out,
                                   variant=fused._variant_for(fused._frames_equivalent(lvl_in), L.K, L.cin, L.cout))
         ctx.L = L
-        ctx.save_for_backward(x, w16)
+        ctx.save_for_backward(x)
         return out
 
     @staticmethod
     def backward(ctx, grad):
         L = ctx.L
-        conv, plan = L.conv, L.plan
-        x, w16 = ctx.saved_tensors
+        conv, plan = L.conv, L            # (the layer carries the compute dtype; the plan may be gone by now)
+        x, = ctx.saved_tensors
         lvl_in = L.lv_in.level
         n_in, m = L.lv_in.n, L.lv_out.n
         g = grad if grad.dtype == plan.dtype else grad.to(plan.dtype)
@@ -169,16 +260,14 @@ class _LevelConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if conv.subm and L.variant is not None and L.cin == L.cout:
                 # the mirrored, transposed filter over the same metadata (module docstring)
-                image_t = ops.make_filter_image(w16.flip(0, 1, 2), transpose_io=True)
                 meta = lvl_in.subm_slab(ops.slab_block_rows(L.cin, L.variant))
                 dx = _rows_buffer(n_in, x.shape[1], plan.dtype, x.device)
-                ops.sparse_conv_slab(g, image_t, meta, lvl_in.n_cap, L.cout, L.cin, num_out_dev=lvl_in.n_dev, out=dx, variant=L.variant)
-            elif conv.subm:
-                dx = ops.sparse_conv(g, w16, L.table().flip(0).contiguous(), n_in, transpose_io=True)
+                ops.sparse_conv_slab(g, L.image_t, meta, lvl_in.n_cap, L.cout, L.cin, num_out_dev=lvl_in.n_dev, out=dx, variant=L.variant)
             else:
-                dx = ops.sparse_conv(g, w16, L.table_t(), n_in, transpose_io=True)
-            if dx.shape[1] != x.shape[1]:
-                dx = torch.nn.functional.pad(dx, (0, x.shape[1] - dx.shape[1]))
+                # the same mirrored image over the layer's own table (SubM), the transposed image over the transposed table (strided)
+                dx = _rows_buffer(n_in, x.shape[1], plan.dtype, x.device)
+                ops.sparse_conv_tiled(g, L.image_t, L.table() if conv.subm else L.table_t(), n_in, L.K, L.cout, L.cin, out=dx)
+            # (columns past cin — the stem's zero padding — are not written: the padding's own backward drops them)
         dw = None
         if ctx.needs_input_grad[1]:
             if L.wg_code and x.stride(0) % 8 == 0:
@@ -209,8 +298,8 @@ def _check_conv_bn(conv, bn, dtype):
     if not isinstance(conv, SparseConvolution) or conv.conv1x1 or conv.transposed or conv.inverse or conv.ndim != 3 \
             or any(d != 1 for d in conv.dilation) or conv.bias is not None or (conv.subm and any(k % 2 == 0 for k in conv.kernel_size)):
         raise fused.Unfusable("convolution flavour not handled by the fused training path")
-    if not ops.tiled_supported(dtype, conv.in_channels, conv.out_channels):
-        raise fused.Unfusable(f"no tiled kernel for {conv.in_channels}->{conv.out_channels}")
+    if not ops.tiled_supported(dtype, conv.in_channels, conv.out_channels) or not ops.tiled_supported(dtype, conv.out_channels, conv.in_channels):
+        raise fused.Unfusable(f"no tiled kernel for {conv.in_channels}->{conv.out_channels} (or its input gradient)")
     c = conv.out_channels
     ok = (type(bn) is nn.BatchNorm1d and bn.training and bn.momentum is not None and bn.track_running_stats and bn.num_features == c
           and c % 8 == 0 and c <= 256 and 256 % (c // 8) == 0
@@ -220,12 +309,13 @@ def _check_conv_bn(conv, bn, dtype):
 
 
 def _conv_bn(conv, bn, relu, x, lv, plan, layers, residual=None):
-    L = layers.get(id(conv)) if layers is not None else None
-    if L is None:                        # the validation walk
+    if layers is None:                   # the validation walk (plan = the compute dtype)
         _check_conv_bn(conv, bn, plan)
         return x, (lv if conv.subm else object())
+    L = plan.layer(conv)
     z = _LevelConv.apply(x, conv.weight, L)
-    y = native_bn.bn_act(z, bn, relu=relu, residual=residual)
+    # (num_batches_tracked of every layer was advanced by ONE launch at the top of the pass: run_encoder)
+    y, _, _ = native_bn._BnAct.apply(z, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
     return y, L.lv_out
 
 
@@ -341,32 +431,19 @@ def run_encoder(enc, voxel_features, coors, batch_size, coors_order="linear"):
         g.wait_stream(main)
     lvl1 = fused.Level(coors, n, None, int(batch_size), enc.sparse_shape, gstream=g, linear_order=True, status_pool=pool)
     lvl1.frames_hint = n / float(fused._ROWS_PER_FLAGSHIP_FRAME)
-    plan = _Plan(enc, _Lv(lvl1, n), dtype)
+    mods = fused._chain_modules(enc)
+    plan = _Plan(enc, _Lv(lvl1, n), dtype, mods)
+    layers = True          # (the walkers' "this is not the validation walk" flag)
     try:
-        # ---- the whole rulebook chain, up front, on the geometry stream
-        layers = {}
-        order = []
-        cur = plan.lv1
-        fused._PREFETCHING[0] = True
-        try:
-            for m in fused._chain_modules(enc):
-                if m.subm:
-                    L = _Layer(m, plan, cur, cur)
-                    L.issue()
-                else:
-                    L0 = _Layer(m, plan, cur, None)
-                    L0.issue()
-                    nxt = _Lv(cur.level.downsample(m.kernel_size, m.stride, m.padding, wait=False, want_nbr=True)[0])
-                    plan.pending.append(nxt)
-                    L0.lv_out = nxt
-                    L, cur = L0, nxt
-                layers[id(m)] = L
-                order.append(L)
-        finally:
-            fused._PREFETCHING[0] = False
+        strided = [i for i, m in enumerate(mods) if not m.subm]
+        plan.advance((strided[0] if strided else len(mods)) - 1)          # level 1's forward products
+        prepare_images(plan, dev, stem_needs_grad=voxel_features.requires_grad)
         # the device-side status words of the chain (fused._first_call_check), read BEFORE the feature pass on the first call of an
-        # encoder (BEVAMD_SPCONV_CHECK=1: every call) — the kernels would stay inside their buffers either way, on a wrong rulebook
+        # encoder (BEVAMD_SPCONV_CHECK=1: every call) — the kernels would stay inside their buffers either way, on a wrong rulebook.
+        # A checked pass builds everything first.
         if fused._CHECK or not enc.__dict__.get("_bevamd_train_geometry_checked"):
+            plan.advance(len(mods) - 1)
+            plan.issue_backward_products()
             if g is not None:
                 g.synchronize()
             bits = fused.geometry_status(lvl1)
@@ -375,10 +452,14 @@ def run_encoder(enc, voxel_features, coors, batch_size, coors_order="linear"):
                                         "coors_order='linear' are not in ascending linear index)")
             enc.__dict__["_bevamd_train_geometry_checked"] = True
         # ---- the feature pass
+        counters = [b for b in (getattr(m, "num_batches_tracked", None) for m in enc.modules() if type(m) is nn.BatchNorm1d) if b is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)
         x, lv = _sequential(enc.conv_input, feats, plan.lv1, plan, layers)
         x, lv = _sequential(enc.encoder_layers, x, lv, plan, layers)
         x, lv = _sequential(enc.conv_out, x, lv, plan, layers)
         out = _DenseBev.apply(x, lv)
+        plan.issue_backward_products()
     finally:
         if g is not None:
             main.wait_stream(g)

@@ -300,6 +300,47 @@ def make_filter_image(filters, transpose_io=False):
     return img
 
 
+def make_filter_images(specs, dtype, device):
+    """Filter images of many convolutions in ONE launch (bevamd_spconv_make_filter_images).  specs: list of (filters
+    [kx,ky,kz,Cin,Cout] fp32 or `dtype`, transpose_io, mirror) -> list of image tensors (views of one buffer).  `mirror` reverses the
+    kernel offsets (k -> K - 1 - k): with transpose_io it is the filter the input gradient of a symmetric SubM layer runs over the
+    layer's own table."""
+    import ctypes
+
+    lib = _capi.load()
+    out = []
+    for lo in range(0, len(specs), 48):
+        part = specs[lo:lo + 48]
+        n = len(part)
+        Ks, cins, couts, flags, elems, srcs = [], [], [], [], [], []
+        for f, tr, mirror in part:
+            f = f.detach()
+            if not f.is_contiguous():
+                f = f.contiguous()
+            if f.dtype not in (torch.float32, dtype):
+                f = f.to(dtype)
+            cin, cout = f.shape[-2], f.shape[-1]
+            K = f.numel() // (cin * cout)
+            e = int(lib.bevamd_spconv_filter_image_elems(K, cin, cout, int(bool(tr))))
+            if e == 0:
+                raise RuntimeError(f"no tiled kernel for {cin} -> {cout} channels")
+            Ks.append(K); cins.append(cin); couts.append(cout); elems.append((e + 127) // 128 * 128); srcs.append(f)
+            flags.append(int(bool(tr)) | (2 if mirror else 0) | (4 if f.dtype == torch.float32 else 0))
+        buf = torch.empty(sum(elems), dtype=dtype, device=device)
+        imgs, at = [], 0
+        for e in elems:
+            imgs.append(buf[at:at + e])
+            at += e
+        VP = ctypes.c_void_p * n
+        with torch.cuda.device(device):
+            rc = lib.bevamd_spconv_make_filter_images(n, VP(*[f.data_ptr() for f in srcs]), VP(*[i.data_ptr() for i in imgs]), _capi.ints(Ks),
+                                                      _capi.ints(cins), _capi.ints(couts), _capi.ints(flags), _DT[dtype],
+                                                      _capi.stream_ptr(device))
+        _capi.check(rc, "spconv_make_filter_images")
+        out.extend(imgs)
+    return out
+
+
 def sparse_conv_tiled(features, image, nbr, num_out, kernel_volume, cin, cout, bias=None, bn_scale=None, bn_shift=None,
                       residual=None, relu=False, num_out_dev=None, out=None, variant=0):
     """One fused launch: out[o] = relu?(bn_scale * (sum_k features[nbr[k, o]] @ W[k] + bias) + bn_shift + residual[o]).

@@ -507,6 +507,13 @@ int bevamd_spconv_tiled_supported(int dtype, int cin, int cout);
 size_t bevamd_spconv_filter_image_elems(int kernel_volume, int cin, int cout, int transpose_io);
 int bevamd_spconv_make_filter_image(const void* filters, int dtype, int kernel_volume, int cin, int cout,
                                     int transpose_io, void* image, void* stream);
+/* Filter images of n <= 48 convolutions in ONE launch (the training path: forward and input-gradient images of every layer of a
+ * step, straight from the fp32 master weights).  filters[i] [K, cin, cout] (fp32 when flags[i] & 4, else `dtype`); images[i] of
+ * bevamd_spconv_filter_image_elems(K, cin, cout, flags[i] & 1) elements of `dtype`; flags[i] & 1 = transpose_io, & 2 = kernel
+ * offsets mirrored (k -> K - 1 - k: the input gradient of a symmetric SubM rulebook walks the same table with the mirrored
+ * transposed filter).  No reference counterpart (spconv_ops.h:322-334 hands torch::mm the filter as it is). */
+int bevamd_spconv_make_filter_images(int n, const void* const* filters, void* const* images, const int* kernel_volume, const int* cin,
+                                     const int* cout, const int* flags, int dtype, void* stream);
 int bevamd_spconv_conv_forward_tiled(const void* features, int dtype, int feat_stride, int num_in,
                                      const void* image, const int* nbr, int nbr_stride, int num_out,
                                      const int* num_out_dev, int kernel_volume, int cin, int cout, void* out,

@@ -50,10 +50,12 @@ def test_subm_layer_forward_and_both_gradients_match_the_gather_kernels(dev, vox
     conv = spconv_conv.SubMConv3d(c, c, 3, padding=1, bias=False, indice_key="t").to(dev)
     lvl = fused.Level(coors, n, None, 2, shape, linear_order=True)
     lvl.frames_hint = n / 160000.0
-    plan = fused_train._Plan(None, fused_train._Lv(lvl, n), torch.float16)
+    plan = fused_train._Plan(None, fused_train._Lv(lvl, n), torch.float16, [conv])
     L = fused_train._Layer(conv, plan, plan.lv1, plan.lv1)
     assert L.variant is not None and L.wg_code, (L.variant, L.wg_code)      # the slab kernels are what runs
     L.issue()
+    plan.layers.append(L)
+    fused_train.prepare_images(plan, dev, stem_needs_grad=True)
     xr = x.clone().requires_grad_(True)
     y = fused_train._LevelConv.apply(xr, conv.weight, L)
     y.backward(gy)
@@ -79,9 +81,11 @@ def test_strided_layer_forward_and_both_gradients_match_the_module_kernels(dev, 
     conv = spconv_conv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key="d").to(dev)
     lvl = fused.Level(coors, n, None, 2, shape, linear_order=True)
     lvl.frames_hint = n / 160000.0
-    plan = fused_train._Plan(None, fused_train._Lv(lvl, n), torch.float16)
+    plan = fused_train._Plan(None, fused_train._Lv(lvl, n), torch.float16, [conv])
     L = fused_train._Layer(conv, plan, plan.lv1, None)
     L.issue()
+    plan.layers.append(L)
+    fused_train.prepare_images(plan, dev, stem_needs_grad=True)
     L.lv_out = fused_train._Lv(lvl.downsample(conv.kernel_size, conv.stride, conv.padding, wait=False, want_nbr=True)[0])
     plan.pending.append(L.lv_out)
     xr = x.clone().requires_grad_(True)
@@ -156,3 +160,34 @@ def test_fallbacks_leave_the_batchnorm_buffers_alone(dev, voxels):
     assert enc.last_path == "modules" and "status" in enc.last_path_reason
     nb = {k: int(b) for k, b in enc.named_buffers() if k.endswith("num_batches_tracked")}
     assert set(nb.values()) == {1}                              # every BatchNorm saw exactly one batch
+
+
+def test_a_step_leaves_no_cyclic_garbage_behind(dev, voxels):
+    """A training step's activations and rulebooks are released by reference counting alone (no plan <-> layer cycle): with Python's
+    cyclic collector paused — bench.py's timed region, or simply a long gap between collections — device memory returns to where it
+    was once the step's outputs and gradients are dropped."""
+    import gc
+
+    vf, vc = voxels
+    enc = _flagship(dev)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = enc(vf, vc, 2, coors_order="linear")
+        assert enc.last_path == "fused-train"
+        (y.float().square().sum() * 1e-3).backward()
+        enc.zero_grad(set_to_none=True)
+
+    step()                      # caches (BatchNorm workspaces, status pool, tree check) are filled
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    gc.disable()
+    try:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert grown <= 8 << 20, grown

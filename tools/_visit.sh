@@ -1,2 +1,12 @@
-timeout 900 python -m pytest tests/test_gpu_fused_columns.py -x -q 2>&1 | tail -3
-timeout 400 python bench.py --mode train-step --amp --no-cpu-baseline > gpurun_out/v4_train_aug.log 2>&1; grep "^{" gpurun_out/v4_train_aug.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['encoder_path'], d['config']['stage_ms'])" || tail -20 gpurun_out/v4_train_aug.log
+timeout 900 python -m pytest tests/test_gpu_fused_train.py -x -q 2>&1 | tail -3
+timeout 400 python bench.py --mode train-step --amp --no-cpu-baseline > gpurun_out/v10_train.log 2>&1; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_last_full.json'))
+print(d['ms_per_step'], d['config']['stage_ms'])
+print('fwd per step', d['config']['encoder_fwd_per_step_ms'][-6:])
+PY
+timeout 400 python bench.py --mode train-step --amp --no-cpu-baseline --train-inputs static > gpurun_out/v10_train.log 2>&1; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_last_full.json'))
+print(d['ms_per_step'], d['config']['stage_ms'])
+PY
