@@ -100,3 +100,40 @@ def test_sparse_encoder_under_ddp_matches_unwrapped(dev, rccl_world):
         assert torch.equal(p.grad, q.grad), name          # deterministic kernels + a one-rank average
         n += 1
     assert n >= 60 and enc.last_path == "modules"
+
+
+def test_fused_training_path_under_ddp_matches_unwrapped(dev, rccl_world):
+    """The fused training path (spconv/fused_train.py: autocast, rows promised in linear order) under DistributedDataParallel over
+    RCCL: one convolution node and one BatchNorm node per layer, so DDP's hooks fire per parameter as the backward proceeds; the
+    gradients equal the unwrapped encoder's bit for bit (deterministic kernels + a one-rank average)."""
+    from bevfusion_amd import synth
+    from bevfusion_amd.voxel import voxelize_batch
+
+    cfg = synth.CL_CONFIG
+    pts = [torch.from_numpy(synth.lidar_points(seed=31 + b, sweeps=2)).to(dev) for b in range(2)]
+    vf, vc, _ = voxelize_batch(pts, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"], cfg["max_voxels"][0], order="key")
+
+    def make():
+        torch.manual_seed(1)
+        return SparseEncoder(5, list(cfg["sparse_shape"]), order=["conv", "norm", "act"], output_channels=128,
+                             encoder_channels=[[16, 16, 32], [32, 32, 64], [64, 64, 128], [128, 128]],
+                             encoder_paddings=[[0, 0, 1], [0, 0, 1], [0, 0, [1, 1, 0]], [0, 0]], block_type="basicblock").to(dev).train()
+
+    ref, enc = make(), make()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = ref(vf, vc, 2, coors_order="linear")
+    (y.float().square().sum() * 1e-3).backward()
+    assert ref.last_path == "fused-train", ref.last_path_reason
+    ddp = torch.nn.parallel.DistributedDataParallel(enc, device_ids=[dev.index])
+    with torch.autocast("cuda", dtype=torch.float16):
+        y2 = ddp(vf, vc, 2, coors_order="linear")
+    (y2.float().square().sum() * 1e-3).backward()
+    torch.cuda.synchronize()
+    assert enc.last_path == "fused-train", enc.last_path_reason
+    assert torch.equal(y, y2)
+    n = 0
+    for (name, p), (_, q) in zip(ref.named_parameters(), enc.named_parameters()):
+        assert p.grad is not None and q.grad is not None and torch.isfinite(q.grad).all(), name
+        assert torch.equal(p.grad, q.grad), name
+        n += 1
+    assert n >= 60

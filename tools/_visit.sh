@@ -1,12 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_fused_train.py -x -q 2>&1 | tail -3
-timeout 400 python bench.py --mode train-step --amp --no-cpu-baseline > gpurun_out/v10_train.log 2>&1; python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_last_full.json'))
-print(d['ms_per_step'], d['config']['stage_ms'])
-print('fwd per step', d['config']['encoder_fwd_per_step_ms'][-6:])
-PY
-timeout 400 python bench.py --mode train-step --amp --no-cpu-baseline --train-inputs static > gpurun_out/v10_train.log 2>&1; python - <<'PY'
-import json
-d=json.load(open('gpurun_out/bench_last_full.json'))
-print(d['ms_per_step'], d['config']['stage_ms'])
-PY
+for i in 1 2; do
+BEVAMD_LIB=bevfusion_amd/lib/exp/noskip.so python tools/time_slab_variant.py 16:3000256 2>&1 | grep "16->16"
+python tools/time_slab_variant.py 16:3000256 2>&1 | grep "16->16"
+done
+timeout 900 python -m pytest tests/test_gpu_spconv_slab.py tests/test_gpu_keyorder.py -x -q 2>&1 | tail -3
