@@ -958,7 +958,7 @@ int bevamd_spconv_conv_wgrad_slab(const void* features, int feat_stride, int num
   hipStream_t stream = (hipStream_t)stream_;
   wgslab::Shape sh;
   BEVAMD_REQUIRE(dtype == DT_F16 || dtype == DT_BF16, "spconv_conv_wgrad_slab: dtype %d is not 16-bit", dtype);
-  BEVAMD_REQUIRE(wgslab::shape_for(cin, cout, sh), "spconv_conv_wgrad_slab: %d -> %d channels (cin == cout in 16 | 32 | 64 | 128)", cin, cout);
+  BEVAMD_REQUIRE(wgslab::shape_for(cin, cout, sh), "spconv_conv_wgrad_slab: %d -> %d channels (cin in 16 | 32 | 64 | 128, cout == cin, or 2 cin up to 128)", cin, cout);
   BEVAMD_REQUIRE(block_rows == bevamd_spconv_wgrad_slab_block_rows(cin),
                  "spconv_conv_wgrad_slab: metadata code %d, %d channels want %d (bevamd_spconv_wgrad_slab_block_rows)", block_rows, cin,
                  bevamd_spconv_wgrad_slab_block_rows(cin));

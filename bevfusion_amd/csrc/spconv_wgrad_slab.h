@@ -315,10 +315,11 @@ __global__ __launch_bounds__(NW * 64, 1) void spconv_wgrad_slab_kernel(Args a) {
     auto wait_frags = [&](auto n_, s16x8 (&x)[CIT], s16x8 (&b)[COT]) {
       constexpr int N = decltype(n_)::value;
       if constexpr (CIT == 1 && COT == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x[0]), "+v"(b[0]) : "n"(N));
+      else if constexpr (CIT == 1 && COT == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(x[0]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
       else if constexpr (CIT == 2 && COT == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
       else asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(x[0]), "+v"(x[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
     };
-    static_assert((CIT == 1 && COT == 1) || (CIT == 2 && (COT == 2 || COT == 4)), "wait_frags lists the fragments of these shapes");
+    static_assert((CIT == 1 && (COT == 1 || COT == 2)) || (CIT == 2 && (COT == 2 || COT == 4)), "wait_frags lists the fragments of these shapes");
     auto mma = [&](int kk, const s16x8 (&x)[CIT], const s16x8 (&b)[COT]) {
 #pragma unroll
       for (int ta = 0; ta < CIT; ++ta)
@@ -498,9 +499,11 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 struct Shape { int cit, cot, nci, nco, cinp, coutp; };
-// cin == cout in {16, 32, 64, 128}: a workgroup owns at most 32 input x 64 output channels (128 accumulator registers per lane)
+// cin == cout in {16, 32, 64, 128}, or cout == 2 cin for cin in {16, 32, 64} (round 6: the strided 3x3x3 layers, whose metadata has the
+// same form): a workgroup owns at most 32 input x 64 output channels (128 accumulator registers per lane)
 static inline bool shape_for(int cin, int cout, Shape& s) {
-  if (cin != cout || (cin != 16 && cin != 32 && cin != 64 && cin != 128)) return false;
+  const bool widths = cin == 16 || cin == 32 || cin == 64 || cin == 128;
+  if (!widths || !(cout == cin || (cout == 2 * cin && cin <= 64))) return false;
   s.cit = cin >= 32 ? 2 : 1;
   s.cot = cout >= 64 ? 4 : cout / 16;
   s.nci = cin / (s.cit * 16);
@@ -542,6 +545,7 @@ static int launch_one(const Args& a, hipStream_t stream) {
 template <bool F16>
 static int launch(const Args& a, const Shape& s, hipStream_t stream) {
   if (s.cit == 1 && s.cot == 1) return launch_one<F16, 1, 1, 256>(a, stream);
+  if (s.cit == 1 && s.cot == 2) return launch_one<F16, 1, 2, 256>(a, stream);
   if (s.cit == 2 && s.cot == 2) return launch_one<F16, 2, 2, 192>(a, stream);
   if (s.cit == 2 && s.cot == 4) return launch_one<F16, 2, 4, 192>(a, stream);
   set_error("spconv_conv_wgrad_slab: no kernel for %d x %d tiles", s.cit, s.cot);

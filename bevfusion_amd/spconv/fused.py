@@ -262,6 +262,20 @@ class Level:
             self._await(ev)
         return meta
 
+    def down_slab_from_table(self, ksize, stride, padding, block_rows, wait=True):
+        """Slab metadata of the strided 3x3x3 convolution from its int32 neighbour table (ops.slab_build) — what the staged-rows
+        filter gradient of a training step reads (spconv/fused_train.py; a layer that trains keeps its table anyway)."""
+        key = (tuple(ksize), tuple(stride), tuple(padding), block_rows, "table")
+        if key not in self._down_slab:
+            out, nbr = self.downsample(ksize, stride, padding, wait=False, want_nbr=True)
+            self._fork()
+            meta = ops.slab_build(nbr, out.n_cap, out.n_dev, block_rows, stream_ptr=self._stream_ptr(), status=self._status())
+            self._down_slab[key] = (meta, self._mark())
+        meta, ev = self._down_slab[key]
+        if wait:
+            self._await(ev)
+        return meta
+
     def downsample(self, ksize, stride, padding, wait=True, want_nbr=True):
         """(output Level with its rank index, nbr [K, cap_out]) of a strided convolution over this set.  want_nbr=False (the
         convolution reads slab metadata instead): the int32 neighbour table is not built, nbr is None — a later call that

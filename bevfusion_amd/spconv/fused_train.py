@@ -147,10 +147,22 @@ class _Layer:
         self.K = conv.kernel_size[0] * conv.kernel_size[1] * conv.kernel_size[2]
         lvl = lv_in.level
         self.variant = fused._slab_variant_for(conv, lvl, self.cin, self.cout) if conv.subm else None
+        # staged-rows filter gradient: cin == cout layers as they are; the stem (cin 5 -> 16) with its rows zero-padded to cout
+        # channels (round 6: its gather-kernel filter gradient took 172 + 49 us and wanted a hash index + an int32 table of level 1
+        # that nothing else reads; padded to 16 -> 16 it is the 23-us kernel of the other level-1 layers, the extra rows of dW dropped)
         self.wg_code = 0
-        if conv.subm and self.cin == self.cout and lvl.linear_order and tuple(conv.kernel_size) == (3, 3, 3) and lvl.allow_slab:
+        self.wg_cin = self.cin
+        if conv.subm and lvl.linear_order and tuple(conv.kernel_size) == (3, 3, 3) and lvl.allow_slab \
+                and (self.cin == self.cout or (self.cin < self.cout and self.cout == 16)):
             lib = _capi.load()
-            if lib.bevamd_spconv_wgrad_slab_supported(ops._DT[plan.dtype], self.cin, self.cout) and ops.slab_grid_ok(lvl.shape, 128):
+            if lib.bevamd_spconv_wgrad_slab_supported(ops._DT[plan.dtype], self.cout, self.cout) and ops.slab_grid_ok(lvl.shape, 128):
+                self.wg_code = int(lib.bevamd_spconv_wgrad_slab_block_rows(self.cout))
+                self.wg_cin = self.cout
+        elif (not conv.subm) and self.K == 27 and tuple(conv.kernel_size) == (3, 3, 3) and lvl.linear_order and lvl.allow_slab \
+                and os.environ.get("BEVAMD_SPCONV_WGRAD_SLAB_STRIDED", "1") != "0":
+            # the strided 3x3x3 layers (16 -> 32, 32 -> 64, 64 -> 128): the same kernel over metadata built from the layer's table
+            lib = _capi.load()
+            if lib.bevamd_spconv_wgrad_slab_supported(ops._DT[plan.dtype], self.cin, self.cout):
                 self.wg_code = int(lib.bevamd_spconv_wgrad_slab_block_rows(self.cin))
         self.nbr_t = None
         self.image = self.image_t = None     # forward / input-gradient filter images of this step (one batched launch: run_encoder)
@@ -172,6 +184,8 @@ class _Layer:
                     lvl.subm_neighbors(conv.kernel_size, wait=False)
         elif forward:
             lvl.downsample(conv.kernel_size, conv.stride, conv.padding, wait=False, want_nbr=True)
+        elif self.wg_code:
+            lvl.down_slab_from_table(conv.kernel_size, conv.stride, conv.padding, self.wg_code, wait=False)
 
     def table(self):
         conv, lvl = self.conv, self.lv_in.level
@@ -271,8 +285,12 @@ class _LevelConv(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if L.wg_code and x.stride(0) % 8 == 0:
-                meta = lvl_in.subm_slab(L.wg_code)
-                dw = ops.sparse_conv_wgrad_slab(x, g, meta, L.cin, L.cout)
+                meta = lvl_in.subm_slab(L.wg_code) if conv.subm else \
+                    lvl_in.down_slab_from_table(conv.kernel_size, conv.stride, conv.padding, L.wg_code)
+                xw = x if x.shape[1] >= L.wg_cin else torch.nn.functional.pad(x, (0, L.wg_cin - x.shape[1]))
+                dw = ops.sparse_conv_wgrad_slab(xw, g, meta, L.wg_cin, L.cout)
+                if L.wg_cin != L.cin:
+                    dw = dw[:, :L.cin, :].contiguous()
             else:
                 lib = _capi.load()
                 xs = x if x.shape[1] == L.cin and x.is_contiguous() else x[:, :L.cin].contiguous()

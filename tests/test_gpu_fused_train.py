@@ -70,19 +70,22 @@ def test_subm_layer_forward_and_both_gradients_match_the_gather_kernels(dev, vox
     assert conv.weight.grad.dtype == torch.float32 and _rel(conv.weight.grad, dw_ref) <= 4e-3
 
 
-def test_strided_layer_forward_and_both_gradients_match_the_module_kernels(dev, voxels):
-    """16 -> 32, 3x3x3 stride 2 over level 1: output set (row order included), forward, input gradient over the transposed table,
-    filter gradient — against build_rulebook + sparse_conv / sparse_conv_backward."""
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64), (64, 128)])
+def test_strided_layer_forward_and_both_gradients_match_the_module_kernels(dev, voxels, cin, cout):
+    """cin -> 2 cin, 3x3x3 stride 2 over level 1: output set (row order included), forward, input gradient over the transposed table,
+    filter gradient on the staged-rows kernel (metadata from the layer's table; the wider layers' ranges exceed a stage and take
+    the piece-by-piece path) — against build_rulebook + sparse_conv / sparse_conv_backward."""
     _, coors = voxels
     n = coors.shape[0]
     shape = list(synth.CL_CONFIG["sparse_shape"])
     g = torch.Generator(device=dev).manual_seed(5)
-    x = (torch.randn((n, 16), generator=g, device=dev) * 0.5).half()
-    conv = spconv_conv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False, indice_key="d").to(dev)
+    x = (torch.randn((n, cin), generator=g, device=dev) * 0.5).half()
+    conv = spconv_conv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False, indice_key="d").to(dev)
     lvl = fused.Level(coors, n, None, 2, shape, linear_order=True)
     lvl.frames_hint = n / 160000.0
     plan = fused_train._Plan(None, fused_train._Lv(lvl, n), torch.float16, [conv])
     L = fused_train._Layer(conv, plan, plan.lv1, None)
+    assert L.wg_code, "the staged-rows filter gradient serves this layer"
     L.issue()
     plan.layers.append(L)
     fused_train.prepare_images(plan, dev, stem_needs_grad=True)
@@ -92,10 +95,11 @@ def test_strided_layer_forward_and_both_gradients_match_the_module_kernels(dev, 
     y = fused_train._LevelConv.apply(xr, conv.weight, L)
     rb = ops.build_rulebook(coors, 2, shape, 3, 2, 1, 1, subm=False)
     m = rb.num_out
-    assert L.lv_out.n == m and tuple(y.shape) == (m, 32)
+    assert L.lv_out.n == m and tuple(y.shape) == (m, cout)
     assert torch.equal(L.lv_out.level.indices[:m], rb.out_indices)
-    gy = (torch.randn((m, 32), generator=g, device=dev) * 0.5).half()
+    gy = (torch.randn((m, cout), generator=g, device=dev) * 0.5).half()
     y.backward(gy)
+    assert fused.geometry_status(lvl) == 0
     w16 = conv.weight.detach().half()
     y_ref = ops.sparse_conv(x, w16, rb.nbr, m)
     nbr, nbr_t = rb.conv_tables()
@@ -191,3 +195,36 @@ def test_a_step_leaves_no_cyclic_garbage_behind(dev, voxels):
     finally:
         gc.enable()
     assert grown <= 8 << 20, grown
+
+
+def test_stem_layer_filter_gradient_on_the_staged_rows_kernel(dev, voxels):
+    """The stem (5 -> 16 SubM, rows zero-padded to 8 channels for the narrow forward kernel): forward on the slab kernel, filter gradient
+    on the staged-rows kernel with the rows padded to 16 channels (the extra rows of dW dropped) — against the gather kernels; no
+    int32 table and no hash index of level 1 is built."""
+    _, coors = voxels
+    n = coors.shape[0]
+    shape = list(synth.CL_CONFIG["sparse_shape"])
+    g = torch.Generator(device=dev).manual_seed(55)
+    x5 = (torch.randn((n, 5), generator=g, device=dev) * 0.5).half()
+    gy = (torch.randn((n, 16), generator=g, device=dev) * 0.5).half()
+    conv = spconv_conv.SubMConv3d(5, 16, 3, padding=1, bias=False, indice_key="s").to(dev)
+    lvl = fused.Level(coors, n, None, 2, shape, linear_order=True)
+    lvl.frames_hint = n / 160000.0
+    plan = fused_train._Plan(None, fused_train._Lv(lvl, n), torch.float16, [conv])
+    L = fused_train._Layer(conv, plan, plan.lv1, plan.lv1)
+    assert L.variant is not None and L.wg_code and L.wg_cin == 16
+    L.issue()
+    L.issue(forward=False)
+    plan.layers.append(L)
+    fused_train.prepare_images(plan, dev, stem_needs_grad=False)
+    x = torch.nn.functional.pad(x5, (0, 3))
+    y = fused_train._LevelConv.apply(x, conv.weight, L)
+    y.backward(gy)
+    assert lvl.index is None and not lvl._subm                  # neither the hash index nor the int32 table exists
+    rb = ops.build_rulebook(coors, 2, shape, 3, 1, 1, 1, subm=True)
+    w16 = conv.weight.detach().half()
+    y_ref = ops.sparse_conv(x5, w16, rb.nbr, n)
+    nbr, nbr_t = rb.conv_tables()
+    _, dw_ref = ops.sparse_conv_backward(x5, w16, gy, nbr, nbr_t, n)
+    assert _rel(y, y_ref) <= 4e-3
+    assert tuple(conv.weight.grad.shape) == (3, 3, 3, 5, 16) and _rel(conv.weight.grad, dw_ref) <= 4e-3

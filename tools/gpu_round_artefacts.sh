@@ -37,14 +37,16 @@ head -30 gpurun_out/${RT}_spconv_layers.txt | cut -c1-200
 python tools/update_bev_pool_traffic.py gpurun_out/pmcb_infer.json $RN > gpurun_out/${RT}_bev_pool_traffic.log 2>&1; cp profiles/bev_pool_traffic.json gpurun_out/${RT}_bev_pool_traffic.json; tail -4 gpurun_out/${RT}_bev_pool_traffic.log
 # training step: lines + kernel trace of the --amp step (SKIP_TRAIN=1: the training path did not change since the last visit)
 if [ -n "$SKIP_TRAIN" ]; then find gpurun_out -name "*.db" -delete; find gpurun_out/pmcb_infer -name "*.csv" -size +4M -delete; exit 0; fi
-for mode in "--amp" ""; do
-  timeout 400 python bench.py --mode train-step --no-cpu-baseline $mode > gpurun_out/${RT}_train${mode}.log 2>&1
-  grep "^{" gpurun_out/${RT}_train${mode}.log | tail -1 > gpurun_out/${RT}_bench_line_train_step${mode}.json
-  python -c "import sys,json; d=json.load(open('gpurun_out/${RT}_bench_line_train_step${mode}.json')); print('train ${mode}', round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['config']['stage_ms'].items()})"
+for mode in "--amp" "" "--amp --train-inputs static"; do
+  tagm=$(echo "$mode" | tr -d ' ' | sed 's/--/_/g')
+  timeout 400 python bench.py --mode train-step --no-cpu-baseline $mode > gpurun_out/${RT}_train${tagm}.log 2>&1
+  grep "^{" gpurun_out/${RT}_train${tagm}.log | tail -1 > gpurun_out/${RT}_bench_line_train_step${tagm}.json
+  python -c "import sys,json; d=json.load(open('gpurun_out/${RT}_bench_line_train_step${tagm}.json')); print('train ${mode}', round(d['value'],1), round(d['ms_per_step'],2), d['config'].get('encoder_path'), {k: round(v,2) for k,v in d['config']['stage_ms'].items()})"
 done
 rm -rf gpurun_out/prof_${RT}t
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${RT}t -o b -- python $R/bench.py --mode train-step --amp --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${RT}t_run.log 2>&1)
 python tools/rocprof_summary.py gpurun_out/prof_${RT}t > gpurun_out/${RT}_train_step_amp_kernel_trace_stats.txt 2>&1
+python tools/train_timeline.py gpurun_out/prof_${RT}t > gpurun_out/${RT}_train_step_amp_timeline.txt 2>&1
 head -12 gpurun_out/${RT}_train_step_amp_kernel_trace_stats.txt | cut -c1-150
 rm -rf gpurun_out/prof_${RT}tf
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${RT}tf -o b -- python $R/bench.py --mode train-step --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${RT}tf_run.log 2>&1)
