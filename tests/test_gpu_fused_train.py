@@ -221,6 +221,18 @@ def test_stem_layer_filter_gradient_on_the_staged_rows_kernel(dev, voxels):
     y = fused_train._LevelConv.apply(x, conv.weight, L)
     y.backward(gy)
     assert lvl.index is None and not lvl._subm                  # neither the hash index nor the int32 table exists
+    # a caller that asks for the gradient of the voxel features (nobody in the reference does) gets it through the layer's table
+    fused_train.prepare_images(plan, dev, stem_needs_grad=True)
+    x5g = x5.clone().requires_grad_(True)
+    y2 = fused_train._LevelConv.apply(torch.nn.functional.pad(x5g, (0, 3)), conv.weight, L)
+    y2.backward(gy)
+    rbx = ops.build_rulebook(coors, 2, shape, 3, 1, 1, 1, subm=True)
+    nbx, nbx_t = rbx.conv_tables()
+    dx_ref, _ = ops.sparse_conv_backward(x5, conv.weight.detach().half(), gy, nbx, nbx_t, n)
+    assert tuple(x5g.grad.shape) == (n, 5) and _rel(x5g.grad, dx_ref) <= 4e-3
+    conv.weight.grad = None
+    y = fused_train._LevelConv.apply(x, conv.weight, L)
+    y.backward(gy)
     rb = ops.build_rulebook(coors, 2, shape, 3, 1, 1, 1, subm=True)
     w16 = conv.weight.detach().half()
     y_ref = ops.sparse_conv(x5, w16, rb.nbr, n)
