@@ -118,33 +118,36 @@ def _flagship(dev):
     return e.to(dev).train()
 
 
-def test_encoder_training_step_fused_vs_modules(dev, voxels):
-    """The flagship encoder in train() under autocast, twice from the same weights: the fused training path (rows promised in linear
-    order) and the module path.  Dense output, every parameter gradient, every BatchNorm buffer."""
+@pytest.mark.parametrize("amp,out_tol,cos", [(torch.float16, 2e-2, 0.999), (torch.bfloat16, 8e-2, 0.99)])
+def test_encoder_training_step_fused_vs_modules(dev, voxels, amp, out_tol, cos):
+    """The flagship encoder in train() under autocast (fp16: the reference's default hook; bf16), twice from the same weights: the fused
+    training path (rows promised in linear order) and the module path.  Dense output, every parameter gradient, every BatchNorm buffer."""
     vf, vc = voxels
     results = []
     for fused_on in (True, False):
         enc = _flagship(dev)
         enc.fused_training = fused_on
-        with torch.autocast("cuda", dtype=torch.float16):
+        with torch.autocast("cuda", dtype=amp):
             y = enc(vf, vc, 2, coors_order="linear")
         assert enc.last_path == ("fused-train" if fused_on else "modules"), (enc.last_path, enc.last_path_reason)
         (y.float().square().sum() * 1e-3).backward()
         results.append((y.detach().float(), {k: p.grad.clone() for k, p in enc.named_parameters()},
                         {k: b.clone() for k, b in enc.named_buffers()}))
     (y0, g0, b0), (y1, g1, b1) = results
-    assert y0.shape == y1.shape and float((y0 - y1).abs().max()) <= 2e-2 * (1 + float(y1.abs().max()))
+    assert y0.shape == y1.shape and float((y0 - y1).abs().max()) <= out_tol * (1 + float(y1.abs().max()))
+    rt = 2e-3 if amp == torch.float16 else 2e-2
     for k in b1:
         if b1[k].dtype.is_floating_point:
-            assert torch.allclose(b0[k], b1[k], rtol=2e-3, atol=2e-4), k
+            assert torch.allclose(b0[k], b1[k], rtol=rt, atol=rt * 0.1), k
         else:
             assert torch.equal(b0[k], b1[k]), k
     assert set(g0) == set(g1)
-    worst = max(float((g0[k] - g1[k]).abs().max()) / (1e-6 + float(g1[k].abs().max())) for k in g1)
-    assert worst <= 0.2, worst
+    if amp == torch.float16:
+        worst = max(float((g0[k] - g1[k]).abs().max()) / (1e-6 + float(g1[k].abs().max())) for k in g1)
+        assert worst <= 0.2, worst
     a = torch.cat([g0[k].reshape(-1).double() for k in g1])
     b = torch.cat([g1[k].reshape(-1).double() for k in g1])
-    assert float((a @ b) / (a.norm() * b.norm())) >= 0.999
+    assert float((a @ b) / (a.norm() * b.norm())) >= cos
 
 
 def test_fallbacks_leave_the_batchnorm_buffers_alone(dev, voxels):
