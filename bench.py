@@ -51,8 +51,12 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed number of frames per step for the WHOLE job, split over the ranks with sharding.frames_for_rank "
                          "(strong scaling); default 0 = --batch frames on every GPU (weak scaling)")
-    ap.add_argument("--overlap", choices=["auto", "chain", "pipeline", "voxel", "head", "lidar", "none"], default="auto",
-                    help="auto (default since round 5): lidar from 4 frames per step, voxel below (measured on one box, two pairs, 8 frames: "
+    ap.add_argument("--overlap", choices=["auto", "ahead", "chain", "pipeline", "voxel", "head", "lidar", "none"], default="auto",
+                    help="auto: ahead from 4 frames per step (round 6), voxel below.  ahead: software pipeline ACROSS steps over two alternating "
+                         "buffer sets — the voxelizer + rulebook chain of batch t+1 run during step t beside the camera stages and the "
+                         "convolutions of batch t; every step still pays one head and one tail and ends with batch t complete (one box, two "
+                         "pairs, 8 frames: ahead 4.43 / 4.46, lidar 4.61 / 4.64 ms).  lidar (default of round 5): the whole LiDAR branch of "
+                         "THIS batch beside the camera stages (round 5, one box, two pairs, 8 frames: "
                          "lidar 4.72 / 4.73, chain 4.81 / 4.85, head 4.83 / 4.83, voxel 4.84 / 4.85 ms; one frame: voxel 0.94, chain 1.16). "
                          "With lidar the camera kernels share the machine with the LiDAR branch, so roofline.kernel_ms is the bev_pool kernel "
                          "measured SOLO right after the timed region and kernel_ms_in_step the launch inside the step.  "
@@ -308,6 +312,9 @@ def compact_line(res, side_file=None):
         e["batch1_ms"] = g("batch1_step", "ms_per_step")
         e["batch1_lidar_branch_ms"] = g("batch1_step", "lidar_branch_ms")
         e["lidar_branch_alone_ms"] = g("lidar_branch_alone", "ms")
+        e["convolutions_alone_ms"] = g("lidar_branch_alone", "convolutions_alone_ms")
+        e["unpipelined_step_ms"] = g("unpipelined_step", "ms_per_step")
+        e["ahead_output_equals_eager"] = ex.get("ahead_output_equals_eager")
         e["bf16_frac"] = g("bev_pool_bf16_features", "frac")
         e["bf16_kernel_ms"] = g("bev_pool_bf16_features", "kernel_ms")
         e["train_amp_ms"] = g("train_step_amp", "ms_per_step")
@@ -1047,11 +1054,15 @@ def main():
         }
 
     if args.overlap == "auto":
-        args.overlap = ("lidar" if B >= 4 else "voxel") if (sp_dtype != torch.float32 and not args.no_graph) else "none"
+        args.overlap = ("ahead" if B >= 4 else "voxel") if (sp_dtype != torch.float32 and not args.no_graph) else "none"
     overlap_head = args.overlap == "head" and sp_dtype != torch.float32 and not args.no_graph
     overlap_voxel = args.overlap == "voxel" and sp_dtype != torch.float32 and not args.no_graph
     overlap_pipe = args.overlap == "pipeline" and sp_dtype != torch.float32 and not args.no_graph
     overlap_chain = args.overlap == "chain" and sp_dtype != torch.float32 and not args.no_graph
+    # ahead: software pipeline ACROSS steps — the coordinate-only half of the LiDAR branch (voxelizer + the encoder's whole rulebook
+    # chain: latency-bound integer kernels) of batch t + 1 runs underneath the convolutions of batch t; two buffer sets alternate
+    overlap_ahead = args.overlap == "ahead" and sp_dtype != torch.float32 and not args.no_graph
+    ahead_gate = os.environ.get("BEVAMD_BENCH_AHEAD_GATE", "step")   # when the next batch's head may start: step | fused | bev_pool
     chain_gate = os.environ.get("BEVAMD_BENCH_CHAIN_GATE", "1") != "0"   # A/B: 0 lets the chain start as soon as the voxelizer is done
 
     def lidar_head():
@@ -1069,8 +1080,8 @@ def main():
                 return enc(vf, vc, B, num_voxels=cnt, coors_order=coors_order)
             return enc(vf, vc, B, num_voxels=cnt, geometry=lvl)
 
-    def voxel_head():
-        vf, vc, _, cnt = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
+    def voxel_head(pl=None):
+        vf, vc, _, cnt = voxelize_batch_device(pts_list if pl is None else pl, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
                                                cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
         return vf, vc, cnt, None
 
@@ -1084,8 +1095,10 @@ def main():
 
     graph = graph_head = graph_tail = None
     overlap_lidar = args.overlap == "lidar" and not args.no_graph
-    head_stream = torch.cuda.Stream() if (overlap_head or overlap_lidar or overlap_pipe or overlap_chain) else None
+    head_prio = int(os.environ.get("BEVAMD_BENCH_HEAD_PRIO", "0"))   # A/B: -1 = the second stream (LiDAR) as a high-priority HIP stream
+    head_stream = torch.cuda.Stream(priority=head_prio) if (overlap_head or overlap_lidar or overlap_pipe or overlap_chain or overlap_ahead) else None
     graph_vox = graph_geo = None
+    ahead_sets = None
     if not args.no_graph:
         # the LiDAR branch has no host sync: capture it once, replay it per frame (HIP graph, one launch)
         side = torch.cuda.Stream()
@@ -1093,7 +1106,7 @@ def main():
         with torch.cuda.stream(side):
             if overlap_head:
                 lidar_tail(*lidar_head())
-            elif overlap_pipe or overlap_chain:
+            elif overlap_pipe or overlap_chain or overlap_ahead:
                 lidar_tail(*geometry_head(*voxel_head()))
             else:
                 lidar_branch()
@@ -1110,6 +1123,26 @@ def main():
             with torch.cuda.graph(graph_tail, pool=graph_vox.pool()):
                 state["lidar_bev"] = lidar_tail(*state["head"])
             state["n_voxels_dev"] = state["head"][2]
+            assert enc.last_path == "fused", enc.last_path_reason
+        elif overlap_ahead:
+            # two buffer sets, each with its own point clouds (set 1: other seeds), its own head graph (voxelizer + rulebook chain)
+            # and its own tail graph (21 convolutions + dense tail) in ONE private pool per set: head and tail of a set never run at
+            # the same time, the two sets do
+            pts_b = [torch.from_numpy(synth.lidar_points(seed=100003 + f)).to(dev) for f in frame_ids]
+            ahead_sets = []
+            for pl in (pts_list, pts_b):
+                with torch.cuda.stream(side):   # eager warm-up of this set's inputs
+                    lidar_tail(*geometry_head(*voxel_head(pl)))
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gh = new_graph()
+                with torch.cuda.graph(gh):
+                    hd = geometry_head(*voxel_head(pl))
+                gt = new_graph()
+                with torch.cuda.graph(gt, pool=gh.pool()):
+                    out = lidar_tail(*hd)
+                ahead_sets.append(dict(pts=pl, head=gh, tail=gt, hd=hd, out=out))
+            state["lidar_bev"], state["n_voxels_dev"] = ahead_sets[0]["out"], ahead_sets[0]["hd"][2]
             assert enc.last_path == "fused", enc.last_path_reason
         elif overlap_head:
             graph_head = new_graph()
@@ -1187,6 +1220,10 @@ def main():
     if overlap_chain:
         STAGES = ["depth_raster (voxelizer beside it on a second stream)", "fused_depth_context_pool (voxelizer beside it)",
                   "bev_pool_forward_cells (the encoder's rulebook chain beside it)", "join + sparse_encoder convolutions + dense tail, alone"]
+    if overlap_ahead:
+        STAGES = ["depth_raster (this batch's convolutions beside it on a second stream)", "fused_depth_context_pool (convolutions beside it)",
+                  "bev_pool_forward_cells (convolutions beside it)",
+                  "join: rest of this batch's convolutions + dense tail, with the NEXT batch's voxelizer + rulebook chain beside them"]
     NSTAGE = len(STAGES)
     bp_done = torch.cuda.Event() if overlap_pipe else None
     fused_done = torch.cuda.Event() if overlap_chain else None
@@ -1245,6 +1282,54 @@ def main():
         if ev:
             ev[4].record()
 
+    ahead_stream = torch.cuda.Stream() if overlap_ahead else None
+    ahead_ev = torch.cuda.Event() if overlap_ahead else None
+    state["phase"] = 0
+
+    def ahead_prime():
+        """the head of the batch the next step convolves (untimed: warm-up does it once; every timed step pays for its successor's)"""
+        ahead_sets[state["phase"]]["head"].replay()
+
+    def step_ahead(ev=None, with_bev_pool=True):
+        cur, nxt = ahead_sets[state["phase"]], ahead_sets[state["phase"] ^ 1]
+        main_stream = torch.cuda.current_stream()
+        head_stream.wait_stream(main_stream)                                  # fork
+        ahead_stream.wait_stream(main_stream)
+        with torch.cuda.stream(head_stream):
+            cur["tail"].replay()                                              # LiDAR, batch t: 21 convolutions + dense tail (its head ran during step t - 1)
+        if ahead_gate == "step":
+            with torch.cuda.stream(ahead_stream):
+                nxt["head"].replay()
+        if ev:
+            ev[0].record()
+        with torch.no_grad():
+            state["depth_img"] = vt.depth_raster(img_stub, cur["pts"], t_l2i, t_ia, t_la)
+        if ev:
+            ev[1].record()
+        plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
+        if ahead_gate == "fused":
+            ahead_ev.record(main_stream)
+            with torch.cuda.stream(ahead_stream):
+                ahead_stream.wait_event(ahead_ev)
+                nxt["head"].replay()
+        if ev:
+            ev[2].record()
+        if with_bev_pool:
+            plan.launch_forward(feats, bev)                                   # the API-level bev_pool op (one kernel; roofline)
+        if ahead_gate not in ("step", "fused"):
+            ahead_ev.record(main_stream)
+            with torch.cuda.stream(ahead_stream):
+                ahead_stream.wait_event(ahead_ev)                             # LiDAR, batch t + 1: voxelizer + rulebook chain, behind the HBM stream,
+                nxt["head"].replay()                                          # underneath the wide convolutions of batch t
+        if ev:
+            ev[3].record()
+        main_stream.wait_stream(head_stream)                                  # join: batch t is complete
+        main_stream.wait_stream(ahead_stream)                                 # ... and so is the head of batch t + 1
+        state["lidar_bev"], state["n_voxels_dev"] = cur["out"], cur["hd"][2]
+        state["phase"] ^= 1
+        if ev:
+            ev[4].record()
+
     # --overlap voxel: where the voxelizer's stream joins.  Several frames per step: in front of bev_pool — the voxelizer (0.3-0.5 ms
     # beside the camera kernels) outlasts the raster + fused pooling stages by a few tens of microseconds since the raster got faster,
     # and bev_pool's roofline figure is that of a kernel running alone (1.09 -> 1.03 ms; the wait shows in the fused pooling stage).
@@ -1257,6 +1342,8 @@ def main():
             return step_pipeline(ev)
         if overlap_chain:
             return step_chain(ev)
+        if overlap_ahead:
+            return step_ahead(ev)
         main_stream = torch.cuda.current_stream()
         if overlap_head:   # fork: LiDAR head on its own stream, underneath the camera stages
             head_stream.wait_stream(main_stream)
@@ -1293,6 +1380,8 @@ def main():
         if ev:
             ev[4].record()
 
+    if overlap_ahead:
+        ahead_prime()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -1350,7 +1439,7 @@ def main():
 
     # the roofline kernel SOLO (all ranks, right after the timed region): under --overlap chain the in-step launch shares the
     # machine with the rulebook chain; the roofline figure of the kernel itself is that of an undisturbed launch
-    shared = overlap_chain or overlap_lidar or (overlap_head and not overlap_voxel) or overlap_pipe
+    shared = overlap_chain or overlap_lidar or (overlap_head and not overlap_voxel) or overlap_pipe or overlap_ahead
     # Round 6 (the line's frac must follow from the committed kernel trace): the solo figure is the average DURATION
     # of a launch — one HIP event pair around EACH of 20 launches, which is what rocprofv3's kernel trace measures (an event between
     # two launches is a barrier: no overlap) — not the back-to-back rate of 20 launches, in which a launch's first workgroups start
@@ -1370,7 +1459,7 @@ def main():
     solo_b2b_ms = kernel_ms(lambda: plan.launch_forward(feats, bev), n=20, warm=2) if shared else None
     solo_ms = kernel_duration_ms(lambda: plan.launch_forward(feats, bev)) if shared else None
 
-    if rank == 0 and world == 1 and not args.no_extras and ((args.overlap == "none" and graph is not None) or overlap_voxel or overlap_chain or overlap_lidar):
+    if rank == 0 and world == 1 and not args.no_extras and ((args.overlap == "none" and graph is not None) or overlap_voxel or overlap_chain or overlap_lidar or overlap_ahead):
         extra = {}
         t_extra = time.perf_counter()
         # (iv) the product's step: what a deployment runs per batch — raster + fused pooling + LiDAR branch — without the API-level
@@ -1379,6 +1468,8 @@ def main():
         def product_step():
             if overlap_chain:
                 return step_chain(None, with_bev_pool=False)
+            if overlap_ahead:
+                return step_ahead(None, with_bev_pool=False)
             main_stream = torch.cuda.current_stream()
             if overlap_lidar:
                 head_stream.wait_stream(main_stream)
@@ -1403,7 +1494,8 @@ def main():
         extra["product_step"] = dict(ms_per_step=pm, frames_per_s=B * 1e3 / pm, frames=B,
                                      note="depth raster + fused depth x context pooling + LiDAR branch (schedule of the headline "
                                           "step); the API-level bev_pool kernel of the headline step left out")
-        extra["lidar_graph"] = (add_counts(graph_node_count(graph_head), graph_node_count(graph_tail)) if overlap_voxel
+        extra["lidar_graph"] = (add_counts(graph_node_count(ahead_sets[0]["head"]), graph_node_count(ahead_sets[0]["tail"])) if overlap_ahead else
+                                add_counts(graph_node_count(graph_head), graph_node_count(graph_tail)) if overlap_voxel
                                 else add_counts(add_counts(graph_node_count(graph_vox), graph_node_count(graph_geo)),
                                                 graph_node_count(graph_tail)) if overlap_chain else graph_node_count(graph))
         if overlap_chain:
@@ -1414,6 +1506,45 @@ def main():
 
             extra["lidar_branch_alone"] = dict(ms=kernel_ms(lidar_alone), frames=B,
                                                note="voxelizer, rulebook-chain and convolution graphs back to back on one stream, HIP events around 20 passes")
+        if overlap_ahead:
+            def lidar_alone():
+                ahead_sets[0]["head"].replay()
+                ahead_sets[0]["tail"].replay()
+
+            def tail_alone():
+                ahead_sets[0]["tail"].replay()
+
+            extra["lidar_branch_alone"] = dict(ms=kernel_ms(lidar_alone), frames=B, convolutions_alone_ms=kernel_ms(tail_alone),
+                                               note="head graph (voxelizer + rulebook chain) + tail graph (21 convolutions + dense tail) of one buffer "
+                                                    "set back to back on one stream, HIP events around 20 passes; convolutions_alone_ms: the tail graph only")
+            # the un-pipelined schedule of rounds 5-6 on the same box, same inputs: the whole LiDAR branch of THIS batch beside the camera stages
+            def step_unpipelined():
+                main_stream = torch.cuda.current_stream()
+                head_stream.wait_stream(main_stream)
+                with torch.cuda.stream(head_stream):
+                    ahead_sets[0]["head"].replay()
+                    ahead_sets[0]["tail"].replay()
+                with torch.no_grad():
+                    state["depth_img"] = vt.depth_raster(img_stub, pts_list, t_l2i, t_ia, t_la)
+                plan.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
+                plan.launch_forward(feats, bev)
+                main_stream.wait_stream(head_stream)
+
+            um = timed(step_unpipelined, args.steps)
+            extra["unpipelined_step"] = dict(ms_per_step=um, frames_per_s=B * 1e3 / um, frames=B,
+                                             note="every batch's voxelizer + rulebook chain + convolutions inside its own step (one stream beside the "
+                                                  "camera stages: the `lidar` schedule with the chain in front of the convolutions instead of four layers ahead)")
+            ahead_prime()   # restore the pipeline's invariant for whatever replays a step after this
+            # the pipelined step computes what the plain encoder computes: batch 0's output against an eager pass over the same clouds
+            with torch.no_grad():
+                vf0, vc0, _, cnt0 = voxelize_batch_device(pts_list, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_num_points"],
+                                                          cfg["max_voxels"][1], order=args.voxel_order, encoder_rows=enc_rows)
+                ref0 = enc(vf0, vc0, B, num_voxels=cnt0, coors_order=coors_order)
+            state["phase"] = 0
+            step_ahead()
+            torch.cuda.synchronize()
+            extra["ahead_output_equals_eager"] = bool(torch.equal(ahead_sets[0]["out"], ref0))
+            del ref0, vf0, vc0
         if overlap_voxel:
             # the LiDAR branch with nothing beside it (what stage_ms.lidar_branch measured up to round 3: under the default
             # schedule that stage no longer contains the voxelizer, which runs beside the raster / fused pooling stages)
@@ -1622,8 +1753,9 @@ def main():
                 "frames_per_step_per_gpu": B,
                 "frames_per_step": frames_per_step,
                 "inputs": "synthetic, resident in HBM; ONE calibration shared by all frames and ranks, camera rig without pitch/roll "
-                          "(the easy case of the column pooling: extra.fused_pool_rigged_ms times a pitched/rolled rig), the same "
-                          "point clouds every step (graph replay on static buffers)",
+                          "(the easy case of the column pooling: extra.fused_pool_rigged_ms times a pitched/rolled rig), "
+                          + ("two sets of point clouds alternating from step to step (graph replay on two sets of static buffers)" if overlap_ahead
+                             else "the same point clouds every step (graph replay on static buffers)"),
                 "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention; see quiet_gc)",
                 "parallelism": f"frames sharded over {world} rank(s), one process per GPU, no data-path collective"
                                + (f"; torch.distributed backend nccl (= RCCL) world size {world}" if world > 1 else ""),
@@ -1639,9 +1771,15 @@ def main():
                             "materialised-volume bev_pool stage is the API-level op of the HBM GB/s metric and is in the step "
                             "too, so the camera reduction is counted twice in `value`"},
                 "lidar_branch_eager_ms": {"voxelize": eager_vox_ms, "sparse_encoder": eager_enc_ms},
-                "hip_graph": graph is not None or graph_tail is not None,
+                "hip_graph": graph is not None or graph_tail is not None or ahead_sets is not None,
                 "voxel_order": args.voxel_order,
-                "overlap": ("chain: voxelizer graph on a second HIP stream beside depth raster + fused pooling, the encoder's rulebook-chain graph "
+                "overlap": ("ahead: software pipeline across steps, two alternating buffer sets (own point clouds). Step t = camera stages of "
+                            "batch t + its 21 convolutions and dense tail (2nd HIP stream; rulebooks built in step t-1) + voxelizer and rulebook "
+                            "chain of batch t+1 (3rd stream, started "
+                            + {"fused": "behind the fused pooling", "bev_pool": "behind bev_pool"}.get(ahead_gate, "with the step")
+                            + "), joined at the end: batch t is complete when step t ends; every step pays one head + one tail "
+                            "(extra.unpipelined_step_ms: head inside its own step). stage_ms.bev_pool: the kernel WITH the rest beside it") if overlap_ahead else
+                           ("chain: voxelizer graph on a second HIP stream beside depth raster + fused pooling, the encoder's rulebook-chain graph "
                             "on that stream beside bev_pool" + (" (gated: it starts when the fused pooling has finished)" if chain_gate else "")
                             + ", join, then the 21 convolutions + dense tail alone; stage_ms.bev_pool is the kernel WITH the chain beside it, "
                             "roofline.kernel_ms the same launch SOLO after the timed region") if overlap_chain else
@@ -1686,10 +1824,9 @@ def main():
                 "rocprof_source": rocprof_src,
                 "kernel_ms_in_step": kern_ms,
                 "frac_in_step": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "measured": ("solo: average duration of 20 launches right after the timed region, one HIP event pair around EACH launch — "
-                             "what rocprofv3's kernel trace measures (rocprof_kernel_us: the stored trace's figure); "
-                             "kernel_ms_back_to_back is the rate of 20 launches without events in between; inside the step the LiDAR "
-                             "branch shares the machine with the kernel: kernel_ms_in_step, frac_in_step") if solo_ms is not None else
+                "measured": ("solo: average duration of 20 launches right after the timed region, one HIP event pair around EACH (what "
+                             "rocprofv3's kernel trace measures; rocprof_kernel_us: the stored trace); kernel_ms_back_to_back: their rate "
+                             "without events; in the step the LiDAR branch shares the machine: kernel_ms_in_step, frac_in_step") if solo_ms is not None else
                             "in the step: HIP events around the one launch of every timed step, nothing beside it",
             },
         }
