@@ -159,7 +159,11 @@ static int run_p(const SlabArgs& sa, hipStream_t stream) {
 #define BEVAMD_SLABR_SHAPES_32(X) X(32, 4, 4, 1, 384, 0) X(32, 2, 4, 1, 192, 0)
 // IDs >= 4 carry kernel flags (spconv_slab_regw.h: 8 = baked slot metadata, block_rows code rows | FMT_BAKED128 << 16); (64, 2, 2, 2): 64-row blocks (one frame's
 // level 4 is 188 blocks of 128 rows on 256 CUs), reading the baked metadata the filter-stationary kernels share
+#ifdef BEVAMD_SLABR_EXTRA_SHAPES   // experiment builds: 64 x 64 wave tiles in 2-wave blocks (1644218)
+#define BEVAMD_SLABR_SHAPES_64(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 2, 168, 2) X(64, 4, 2, 2, 168, 8) X(64, 4, 2, 1, 168, 8) X(64, 2, 4, 1, 168, 8) X(32, 4, 4, 1, 320, 0)
+#else
 #define BEVAMD_SLABR_SHAPES_64(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 2, 168, 2) X(64, 4, 2, 2, 168, 8)
+#endif
 #define BEVAMD_SLABR_SHAPES_128(X) X(64, 4, 2, 2, 184, 0) X(64, 4, 4, 2, 320, 0) X(64, 4, 2, 2, 184, 8) X(64, 2, 2, 2, 120, 0)
 
 static inline const ShapeR* shapes_r_of(int cin, int* n) {

@@ -18,6 +18,10 @@
 #pragma once
 #include "spconv_slab.h"
 
+#ifndef BEVAMD_SLABR_EXP
+#define BEVAMD_SLABR_EXP 0   // experiment builds (tools/exp_build.sh): 1 = s_setprio around the MFMA groups, 2 = fragment reads interleaved with the MFMAs
+#endif
+
 namespace bevamd {
 namespace slab {
 
@@ -252,24 +256,53 @@ __global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64 && MT <= 4) 
       {
         const int dn = d + P::WD;
         const Sub& un = dn < TAPS ? sub[0] : (sub[1].done ? sub[0] : sub[1]);   // past the last piece: a valid, unused load
-        load_w(un, dn % TAPS, wf[dn % (P::WD + 1)]);
+        if constexpr (!(BEVAMD_SLABR_EXP & 4)) load_w(un, dn % TAPS, wf[dn % (P::WD + 1)]);
+        else if (d == 0) load_w(un, dn % TAPS, wf[dn % (P::WD + 1)]);   // ablation: one filter set per plane instead of nine
         load_slots(un, dn % TAPS, raw[dn % (P::WD + 1)]);
       }
-      if (d == 0) stage_x(sub[1], xb ^ 1);
+      if constexpr (!(BEVAMD_SLABR_EXP & 8)) { if (d == 0) stage_x(sub[1], xb ^ 1); }   // ablation 8: no row staging after the first piece
 #pragma unroll
       for (int cc = 0; cc < P::CH; ++cc) {
         const int i = d * P::CH + cc;
+#if BEVAMD_SLABR_EXP & 2   // experiment: one fragment read of unit i + 1 behind every NTW MFMAs of unit i instead of all reads in front
+        if (i + 1 < U && (i + 1) % P::CH == 0) to_offsets(sub[0], fast, raw[(d + 1) % (P::WD + 1)], xo[(d + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int nt = 0; nt < P::NTW; ++nt)
+            wt.acc[mt][nt] = mfma<DT>(wf[d % (P::WD + 1)][cc * P::NTW + nt], xa[i & 1][mt], wt.acc[mt][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < U) {
+            const int d1 = (i + 1) / P::CH, c1 = (i + 1) % P::CH;
+            const unsigned o = xo[d1 & 1][mt];
+            if constexpr (BK) xa[(i + 1) & 1][mt] = *(const u32x4*)(X + (o ^ piece_xor[c1]));
+            else xa[(i + 1) & 1][mt] = *(const u32x4*)(X + (o & 0xFFFFFu) + (((unsigned)(c1 * 4 + g4)) ^ (o >> 20)) * 16);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#else
         if (i + 1 < U) {
           if ((i + 1) % P::CH == 0) to_offsets(sub[0], fast, raw[(d + 1) % (P::WD + 1)], xo[(d + 1) & 1]);
-          fetch(i + 1);
+          if constexpr (!(BEVAMD_SLABR_EXP & 16)) fetch(i + 1);   // ablation 16: no fragment reads after the first unit
+          else if (i == 0) fetch(1);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if BEVAMD_SLABR_EXP & 1   // experiment: the wave that has its operands goes first
+        __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
         for (int nt = 0; nt < P::NTW; ++nt)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (BEVAMD_SLABR_EXP & 32) { if (nt + mt) continue; }   // ablation 32: one MFMA per unit instead of NTW * MT
             wt.acc[mt][nt] = mfma<DT>(wf[d % (P::WD + 1)][cc * P::NTW + nt], xa[i & 1][mt], wt.acc[mt][nt]);
+          }
+#if BEVAMD_SLABR_EXP & 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
     // the next piece's rows (requested nine taps ago, in front of all but the two newest filter sets) have landed; every
@@ -283,6 +316,15 @@ __global__ __launch_bounds__(RW * CW * 64, ((FLAGS & 8) && CIN > 64 && MT <= 4) 
   }
   // Epilogue scratch aliases the X buffers: every wave passed the last barrier, nobody reads X any more.  (Requesting the
   // residual rows at the start of the last plane instead of here was measured: +16 live registers, one wave per SIMD less.)
+  if constexpr (BEVAMD_SLABR_EXP & 64) {   // ablation 64: no epilogue (one store per wave keeps the accumulators alive)
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < P::NTW; ++nt) t += wt.acc[mt][nt][0] + wt.acc[mt][nt][1] + wt.acc[mt][nt][2] + wt.acc[mt][nt][3];
+    if (t == 12345.678f) ((float*)a.out)[tid] = t;
+    return;
+  }
   wt.store(aw);
 }
 

@@ -1,4 +1,6 @@
-timeout 900 python -m pytest tests/test_gpu_fused_train.py tests/test_gpu_wgrad_slab.py -x -q 2>&1 | tail -5
-for m in "" "--train-inputs static"; do
-timeout 400 python bench.py --mode train-step --amp --no-cpu-baseline $m > gpurun_out/v11_train.log 2>&1; grep "^{" gpurun_out/v11_train.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['encoder_path'], d['config']['stage_ms'], d['roofline']['kernel_ms'], d['roofline']['frac'])" || tail -20 gpurun_out/v11_train.log
-done
+timeout 900 python bench.py > gpurun_out/x6_bench.log 2> gpurun_out/x6_bench.err; tail -1 gpurun_out/x6_bench.log > gpurun_out/x6_line.json; wc -c gpurun_out/x6_line.json; python -c "
+import json
+d = json.load(open('gpurun_out/x6_line.json'))
+print(d['value'], d['ms_per_step'], d['config']['stage_ms'], d['roofline']['frac'], d['roofline']['frac_in_step']); print(d['extra']); print(d['config']['overlap'])"
+tail -3 gpurun_out/x6_bench.err
+timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-extras | tail -1 | cut -c1-400

@@ -25,7 +25,7 @@ def main():
         out = torch.empty(r, c, device=dev, dtype=torch.float16)
         us = min(timeit(lambda: torch.matmul(a, w, out=out)) for _ in range(3))
         gf = 2.0 * r * 27 * c * c / 1e9
-        print(f"dense GEMM [{r} x {27 * c}] x [{27 * c} x {c}] fp16: {us:7.1f} us = {gf / us * 1e-3:6.1f} TFLOP/s (reads {a.numel() * 2 / 1e6:.0f} MB of A: {a.numel() * 2 / us / 1e6:.2f} TB/s)", flush=True)
+        print(f"dense GEMM [{r} x {27 * c}] x [{27 * c} x {c}] fp16: {us:7.1f} us = {gf / us * 1e3:6.1f} TFLOP/s (reads {a.numel() * 2 / 1e6:.0f} MB of A: {a.numel() * 2 / us / 1e6:.2f} TB/s)", flush=True)
         del a
     # the machine's square-GEMM rate on random data, for scale
     for n in (4096, 8192):
