@@ -332,7 +332,8 @@ def compact_line(res, side_file=None):
         out["extra"] = {k: v for k, v in e.items() if v is not None}
     rs = res.get("roofline_spconv")
     if rs:
-        out["roofline_spconv"] = {k: rs.get(k) for k in ("total_us", "total_gflop", "tflops", "frac_mfma_peak", "n_layers") if k in rs}
+        out["roofline_spconv"] = {k: rs.get(k) for k in ("total_us", "total_gflop", "tflops", "frac_mfma_peak", "n_layers", "dense_tap_tflops", "gemm_yardstick_tflops",
+                                                          "dense_tap_frac_of_gemm_yardstick") if k in rs}
     bx = res.get("box")
     if bx:
         out["box"] = {k: bx[k] for k in ("gpu_unique_id", "pci", "sclk", "mclk") if k in bx}
@@ -1043,6 +1044,20 @@ def main():
             _fused.LAYER_PROFILE = None
             _fused.LAYER_PROFILE_REPS = 1
         tot_us, tot_gf = sum(l["us"] for l in layers), sum(l["gflop"] for l in layers)
+        # what the kernels ISSUE (every tap of an output-stationary tile, real pair or not) and the yardstick for it: the vendor
+        # library's square fp16 GEMM on random operands on THIS box (matrix-dense bodies clock ~1.9 GHz: EXPERIMENTS D.9)
+        dense_gf = sum(l["gflop"] / l["useful_mfma_fraction"] for l in layers if l.get("useful_mfma_fraction"))
+        ga, gb = (torch.randn(4096, 4096, device=dev, dtype=torch.float16) for _ in range(2))
+        for _ in range(3):
+            torch.matmul(ga, gb)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for _ in range(20):
+            torch.matmul(ga, gb)
+        g1.record()
+        g1.synchronize()
+        gemm_tflops = 2.0 * 4096 ** 3 * 20 / (g0.elapsed_time(g1) * 1e-3) / 1e12
+        del ga, gb
         roofline_spconv = {
             "note": "21 convolutions of the SparseEncoder, one eager pass with the rulebooks already built (HIP events around 5 back-to-back "
                     "launches of every layer, nothing beside them). FLOP = 2*pairs*Cin*Cout (real pairs only); ideal bytes = "
@@ -1050,6 +1065,9 @@ def main():
                     "The op is neither: rows live in L2 and 133 GFLOP/frame is < 0.1 ms of MFMA — fractions are for orientation.",
             "total_us": tot_us, "total_gflop": tot_gf, "tflops": tot_gf * 1e3 / tot_us, "frac_mfma_peak": tot_gf * 1e3 / tot_us / 2500.0,
             "n_layers": len(layers),
+            "dense_tap_tflops": dense_gf * 1e3 / tot_us, "gemm_yardstick_tflops": gemm_tflops,
+            "dense_tap_frac_of_gemm_yardstick": dense_gf * 1e3 / tot_us / gemm_tflops,
+            "yardstick": "torch.matmul (hipBLASLt) 4096^3 fp16 on random operands, 20 launches between HIP events, measured in this run",
             "layers": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in l.items()} for l in layers],
         }
 

@@ -1,6 +1,6 @@
-timeout 900 python bench.py > gpurun_out/x6_bench.log 2> gpurun_out/x6_bench.err; tail -1 gpurun_out/x6_bench.log > gpurun_out/x6_line.json; wc -c gpurun_out/x6_line.json; python -c "
-import json
-d = json.load(open('gpurun_out/x6_line.json'))
-print(d['value'], d['ms_per_step'], d['config']['stage_ms'], d['roofline']['frac'], d['roofline']['frac_in_step']); print(d['extra']); print(d['config']['overlap'])"
-tail -3 gpurun_out/x6_bench.err
-timeout 300 python bench.py --batch 1 --no-cpu-baseline --no-extras | tail -1 | cut -c1-400
+# filter-stationary 32 -> 32 kernel ablations (wrong results by design): 1 no row requests, 2 no fragment reads, 4 one MFMA per tap, 8 no epilogue, 16 no slot / residual requests
+timeout 300 python tools/time_slab_variant.py 32:4000112 2>&1 | grep variant
+for m in 1 2 4 8 16 6 31; do
+  BEVAMD_LIB=bevfusion_amd/lib/exp/fabl$m.so timeout 300 python tools/time_slab_variant.py 32:4000112 2>&1 | grep -E "variant|rror"
+done
+timeout 300 python tools/time_slab_variant.py 32:4000112 2>&1 | grep variant
