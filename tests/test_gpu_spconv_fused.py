@@ -175,6 +175,19 @@ def test_fused_encoder_is_graph_capturable(dev):
     assert r.returncode == 0 and "GRAPH-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_software_pipeline_across_steps_equals_eager(dev):
+    """bench.py --overlap ahead in small (graph_probe.py --ahead): the head (voxelizer + rulebook chain) of batch t + 1 replays on one
+    stream while the tail (convolutions) of batch t replays on another, two buffer sets alternating with NEW points every step;
+    every step's output equals the eager encoder bit for bit.  Child process under a hard timeout."""
+    import os
+    import subprocess
+    import sys
+
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_probe.py")
+    r = subprocess.run([sys.executable, probe, "--ahead"], capture_output=True, text=True, timeout=230)
+    assert r.returncode == 0 and "AHEAD-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_points_to_bev_batch_of_three_without_host_sync(dev):
     """voxelize_batch_device -> fused encoder (device voxel count) == synchronised voxelize_batch -> encoder, B = 3."""
     from bevfusion_amd.voxel import voxelize_batch, voxelize_batch_device

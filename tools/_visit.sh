@@ -1,4 +1,2 @@
-for rep in 1 2 3; do
-timeout 300 python tools/time_slab_variant.py 32:4000112 2>&1 | grep variant
-BEVAMD_LIB=bevfusion_amd/lib/exp/oldepi.so timeout 300 python tools/time_slab_variant.py 32:4000112 2>&1 | grep variant
-done
+timeout 300 python tests/graph_probe.py --ahead 2>&1 | tail -12
+timeout 600 python -m pytest tests/test_gpu_spconv_fused.py -x -q 2>&1 | tail -3
