@@ -51,6 +51,9 @@ int bevamd_spconv_slab_variants(int cin, int* codes, int max_n) {
 #define BEVAMD_ROW(CAP) if (cin == 32) put(slab::FSTAT_BASE + CAP);
   BEVAMD_SLABF_SHAPES_32(BEVAMD_ROW)
 #undef BEVAMD_ROW
+#define BEVAMD_ROW(CAP) if (cin == 32) put(slab::FSTAT2_BASE + CAP);
+  BEVAMD_SLABF2_SHAPES_32(BEVAMD_ROW)
+#undef BEVAMD_ROW
   return k;
 }
 

@@ -5,6 +5,7 @@
 #include "spconv_slab_persist.h"
 #include "spconv_slab_small.h"
 #include "spconv_slab_fstat.h"
+#include "spconv_slab_fstat2.h"
 
 namespace bevamd {
 namespace slab {
@@ -215,6 +216,30 @@ static int run_f(const SlabArgs& sa, hipStream_t stream) {
   BEVAMD_LAUNCH_CHECK("spconv_slabf");
   return BEVAMD_OK;
 }
+// ---- filter-stationary wave pairs (spconv_slab_fstat2.h), 32 -> 32: variant = 4100000 + CAP; same metadata as 4000000 + CAP --
+constexpr int FSTAT2_BASE = 4100000;
+#define BEVAMD_SLABF2_SHAPES_32(X) X(96) X(128)
+static inline bool fstat2_built(int cin, int variant) {
+#define BEVAMD_ROW(CAP) if (cin == 32 && variant == FSTAT2_BASE + CAP) return true;
+  BEVAMD_SLABF2_SHAPES_32(BEVAMD_ROW)
+#undef BEVAMD_ROW
+  return false;
+}
+template <int DT, int CAP>
+static int run_f2(const SlabArgs& sa, hipStream_t stream) {
+  typedef PlanF2<CAP> P;
+  static_assert(P::BYTES <= 53 * 1024, "three wave pairs per CU at least");
+  auto kern = &spconv_slabf2_kernel<DT, CAP>;
+  static PerDevice pd = {};
+  const int wg_per_xcd = resident_per_xcd(pd, kern, 128, P::BYTES);
+  if (wg_per_xcd <= 0) { set_error("spconv slab: occupancy query failed"); return BEVAMD_ERR_HIP; }
+  const long long nblk = ((long long)sa.a.m_cap + P::BM - 1) / P::BM;
+  long long gx = (nblk + 7) / 8;
+  if (gx > persistent_cap(wg_per_xcd)) gx = persistent_cap(wg_per_xcd);
+  kern<<<dim3((unsigned)(gx * 8)), dim3(128), P::BYTES, stream>>>(sa);
+  BEVAMD_LAUNCH_CHECK("spconv_slabf2");
+  return BEVAMD_OK;
+}
 template <int DT>
 int launch_f_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t stream) {
   if (cin == 32 && nt == 2 && !sa.a.row_epilogue) {
@@ -224,6 +249,9 @@ int launch_f_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t 
 #define BEVAMD_ROW(CAP) if (cin == 32 && nt == 2 && variant == FSTAT_BASE + CAP) return run_f<DT, CAP>(sa, stream);
   BEVAMD_SLABF_SHAPES_32(BEVAMD_ROW)
 #undef BEVAMD_ROW
+#define BEVAMD_ROW(CAP) if (cin == 32 && nt == 2 && variant == FSTAT2_BASE + CAP) return run_f2<DT, CAP>(sa, stream);
+  BEVAMD_SLABF2_SHAPES_32(BEVAMD_ROW)
+#undef BEVAMD_ROW
   set_error("spconv slab: no filter-stationary kernel for cin=%d, cout tiles=%d, variant=%d", cin, nt, variant);
   return BEVAMD_ERR_UNSUPPORTED;
 }
@@ -231,7 +259,7 @@ int launch_f_impl(const SlabArgs& sa, int cin, int nt, int variant, hipStream_t 
 // rows per block of any variant code (0 = none built)
 static inline int block_rows_of(int cin, int variant) {
   if (cin <= 16) return cin > 0 ? small_block_rows(cin <= 8 ? 8 : 16, variant) : 0;
-  if (variant >= FSTAT_BASE) return fstat_built(cin, variant) ? BAKED_ROWS : 0;
+  if (variant >= FSTAT_BASE) return (fstat_built(cin, variant) || fstat2_built(cin, variant)) ? BAKED_ROWS : 0;
   if (variant >= REGW_BASE) {
     const ShapeR* r = find_shape_r(cin, variant);
     if (!r) return 0;

@@ -508,7 +508,15 @@ _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and 
 # 128 channels below 4 frames: 64-row blocks (1642220: one frame's level 4 is 188 blocks of 128 rows on 256 CUs; 39.5 -> 34.0 us,
 # gather kernel 38.8) — the kernel reads the filter-stationary kernels' baked 64-row metadata (EXPERIMENTS.md C.3: the "epilogue
 # bug" of B.17 was that metadata format read as raw slots).
-_SLAB_DEFAULT = {32: 4000112, 64: 1644228, 128: 1644220}
+# Round 6: 32 channels on the filter-stationary WAVE-PAIR kernel (spconv_slab_fstat2.h, 4100128: two waves per SIMD split the input
+# channels, same baked metadata as 4000112).  One box, 8 frames, the encoder's epilogues: 139.7 / 149.8 / 154.3 us (BN + ReLU / + residual /
+# + device-side row count) against 167.0 / 171.9 / 173.6 of the one-wave kernel; inside the HIP graph 141-145 against 161-170 us per
+# layer.  The 8-frame step does not move (4.32-4.36 ms either way, three interleaved pairs of 200 steps: those layers run beside bev_pool
+# and the next batch's rulebook chain, and the three together are bound by what they share), the 4-frame step does: 2.36-2.37 against
+# 2.40-2.41 ms.  Seen once and not explained: with --overlap none (everything on one stream) the SECOND of the four layers takes
+# 250 us in every replay (layers 1, 3, 4: 141-145; same counters per dispatch under --pmc, no dependence on where the three row
+# streams lie — tools/slab_alias_probe.py); not with --overlap lidar / ahead (EXPERIMENTS D.12).
+_SLAB_DEFAULT = {32: 4100128, 64: 1644228, 128: 1644220}
 _SLAB_DEFAULT_SMALL_BATCH = {32: 1322410, 128: 1642220}   # below 4 frames per step
 _SLAB_MIN_BATCH = {}
 # The same decisions in LIVE ROWS (8 sparse frames are not 8 capped ones).  The tilings were measured on

@@ -1,6 +1,6 @@
 """Direct oracle parity of exactly what the driver's bench times ("next round" item 3).
 
-  (i)   >= 4 frames per step — the regime in which `fused._slab_variant_for` picks the filter-stationary 32-channel kernel (4000112)
+  (i)   >= 4 frames per step — the regime in which `fused._slab_variant_for` picks the filter-stationary 32-channel kernel (round 6: the wave-pair kernel 4100128)
         and the 128-channel slab kernel (1644220; 64 channels: 1644228, baked slot metadata), with level 1 in key order (narrow slab kernels 3000256 / 3100128): per level,
         the fp16 output of the first SubM layer and of the strided convolution leaving the level, each against
         `oracle.indice_conv` (float64) on the GPU's own stage input, <= 6e-4 * (1 + max|ref|) (2 x the observed error, profiles/r05_parity_observed.json);
@@ -53,7 +53,7 @@ def test_four_frame_step_every_level_vs_oracle_with_the_benchmarked_variants(dev
     lvl = fused.Level(c, c.shape[0], tot.reshape(-1)[:1].int().contiguous(), B, list(CFG["sparse_shape"]), linear_order=True)
     ind, shape = c[:n].cpu().numpy(), list(CFG["sparse_shape"])
     widths = [16, 32, 64, 128]
-    expect = {16: 3000256, 32: 4000112, 64: 1644228, 128: 1644220}
+    expect = {16: 3000256, 32: 4100128, 64: 1644228, 128: 1644220}
     down = [((3, 3, 3), (2, 2, 2), (1, 1, 1), 32), ((3, 3, 3), (2, 2, 2), (1, 1, 1), 64), ((3, 3, 3), (2, 2, 2), (1, 1, 0), 128),
             ((1, 1, 3), (1, 1, 2), (0, 0, 0), 128)]
     x = torch.zeros((lvl.n_cap, 16), dtype=torch.float16, device=dev)

@@ -1,5 +1,7 @@
-timeout 900 python bench.py --no-cpu-baseline > gpurun_out/x11_bench.log 2> gpurun_out/x11_bench.err; tail -1 gpurun_out/x11_bench.log > gpurun_out/x11_line.json; wc -c gpurun_out/x11_line.json; python -c "
-import json
-d = json.load(open('gpurun_out/x11_line.json'))
-print(d['value'], d['ms_per_step'], d['config']['stage_ms'], d['roofline']['frac'], d['roofline']['frac_in_step']); print(d['extra']); print(d['roofline_spconv'])"
-tail -3 gpurun_out/x11_bench.err
+for rep in 1 2 3; do
+for s in BEVAMD_X=0 BEVAMD_SPCONV_SLAB_VARIANTS=32:4100128; do
+env $s python bench.py --no-cpu-baseline --no-extras --steps 200 --warmup 20 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$s'.ljust(44), round(d['ms_per_step'], 3))"
+done; done

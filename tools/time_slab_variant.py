@@ -45,10 +45,21 @@ def main():
         f = torch.randn(ind.shape[0], c, device=dev).half()
         w = (torch.randn(27, c, c, device=dev) / (27 * c) ** 0.5).half()
         img = sops.make_filter_image(w.view(27, 1, 1, c, c))
+        # EPI=0 bare product, 1 folded BatchNorm + ReLU (first convolution of a block), 2 ... + residual (the second), 3 = also through
+        # the device-side row count, as the encoder's sync-free route runs it
+        epi = int(os.environ.get("EPI", "0"))
+        kw = {}
+        if epi >= 1:
+            kw = dict(bn_scale=torch.rand(c, device=dev) + 0.5, bn_shift=torch.randn(c, device=dev), relu=True)
+        if epi >= 2:
+            kw["residual"] = torch.randn(ind.shape[0], c, device=dev).half()
+        if epi >= 3:
+            kw["num_out_dev"] = torch.tensor([rb.num_out], dtype=torch.int32, device=dev)
+        out = torch.empty(ind.shape[0], c, device=dev, dtype=torch.float16)
         for v in want[c]:
             meta = sops.slab_build(rb.nbr, rb.num_out, None, sops.slab_block_rows(c, v))
-            t = min(timeit(lambda: sops.sparse_conv_slab(f, img, meta, rb.num_out, c, c, variant=v))[0] for _ in range(3))
-            print(f"{tag:24s} {c:3d}->{c:<3d} rows={rb.num_out:8d} variant {v}: {t:7.1f} us", flush=True)
+            t = min(timeit(lambda: sops.sparse_conv_slab(f, img, meta, rb.num_out, c, c, variant=v, out=out, **kw))[0] for _ in range(3))
+            print(f"{tag:24s} {c:3d}->{c:<3d} rows={rb.num_out:8d} epi {epi} variant {v}: {t:7.1f} us", flush=True)
 
 
 if __name__ == "__main__":
