@@ -513,11 +513,15 @@ _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and 
 # + device-side row count) against 167.0 / 171.9 / 173.6 of the one-wave kernel; inside the HIP graph 141-145 against 161-170 us per
 # layer.  The 8-frame step does not move (4.32-4.36 ms either way, three interleaved pairs of 200 steps: those layers run beside bev_pool
 # and the next batch's rulebook chain, and the three together are bound by what they share), the 4-frame step does: 2.36-2.37 against
-# 2.40-2.41 ms.  Seen once and not explained: with --overlap none (everything on one stream) the SECOND of the four layers takes
-# 250 us in every replay (layers 1, 3, 4: 141-145; same counters per dispatch under --pmc, no dependence on where the three row
-# streams lie — tools/slab_alias_probe.py); not with --overlap lidar / ahead (EXPERIMENTS D.12).
+# 2.40-2.41 ms.  Two waves per SIMD leave room for a neighbour: with a rulebook kernel of the next levels beside it (the encoder's own
+# geometry stream under --overlap none) a layer takes 250 us where the one-wave kernel, whose 469-register waves fill the SIMDs, took
+# 170 and let the rulebook kernel wait instead — the LiDAR branch alone is 30 us slower for it (3.46 against 3.43 ms), every shared
+# schedule (ahead, lidar) is not (EXPERIMENTS D.12).
 _SLAB_DEFAULT = {32: 4100128, 64: 1644228, 128: 1644220}
-_SLAB_DEFAULT_SMALL_BATCH = {32: 1322410, 128: 1642220}   # below 4 frames per step
+_SLAB_DEFAULT_SMALL_BATCH = {32: 1322410, 128: 1642220}   # below _SLAB_SMALL_BATCH_BELOW frames per step
+# 32 channels: the wave-pair kernel from TWO frames on (one box, encoder epilogues + device-side row count, 1 / 2 / 3 frames:
+# 1322410 29.6 / 53.2 / 74.2 us, 4000112 30.8 / 50.3 / 67.2, 4100128 29.2 / 43.5 / 58.8); 128 channels: 64-row blocks below 4 frames
+_SLAB_SMALL_BATCH_BELOW = {32: 1.5, 128: 3.5}
 _SLAB_MIN_BATCH = {}
 # The same decisions in LIVE ROWS (8 sparse frames are not 8 capped ones).  The tilings were measured on
 # capped flagship frames (160 k voxels each), so "frames" = live level-1 rows / 160 k.  The host does not know the row count on the
@@ -628,7 +632,7 @@ def _slab_variant_for(conv, lvl, cin, cout):
     frames = _frames_equivalent(lvl)
     if cin not in _SLAB_DEFAULT or frames < _SLAB_MIN_BATCH.get(cin, 1) - 0.5:
         return None
-    default = _SLAB_DEFAULT_SMALL_BATCH.get(cin, _SLAB_DEFAULT[cin]) if frames < 3.5 else _SLAB_DEFAULT[cin]
+    default = _SLAB_DEFAULT_SMALL_BATCH[cin] if frames < _SLAB_SMALL_BATCH_BELOW.get(cin, 0.0) else _SLAB_DEFAULT[cin]
     variant = _slab_overrides().get(cin, default)
     rows = ops.slab_block_rows(cin, variant)
     if rows == 0 or not ops.slab_grid_ok(lvl.shape, rows):
