@@ -13,8 +13,6 @@ timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${RT}_tests.log 2>
 rc=$?; echo "== tests rc=$rc"; grep -E "^E |FAILED|passed|failed" gpurun_out/${RT}_tests.log | tail -4 | cut -c1-300
 if [ $rc -ge 124 ]; then echo "== the test run died (rc $rc): stop"; exit 3; fi
 fi
-timeout 900 python bench.py > gpurun_out/${RT}_bench.log 2>gpurun_out/${RT}_bench.err; cp gpurun_out/bench_last_full.json gpurun_out/${RT}_bench_full.json
-echo "== bench rc=$?"; grep "^{" gpurun_out/${RT}_bench.log | tail -1 > gpurun_out/${RT}_bench_line.json; cut -c1-300 gpurun_out/${RT}_bench_line.json
 # kernel-trace stats + timeline of the default step
 rm -rf gpurun_out/prof_${RT}
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${RT} -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_${RT}_run.log 2>&1)
@@ -22,6 +20,10 @@ python tools/rocprof_summary.py gpurun_out/prof_${RT} --roofline-json gpurun_out
 grep -A2 "by setting" gpurun_out/${RT}_bench_kernel_trace_stats.txt | cut -c1-400
 python tools/graph_timeline.py gpurun_out/prof_${RT} > gpurun_out/${RT}_step_timeline.txt 2>&1
 head -3 gpurun_out/${RT}_step_timeline.txt | tail -1
+# the default line AFTER the kernel trace of this visit, whose solo split it quotes as rocprof_kernel_us (same box, same code)
+cp gpurun_out/${RT}_roofline_rocprof.json profiles/roofline_rocprof.json
+timeout 900 python bench.py > gpurun_out/${RT}_bench.log 2>gpurun_out/${RT}_bench.err; cp gpurun_out/bench_last_full.json gpurun_out/${RT}_bench_full.json
+echo "== bench rc=$?"; grep "^{" gpurun_out/${RT}_bench.log | tail -1 > gpurun_out/${RT}_bench_line.json; cut -c1-300 gpurun_out/${RT}_bench_line.json
 # single-frame timeline
 rm -rf gpurun_out/prof_${RT}b1
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_${RT}b1 -o b -- python $R/bench.py --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_${RT}b1_run.log 2>&1)
