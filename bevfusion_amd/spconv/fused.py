@@ -520,8 +520,9 @@ _SORTED_ALL = os.environ.get("BEVAMD_SPCONV_SORTED_ALL", "0") == "1"  # ... and 
 _SLAB_DEFAULT = {32: 4100128, 64: 1644228, 128: 1644220}
 _SLAB_DEFAULT_SMALL_BATCH = {32: 1322410, 128: 1642220}   # below _SLAB_SMALL_BATCH_BELOW frames per step
 # 32 channels: the wave-pair kernel from TWO frames on (one box, encoder epilogues + device-side row count, 1 / 2 / 3 frames:
-# 1322410 29.6 / 53.2 / 74.2 us, 4000112 30.8 / 50.3 / 67.2, 4100128 29.2 / 43.5 / 58.8); 128 channels: 64-row blocks below 4 frames
-_SLAB_SMALL_BATCH_BELOW = {32: 1.5, 128: 3.5}
+# 1322410 29.6 / 53.2 / 74.2 us, 4000112 30.8 / 50.3 / 67.2, 4100128 29.2 / 43.5 / 58.8); 128 channels: 64-row blocks below 2.5 frames
+# (same box, 1 / 2 / 3 / 4 frames: 1642220 34.4 / 54.7 / 85.5 / 102.2 us, 1644220 40.4 / 56.6 / 79.9 / 93.4; 3.5 until round 6)
+_SLAB_SMALL_BATCH_BELOW = {32: 1.5, 128: 2.5}
 _SLAB_MIN_BATCH = {}
 # The same decisions in LIVE ROWS (8 sparse frames are not 8 capped ones).  The tilings were measured on
 # capped flagship frames (160 k voxels each), so "frames" = live level-1 rows / 160 k.  The host does not know the row count on the

@@ -449,7 +449,7 @@ def test_tilings_follow_the_live_row_count_not_the_frame_count(dev):
 
     sparse, fs = kinds_of(1)
     dense, fd = kinds_of(10)
-    assert 0.5 < fs < 1.5 and fd == 8.0        # (the 32-channel switch-over is at 1.5 frames, the 128-channel one at 3.5) one sweep: ~23 k voxels per frame, 8 of them ~ one capped frame
+    assert 0.5 < fs < 1.5 and fd == 8.0        # (the 32-channel switch-over is at 1.5 frames, the 128-channel one at 2.5) one sweep: ~23 k voxels per frame, 8 of them ~ one capped frame
     assert sparse[(32, 32, True)] == ("slab", 1322410) and dense[(32, 32, True)] == ("slab", 4100128)
     assert sparse[(128, 128, True)] == ("slab", 1642220) and dense[(128, 128, True)] == ("slab", 1644220)   # 64-row blocks when rows are few
     assert sparse[(64, 64, True)] == dense[(64, 64, True)] == ("slab", 1644228)
