@@ -194,7 +194,11 @@ static inline const ShapeR* find_shape_r(int cin, int variant) {
 }
 // ---- filter-stationary kernels (spconv_slab_fstat.h), 32 -> 32: variant = 4000000 + CAP; 64-row blocks, BAKED slots --
 constexpr int FSTAT_BASE = 4000000;
+#ifdef BEVAMD_PROFILING   // the 96-row buffers measured slower (one wave: 3 % ; wave pairs: 148 against 143 us): sweeps only
 #define BEVAMD_SLABF_SHAPES_32(X) X(112) X(96)
+#else
+#define BEVAMD_SLABF_SHAPES_32(X) X(112)
+#endif
 static inline bool fstat_built(int cin, int variant) {
 #define BEVAMD_ROW(CAP) if (cin == 32 && variant == FSTAT_BASE + CAP) return true;
   BEVAMD_SLABF_SHAPES_32(BEVAMD_ROW)
@@ -218,7 +222,11 @@ static int run_f(const SlabArgs& sa, hipStream_t stream) {
 }
 // ---- filter-stationary wave pairs (spconv_slab_fstat2.h), 32 -> 32: variant = 4100000 + CAP; same metadata as 4000000 + CAP --
 constexpr int FSTAT2_BASE = 4100000;
+#ifdef BEVAMD_PROFILING
 #define BEVAMD_SLABF2_SHAPES_32(X) X(96) X(128)
+#else
+#define BEVAMD_SLABF2_SHAPES_32(X) X(128)
+#endif
 static inline bool fstat2_built(int cin, int variant) {
 #define BEVAMD_ROW(CAP) if (cin == 32 && variant == FSTAT2_BASE + CAP) return true;
   BEVAMD_SLABF2_SHAPES_32(BEVAMD_ROW)
