@@ -28,6 +28,7 @@ BUDGET = {
     "void bevamd::slab::spconv_slabs_kernel<1, 16, 1, 4, 4, 1, 384>": (256, "2 waves per SIMD"),
     "void bevamd::slab::spconv_slabs_kernel<1, 16, 2, 2, 4, 1, 256>": (256, "2 waves per SIMD (both output tiles in one wave: 112 filter registers)"),
     # levels 2-4
+    "void bevamd::slab::spconv_slabf2_kernel<1, 128>": (256, "round 6 default for 32 channels: a wave pair splits the input channels, 108 filter registers each, 2 waves per SIMD"),
     "void bevamd::slab::spconv_slabf_kernel<1, 112>": (512, "one wave per SIMD: the whole 27 x 32 x 32 filter in registers"),
     "void bevamd::slab::spconv_slabr_kernel<1, 64, 64, 4, 4, 2, 2, 168, 8>": (256, "2 waves per SIMD"),
     "void bevamd::slab::spconv_slabr_kernel<1, 64, 128, 8, 4, 2, 2, 184, 0>": (256, "2 waves per SIMD"),
