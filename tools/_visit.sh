@@ -1,1 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_spconv_slab.py tests/test_gpu_keyorder.py tests/test_gpu_flagship_oracle.py tests/test_gpu_fused_train.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_spconv_slab.py -x -q -m gpu 2>&1 | tail -15
+for e in 0 1 3; do EPI=$e timeout 300 python tools/time_slab_variant.py 64:1644228 64:4200128 2>&1 | grep -E "variant|rror"; done
