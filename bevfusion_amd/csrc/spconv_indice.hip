@@ -546,7 +546,11 @@ __global__ __launch_bounds__(256) void sp_dense_bev_kernel(const T* __restrict__
 // per wave instruction) instead of being read 2 bytes at a time, one row per lane, once per channel; the transposed
 // reads then come out of LDS (pitch = row + 4 bytes: an odd number of dwords, conflict-free along the row index).
 // Needs row bytes % 4 == 0 and 64*Z*(row + 4) bytes of LDS; the host falls back to the kernel above otherwise.
-template <typename T, int KIND>
+// WIDE: rows of 16 * LPR bytes with 64 % LPR == 0, 16-byte aligned (the encoder's 128-channel 16-bit rows: LPR = 16): the staging
+// loop above it was ONE dependent chain per row — row id out of LDS, 4 bytes per lane from global, LDS store, 32 times per wave:
+// ~10 us per tile of pure latency (round 6: 72 us per 8-frame step for a 190 MB kernel).  Here a wave instruction loads 64 / LPR
+// whole rows in 16-byte pieces and all of a wave's rows are in flight before the first is stored: one round trip per tile.
+template <typename T, int KIND, bool WIDE = false>
 __global__ __launch_bounds__(256) void sp_dense_bev_staged_kernel(const T* __restrict__ feat, int pitch, int C, IndexRef ix,
                                                                   int X, int Y, int Z, T* __restrict__ out) {
   extern __shared__ int rows[];  // [Z][64] row ids, then the staged rows
@@ -562,10 +566,34 @@ __global__ __launch_bounds__(256) void sp_dense_bev_staged_kernel(const T* __res
   const int row_dw = C * (int)sizeof(T) / 4, lpitch = row_dw + 1;   // dwords
   uint32_t* tile = (uint32_t*)(rows + nrows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = wave; t < nrows; t += 4) {   // one staged row per wave and trip; all loads of a trip are independent
-    const int r = rows[t];
-    const uint32_t* src = (const uint32_t*)(feat + (size_t)(r >= 0 ? r : 0) * pitch);
-    for (int j = lane; j < row_dw; j += 64) tile[t * lpitch + j] = r >= 0 ? src[j] : 0u;
+  if constexpr (WIDE) {
+    const int lpr = row_dw >> 2, rpi = 64 / lpr;        // lanes per row, rows per wave instruction
+    const int sub = lane / lpr, piece = lane - sub * lpr;
+    constexpr int U = 8;                                // wave instructions in flight: U * rpi rows per wave and trip
+    for (int t0 = wave * U * rpi; t0 < nrows; t0 += 4 * U * rpi) {
+      uint4 v[U];
+      int tt[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        tt[u] = t0 + u * rpi + sub;
+        const int r = tt[u] < nrows ? rows[tt[u]] : -1;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (r >= 0) v[u] = *(const uint4*)((const char*)feat + (size_t)r * pitch * sizeof(T) + piece * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (tt[u] < nrows) {
+          uint32_t* dst = tile + tt[u] * lpitch + piece * 4;   // the odd dword pitch keeps the transposed reads conflict-free: 4-byte stores
+          dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+        }
+      }
+    }
+  } else {
+    for (int t = wave; t < nrows; t += 4) {   // one staged row per wave and trip; all loads of a trip are independent
+      const int r = rows[t];
+      const uint32_t* src = (const uint32_t*)(feat + (size_t)(r >= 0 ? r : 0) * pitch);
+      for (int j = lane; j < row_dw; j += 64) tile[t * lpitch + j] = r >= 0 ? src[j] : 0u;
+    }
   }
   __syncthreads();
   const int CZ = C * Z;
@@ -578,6 +606,7 @@ __global__ __launch_bounds__(256) void sp_dense_bev_staged_kernel(const T* __res
     constexpr int LPP = 64 / YPL;            // lanes per plane row of the tile
     constexpr int PPI = 64 / LPP;            // planes per wave instruction
     const int sub = lane / LPP, chunk = lane % LPP;
+#pragma unroll 4   // four independent groups of LDS reads in flight per lane (the loop is a chain of LDS round trips otherwise)
     for (int idx0 = wave * PPI; idx0 < CZ; idx0 += 4 * PPI) {
       const int idx = idx0 + sub;
       if (idx >= CZ) continue;
@@ -1239,9 +1268,11 @@ int bevamd_spconv_dense_bev(const void* features, int elem_bytes, int pitch, int
   const size_t row_bytes = (size_t)channels * elem_bytes;
   const size_t staged = lds + (size_t)64 * Z * (row_bytes + 4);
   const bool stage = ((uintptr_t)out & 7) == 0 && row_bytes % 4 == 0 && ((size_t)pitch * elem_bytes) % 4 == 0 && ((uintptr_t)features & 3) == 0 && staged <= 64 * 1024;
+  const bool wide = row_bytes % 16 == 0 && row_bytes / 16 <= 64 && 64 % (row_bytes / 16) == 0 && ((size_t)pitch * elem_bytes) % 16 == 0 && ((uintptr_t)features & 15) == 0;
 #define BEVAMD_DENSE(T, KIND)                                                                                               \
   do {                                                                                                                      \
-    if (stage) sp_dense_bev_staged_kernel<T, KIND><<<grid, block, staged, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out); \
+    if (stage && wide) sp_dense_bev_staged_kernel<T, KIND, true><<<grid, block, staged, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out); \
+    else if (stage) sp_dense_bev_staged_kernel<T, KIND><<<grid, block, staged, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out); \
     else sp_dense_bev_kernel<T, KIND><<<grid, block, lds, stream>>>((const T*)features, pitch, channels, ix, X, Y, Z, (T*)out);          \
   } while (0)
   if (elem_bytes == 2) {
