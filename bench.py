@@ -316,6 +316,8 @@ def compact_line(res, side_file=None):
         e["unpipelined_step_ms"] = g("unpipelined_step", "ms_per_step")
         e["ahead_output_equals_eager"] = ex.get("ahead_output_equals_eager")
         e["varied_rig_step_ms"] = g("varied_rig_step", "ms_per_step")
+        e["alone_step_ms"] = g("bev_pool_alone_step", "ms_per_step")
+        e["alone_frac_in_step"] = g("bev_pool_alone_step", "frac_in_step")
         e["bf16_frac"] = g("bev_pool_bf16_features", "frac")
         e["bf16_kernel_ms"] = g("bev_pool_bf16_features", "kernel_ms")
         e["train_amp_ms"] = g("train_step_amp", "ms_per_step")
@@ -1082,6 +1084,11 @@ def main():
     # chain: latency-bound integer kernels) of batch t + 1 runs underneath the convolutions of batch t; two buffer sets alternate
     overlap_ahead = args.overlap == "ahead" and sp_dtype != torch.float32 and not args.no_graph
     ahead_gate = os.environ.get("BEVAMD_BENCH_AHEAD_GATE", "step")   # when the next batch's head may start: step | fused | bev_pool
+    # ahead, BEVAMD_BENCH_BEVPOOL_ALONE=1: the API-level bev_pool kernel first and ALONE, every other stream of the step forked behind
+    # it — the roofline kernel at its solo rate INSIDE the timed step (0.61-0.62 of 8 TB/s in the step against 0.36-0.37) for 2.5 % of
+    # the step (4.53 against 4.42 ms, three interleaved pairs on one box); the default keeps the faster schedule and reports this one
+    # as extra.alone_step_ms / alone_frac_in_step
+    bev_pool_alone = overlap_ahead and os.environ.get("BEVAMD_BENCH_BEVPOOL_ALONE", "0") == "1"
     chain_gate = os.environ.get("BEVAMD_BENCH_CHAIN_GATE", "1") != "0"   # A/B: 0 lets the chain start as soon as the voxelizer is done
 
     def lidar_head():
@@ -1302,6 +1309,7 @@ def main():
             ev[4].record()
 
     ahead_stream = torch.cuda.Stream() if overlap_ahead else None
+    state["bev_pool_alone"] = bev_pool_alone
     ahead_ev = torch.cuda.Event() if overlap_ahead else None
     state["phase"] = 0
 
@@ -1309,40 +1317,49 @@ def main():
         """the head of the batch the next step convolves (untimed: warm-up does it once; every timed step pays for its successor's)"""
         ahead_sets[state["phase"]]["head"].replay()
 
-    def step_ahead(ev=None, with_bev_pool=True, pl=None):
+    def step_ahead(ev=None, with_bev_pool=True, pl=None, alone=None):
         pl = pl or plan
+        bev_pool_alone = state.get("bev_pool_alone", False) if alone is None else alone
         cur, nxt = ahead_sets[state["phase"]], ahead_sets[state["phase"] ^ 1]
         main_stream = torch.cuda.current_stream()
+        if ev:
+            ev[0].record()
+        if bev_pool_alone:
+            # the API-level bev_pool op (one kernel; roofline) FIRST and with nothing beside it: every other stream forks behind it.
+            # Beside the convolutions the HBM stream and the layers slow each other by more than they overlap (EXPERIMENTS D.15)
+            if with_bev_pool:
+                pl.launch_forward(feats, bev)
+            if ev:
+                ev[1].record()
         head_stream.wait_stream(main_stream)                                  # fork
         ahead_stream.wait_stream(main_stream)
         with torch.cuda.stream(head_stream):
             cur["tail"].replay()                                              # LiDAR, batch t: 21 convolutions + dense tail (its head ran during step t - 1)
-        if ahead_gate == "step":
+        if ahead_gate == "step" or bev_pool_alone:
             with torch.cuda.stream(ahead_stream):
                 nxt["head"].replay()
-        if ev:
-            ev[0].record()
         with torch.no_grad():
             state["depth_img"] = vt.depth_raster(img_stub, cur["pts"], t_l2i, t_ia, t_la)
         if ev:
-            ev[1].record()
+            ev[2 if bev_pool_alone else 1].record()
         pl.launch_fused(depth_prob.view(-1), ctx_cl, dbins, fh, fw, out=fused_out)
-        if ahead_gate == "fused":
+        if ahead_gate == "fused" and not bev_pool_alone:
             ahead_ev.record(main_stream)
             with torch.cuda.stream(ahead_stream):
                 ahead_stream.wait_event(ahead_ev)
                 nxt["head"].replay()
         if ev:
-            ev[2].record()
-        if with_bev_pool:
-            pl.launch_forward(feats, bev)                                   # the API-level bev_pool op (one kernel; roofline)
-        if ahead_gate not in ("step", "fused"):
-            ahead_ev.record(main_stream)
-            with torch.cuda.stream(ahead_stream):
-                ahead_stream.wait_event(ahead_ev)                             # LiDAR, batch t + 1: voxelizer + rulebook chain, behind the HBM stream,
-                nxt["head"].replay()                                          # underneath the wide convolutions of batch t
-        if ev:
-            ev[3].record()
+            ev[3 if bev_pool_alone else 2].record()
+        if not bev_pool_alone:
+            if with_bev_pool:
+                pl.launch_forward(feats, bev)                               # the API-level bev_pool op, beside the LiDAR streams
+            if ahead_gate not in ("step", "fused"):
+                ahead_ev.record(main_stream)
+                with torch.cuda.stream(ahead_stream):
+                    ahead_stream.wait_event(ahead_ev)                         # LiDAR, batch t + 1: voxelizer + rulebook chain, behind the HBM stream,
+                    nxt["head"].replay()                                      # underneath the wide convolutions of batch t
+            if ev:
+                ev[3].record()
         main_stream.wait_stream(head_stream)                                  # join: batch t is complete
         main_stream.wait_stream(ahead_stream)                                 # ... and so is the head of batch t + 1
         state["lidar_bev"], state["n_voxels_dev"] = cur["out"], cur["hd"][2]
@@ -1418,7 +1435,7 @@ def main():
     stage_ms = [float(np.mean([e[s].elapsed_time(e[s + 1]) for e in evs])) for s in range(NSTAGE)]
     state["n_voxels"] = int(state["n_voxels_dev"].reshape(-1)[0])
     assert tuple(state["lidar_bev"].shape) == (B, 256, 180, 180)
-    if overlap_pipe:   # report in the canonical order (raster, fused pooling, bev_pool, LiDAR)
+    if overlap_pipe or bev_pool_alone:   # report in the canonical order (raster, fused pooling, bev_pool, LiDAR)
         stage_ms = [stage_ms[1], stage_ms[2], stage_ms[0], stage_ms[3]]
     kern_ms = stage_ms[2]  # the bev_pool stage is exactly one kernel launch
     fused_ms = stage_ms[1]
@@ -1604,6 +1621,19 @@ def main():
                                                      "pitched within +-1.5 deg and rolled within +-1 deg (synth.rigged_geometry), plans built "
                                                      "outside the step as at inference")
                 del plan_v
+                # (v'') the step with the API-level bev_pool kernel FIRST and ALONE (every other stream forked behind it): what the
+                # roofline kernel does INSIDE a step when nothing shares the machine with it, and what that schedule costs
+                am = timed(lambda: step_ahead(None, alone=True), args.steps)
+                aevs = [[torch.cuda.Event(enable_timing=True) for _ in range(NSTAGE + 1)] for _ in range(10)]
+                for e5 in aevs:
+                    step_ahead(e5, alone=True)
+                torch.cuda.synchronize()
+                ak = float(np.mean([e5[0].elapsed_time(e5[1]) for e5 in aevs]))
+                extra["bev_pool_alone_step"] = dict(ms_per_step=am, frames_per_s=B * 1e3 / am, kernel_ms_in_step=ak,
+                                                    frac_in_step=(n_kept * C * elem + n_int * 24 + B * D * H * W * C * 4) / (ak * 1e-3) / 8e12,
+                                                    note="--overlap ahead with the bev_pool launch in front of the fork: nothing runs beside "
+                                                         "the roofline kernel, the step pays for it (BEVAMD_BENCH_BEVPOOL_ALONE=1 makes it the "
+                                                         "timed schedule)")
         except Exception as e:
             extra["fused_pool"] = dict(error=repr(e)[:300])
         # (i) BASELINE configs[1]: bev_pool on bf16 camera features, same plan, same launch

@@ -1,2 +1,7 @@
-# scratch: the command list of the current GPU visit (overwritten per visit; tools/gpu_visit.sh and tools/gpu_round_artefacts.sh are the kept ones)
-timeout 900 python -m pytest tests/test_gpu_spconv_slab.py -x -q -m gpu 2>&1 | tail -3
+for rep in 1 2 3; do
+for s in BEVAMD_BENCH_BEVPOOL_ALONE=0 BEVAMD_BENCH_BEVPOOL_ALONE=1; do
+env $s python bench.py --no-cpu-baseline --no-extras --steps 100 --warmup 10 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$s'.ljust(36), round(d['ms_per_step'], 3), {k: round(v, 3) for k, v in d['config']['stage_ms'].items()}, round(d['roofline']['frac_in_step'],3))"
+done; done
