@@ -1888,9 +1888,9 @@ def main():
                 "rocprof_source": rocprof_src,
                 "kernel_ms_in_step": kern_ms,
                 "frac_in_step": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "measured": ("solo: average duration of 20 launches right after the timed region, one HIP event pair around EACH (what "
-                             "rocprofv3's kernel trace measures; rocprof_kernel_us: the stored trace); kernel_ms_back_to_back: their rate "
-                             "without events; in the step the LiDAR branch shares the machine: kernel_ms_in_step, frac_in_step") if solo_ms is not None else
+                "measured": ("solo: mean duration of 20 launches after the timed region, one HIP event pair around EACH (as a kernel "
+                             "trace measures; rocprof_kernel_us: the stored trace); kernel_ms_in_step: with the LiDAR streams beside it "
+                             "(extra.alone_frac_in_step: first and alone in the step)") if solo_ms is not None else
                             "in the step: HIP events around the one launch of every timed step, nothing beside it",
             },
         }
