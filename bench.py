@@ -271,6 +271,14 @@ def _r(v, sig=5):
     return v
 
 
+def _backend_name():
+    """'nccl (= RCCL)' on a multi-GPU node; 'gloo' under BEVAMD_BENCH_SHARED_GPU (tests: several ranks on one device)"""
+    import torch.distributed as dist
+
+    b = dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"
+    return "nccl (= RCCL)" if b == "nccl" else b
+
+
 def compact_line(res, side_file=None):
     """The ONE line the driver parses, from the full result `res` (which goes to the side file): the contract keys, the
     roofline of the dominant kernel, the CPU baseline's figures, the secondary measurements as bare numbers.  No per-layer tables,
@@ -883,7 +891,7 @@ def train_step(args, rank, world, frame_ids, dev):
                        "frames_per_step_per_gpu": B, "frames_per_step": frames_per_step, "stage_ms": stage,
                        "per_step_ms": per_step_ms, "encoder_fwd_per_step_ms": fwd_step_ms,
                        "host_gc": "Python's cyclic collector is off inside the timed region (timeit's convention; see quiet_gc)",
-                       "gradient_allreduce": (f"DistributedDataParallel over torch.distributed nccl (= RCCL), world {world}, "
+                       "gradient_allreduce": (f"DistributedDataParallel over torch.distributed {_backend_name()}, world {world}, "
                                               f"{nparam * 4 / 1e6:.1f} MB per step") if world > 1 else "single rank: none"},
             "roofline": {"kernel": "bev_pool_bwd_points_vec_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -910,11 +918,15 @@ def main():
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): using {world}", file=sys.stderr)
     if not args.dry_run and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback); --dry-run exercises the launch logic")
+    # tests on a ONE-GPU box (tests/test_gpu_bench_multirank.py): every rank on device 0, collectives over gloo — the whole N > 1
+    # control flow of the REAL step (per-rank frames, plans, HIP graphs, barriers, max over ranks, rank-0 line) without a second GPU.
+    # RCCL refuses two ranks on one device; the RCCL path itself is tests/test_gpu_ddp.py
+    shared_gpu = os.environ.get("BEVAMD_BENCH_SHARED_GPU", "0") == "1"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dry_run:
+        if args.dry_run or shared_gpu:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" == RCCL on ROCm
@@ -938,7 +950,7 @@ def main():
         return
     if not frame_ids:
         raise SystemExit(f"rank {rank}: no frames to process (--global-batch {args.global_batch} < {world} ranks)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if shared_gpu else local_rank)
     torch.cuda.set_device(dev)
     from bevfusion_amd.sharding import bind_rank_to_cpus
 
