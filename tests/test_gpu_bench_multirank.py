@@ -20,6 +20,11 @@ def run_bench(*flags):
     env["BEVAMD_BENCH_SHARED_GPU"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *flags]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    if r.returncode != 0 and "ChildFailedError" in r.stderr:
+        # a rank aborted inside the gloo rendezvous / teardown (rare, never reproduced in isolation: tests/test_bench_launch.py):
+        # one more try — a deterministic failure fails again
+        print("bench.py launch retried after:", r.stderr[-600:], file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
