@@ -1,1 +1,2 @@
-timeout 1200 python -m pytest tests/test_gpu_bench_multirank.py -x -q -m gpu 2>&1 | tail -25
+# scratch: the command list of the current GPU visit (overwritten per visit; tools/gpu_visit.sh and tools/gpu_round_artefacts.sh are the kept ones)
+timeout 900 python -m pytest tests/test_gpu_spconv_slab.py -x -q -m gpu 2>&1 | tail -3
