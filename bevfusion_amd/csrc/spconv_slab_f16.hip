@@ -129,6 +129,8 @@ int bevamd_spconv_conv_forward_slab(const void* features, int dtype, int feat_st
                  "spconv_conv_forward_slab: feature pitch %d must be a multiple of 8 and >= %d, 16-byte aligned", feat_stride, cinp);
   BEVAMD_REQUIRE((unsigned long long)num_in * (unsigned long long)feat_stride * 2ull < 0x100000000ull,
                  "spconv_conv_forward_slab: the feature tensor must be smaller than 4 GiB (buffer descriptor)");
+  BEVAMD_REQUIRE(!residual || (unsigned long long)num_out * (unsigned long long)residual_stride * 2ull < 0x100000000ull,
+                 "spconv_conv_forward_slab: the residual tensor must be smaller than 4 GiB (buffer descriptor)");
   BEVAMD_REQUIRE(((uintptr_t)image & 15) == 0 && ((uintptr_t)slots & 15) == 0, "spconv_conv_forward_slab: image / slots must be 16-byte aligned");
   BEVAMD_REQUIRE(out_stride >= cout && (!residual || residual_stride >= cout), "spconv_conv_forward_slab: bad output pitch");
   BEVAMD_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "spconv_conv_forward_slab: scale and shift go together");
