@@ -52,7 +52,7 @@ def parse():
                     help="fixed number of frames per step for the WHOLE job, split over the ranks with sharding.frames_for_rank "
                          "(strong scaling); default 0 = --batch frames on every GPU (weak scaling)")
     ap.add_argument("--overlap", choices=["auto", "ahead", "chain", "pipeline", "voxel", "head", "lidar", "none"], default="auto",
-                    help="auto: ahead from 4 frames per step (round 6), voxel below.  ahead: software pipeline ACROSS steps over two alternating "
+                    help="auto: ahead from 2 frames per step (round 6; 1.39 / 1.96 ms against 1.52 / 2.06 at 2 / 3 frames), voxel for a single frame (a latency figure).  ahead: software pipeline ACROSS steps over two alternating "
                          "buffer sets — the voxelizer + rulebook chain of batch t+1 run during step t beside the camera stages and the "
                          "convolutions of batch t; every step still pays one head and one tail and ends with batch t complete (one box, two "
                          "pairs, 8 frames: ahead 4.43 / 4.46, lidar 4.61 / 4.64 ms).  lidar (default of round 5): the whole LiDAR branch of "
@@ -1087,7 +1087,7 @@ def main():
         }
 
     if args.overlap == "auto":
-        args.overlap = ("ahead" if B >= 4 else "voxel") if (sp_dtype != torch.float32 and not args.no_graph) else "none"
+        args.overlap = ("ahead" if B >= 2 else "voxel") if (sp_dtype != torch.float32 and not args.no_graph) else "none"
     overlap_head = args.overlap == "head" and sp_dtype != torch.float32 and not args.no_graph
     overlap_voxel = args.overlap == "voxel" and sp_dtype != torch.float32 and not args.no_graph
     overlap_pipe = args.overlap == "pipeline" and sp_dtype != torch.float32 and not args.no_graph

@@ -2,7 +2,7 @@
 BEVAMD_BENCH_SHARED_GPU=1 puts both ranks on device 0 and runs the collectives over gloo (RCCL refuses two ranks on one device; the
 RCCL path itself is test_gpu_ddp.py).  Everything else is what the driver's 8-GPU launch runs: bench.py re-spawns itself under
 torch.distributed.run on 127.0.0.1, every rank gets its own frame ids, builds its own plans and HIP graphs (the pipelined schedule
-from 4 frames per step), the timed region is bracketed by barriers, rank 0 prints ONE line with the max over ranks."""
+from 2 frames per step), the timed region is bracketed by barriers, rank 0 prints ONE line with the max over ranks."""
 import json
 import os
 import subprocess
@@ -32,7 +32,7 @@ def run_bench(*flags):
 
 
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
-@pytest.mark.parametrize("batch", [2, 4])   # 2: the `voxel` schedule, 4: the software pipeline across steps
+@pytest.mark.parametrize("batch", [2, 4])   # both on the software pipeline across steps (two buffer sets per rank)
 def test_two_ranks_weak_scaling_on_one_device(batch):
     res = run_bench("--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", str(batch), "--no-cpu-baseline", "--no-extras")
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 4 and res["warmup"] == 2
